@@ -1,0 +1,192 @@
+"""ctypes wrapper over oracle/liborb_oracle.so.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py — never from the product package.  PARITY UNPINNED
+(see oracle/orb_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liborb_oracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "orb_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+_lib = None
+
+
+class FeatSet(C.Structure):
+    _fields_ = [("n", C.c_int), ("desc", C.c_void_p), ("nnodes", C.c_int), ("node_id", C.c_void_p),
+                ("node_off", C.c_void_p), ("feat", C.c_void_p), ("flag", C.c_void_p), ("angle", C.c_void_p),
+                ("x", C.c_void_p), ("y", C.c_void_p), ("octave", C.c_void_p), ("u_right", C.c_void_p)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.oracle_create.restype = C.c_void_p
+        L.oracle_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.oracle_destroy.argtypes = [C.c_void_p]
+        for f in ("oracle_scale_factors", "oracle_inv_scale_factors", "oracle_level_sigma2", "oracle_inv_level_sigma2"):
+            getattr(L, f).restype = C.POINTER(C.c_float)
+            getattr(L, f).argtypes = [C.c_void_p]
+        for f in ("oracle_features_per_level", "oracle_umax"):
+            getattr(L, f).restype = C.POINTER(C.c_int)
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.oracle_extract.restype = C.c_int
+        L.oracle_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_level_dims.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.oracle_level_pixels.restype = C.c_void_p
+        L.oracle_level_pixels.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_level_blurred.restype = C.c_void_p
+        L.oracle_level_blurred.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_level_nkeypoints.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_cv_round_f.argtypes = [C.c_float]
+        L.oracle_fast_atan2.restype = C.c_float
+        L.oracle_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.oracle_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.oracle_fast_score.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.oracle_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_size_t]
+        L.oracle_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.oracle_distribute_octtree.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_hamming.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.oracle_search_by_bow_kf_f.argtypes = [C.POINTER(FeatSet), C.POINTER(FeatSet), C.c_float, C.c_int, C.c_void_p]
+        L.oracle_search_by_bow_kf_kf.argtypes = [C.POINTER(FeatSet), C.POINTER(FeatSet), C.c_float, C.c_int, C.c_void_p]
+        L.oracle_search_for_triangulation.argtypes = [C.POINTER(FeatSet), C.POINTER(FeatSet), C.c_void_p, C.c_float, C.c_float,
+                                                      C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_three_maxima.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """One ORBextractor instance of the CPU oracle (keeps its pyramid after extract)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        self.h = self.L.oracle_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        if not self.h:
+            raise ValueError("oracle_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oracle_destroy(self.h)
+            self.h = None
+
+    def _farr(self, fn, n=None):
+        return np.ctypeslib.as_array(fn(self.h), shape=(n or self.nlevels,)).copy()
+
+    def scale_factors(self): return self._farr(self.L.oracle_scale_factors)
+    def inv_scale_factors(self): return self._farr(self.L.oracle_inv_scale_factors)
+    def level_sigma2(self): return self._farr(self.L.oracle_level_sigma2)
+    def inv_level_sigma2(self): return self._farr(self.L.oracle_inv_level_sigma2)
+    def features_per_level(self): return self._farr(self.L.oracle_features_per_level)
+    def umax(self): return self._farr(self.L.oracle_umax, 16)
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        cap = self.nfeatures + 4 * self.nlevels + 64
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n = self.L.oracle_extract(self.h, _p(img), w, h, img.strides[0], _p(kps), _p(desc), cap)
+        if n < 0:
+            raise RuntimeError(f"oracle_extract failed: {n}")
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level(self, l, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        assert self.L.oracle_level_dims(self.h, l, C.byref(w), C.byref(h)) == 0
+        ptr = (self.L.oracle_level_blurred if blurred else self.L.oracle_level_pixels)(self.h, l)
+        if not ptr:
+            return None
+        buf = (C.c_uint8 * (w.value * h.value)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(h.value, w.value).copy()
+
+    def candidates(self, l):
+        n = self.L.oracle_level_candidates(self.h, l, None, None, None, 0)
+        x = np.zeros(n, np.int32); y = np.zeros(n, np.int32); r = np.zeros(n, np.int32)
+        self.L.oracle_level_candidates(self.h, l, _p(x), _p(y), _p(r), n)
+        return x, y, r
+
+    def nkeypoints(self, l):
+        return self.L.oracle_level_nkeypoints(self.h, l)
+
+
+def stereo_match(oL, oR, kL, dL, kR, dR, bf, min_z):
+    kL = np.ascontiguousarray(kL); kR = np.ascontiguousarray(kR)
+    dL = np.ascontiguousarray(dL); dR = np.ascontiguousarray(dR)
+    ur = np.zeros(len(kL), np.float32); dp = np.zeros(len(kL), np.float32)
+    rc = lib().oracle_stereo_match(oL.h, oR.h, _p(kL), _p(dL), len(kL), _p(kR), _p(dR), len(kR), bf, min_z, _p(ur), _p(dp))
+    assert rc == 0
+    return ur, dp
+
+
+def hamming(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().oracle_hamming(_p(a), _p(b))
+
+
+def make_featset(fs):
+    """fs: dict with desc [n,32] u8, node_id u32, node_off i32, feat u32, flag u8, angle f32,
+    optional x,y f32, octave i32, u_right f32.  Returns (FeatSet, keepalive)."""
+    keep = {}
+    def arr(k, dt):
+        if fs.get(k) is None:
+            return None
+        keep[k] = np.ascontiguousarray(fs[k], dtype=dt)
+        return keep[k].ctypes.data
+    s = FeatSet()
+    s.desc = arr("desc", np.uint8)
+    s.n = len(keep["desc"])
+    s.node_id = arr("node_id", np.uint32); s.node_off = arr("node_off", np.int32); s.feat = arr("feat", np.uint32)
+    s.nnodes = len(keep["node_id"])
+    s.flag = arr("flag", np.uint8); s.angle = arr("angle", np.float32)
+    s.x = arr("x", np.float32); s.y = arr("y", np.float32)
+    s.octave = arr("octave", np.int32); s.u_right = arr("u_right", np.float32)
+    return s, keep
+
+
+def search_by_bow_kf_f(kf, f, nnratio, check_ori):
+    a, ka = make_featset(kf); b, kb = make_featset(f)
+    out = np.full(b.n, -1, np.int32)
+    n = lib().oracle_search_by_bow_kf_f(C.byref(a), C.byref(b), nnratio, int(check_ori), _p(out))
+    return out, n
+
+
+def search_by_bow_kf_kf(k1, k2, nnratio, check_ori):
+    a, ka = make_featset(k1); b, kb = make_featset(k2)
+    out = np.full(a.n, -1, np.int32)
+    n = lib().oracle_search_by_bow_kf_kf(C.byref(a), C.byref(b), nnratio, int(check_ori), _p(out))
+    return out, n
+
+
+def search_for_triangulation(k1, k2, F12, ex, ey, sf2, sig2, nnratio, check_ori, only_stereo):
+    a, ka = make_featset(k1); b, kb = make_featset(k2)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sf2 = np.ascontiguousarray(sf2, np.float32); sig2 = np.ascontiguousarray(sig2, np.float32)
+    pairs = np.zeros((a.n, 2), np.int32)
+    n = lib().oracle_search_for_triangulation(C.byref(a), C.byref(b), _p(F), ex, ey, _p(sf2), _p(sig2),
+                                              nnratio, int(check_ori), int(only_stereo), _p(pairs), a.n)
+    return pairs[:n].copy()

@@ -1,0 +1,120 @@
+/*
+ * orb_oracle.h — CPU restatement of the ORB-SLAM2 feature front end + Hamming matchers.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (orb-slam2_amd/, include/)
+ * includes, links or calls this; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may use it, and only as the checker / timed baseline.
+ *
+ * PARITY UNPINNED: the reference (zhuwsh/ORB-SLAM2) has no tests or golden vectors, and
+ * its arithmetic partly lives in OpenCV (>=2.4.3, "tested with 2.4.11 and 3.2",
+ * reference README.md:68), which is neither vendored nor installed here, so the reference
+ * cannot be compiled (src/ORBextractor.cc:57 fails at #include <opencv2/core/core.hpp>).
+ * This file restates the reference's own code (citations per function) plus the published
+ * OpenCV-3.2 generic-C++ (non-IPP) algorithms for resize/FAST/GaussianBlur/fastAtan2/cvRound
+ * (SURVEY.md Appendix B).  It is pinned only by the handful of known answers the reference
+ * text holds (umax table, feature quotas, thresholds: see tests/test_oracle_known_answers.py).
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* == cv::KeyPoint, 28 bytes (reference include/ORBextractor.h:74-76 output type) */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} oracle_kp;
+
+typedef struct orb_oracle orb_oracle;
+
+/* ORBextractor::ORBextractor, src/ORBextractor.cc:429-534 */
+orb_oracle *oracle_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th);
+void oracle_destroy(orb_oracle *o);
+
+/* tables (E0/E9): each array has nlevels entries */
+int oracle_nlevels(const orb_oracle *o);
+const float *oracle_scale_factors(const orb_oracle *o);
+const float *oracle_inv_scale_factors(const orb_oracle *o);
+const float *oracle_level_sigma2(const orb_oracle *o);
+const float *oracle_inv_level_sigma2(const orb_oracle *o);
+const int *oracle_features_per_level(const orb_oracle *o);
+const int *oracle_umax(const orb_oracle *o); /* 16 entries */
+
+/* ORBextractor::operator(), src/ORBextractor.cc:1261-1339.
+ * Returns number of keypoints (<= cap) or <0 on error (-1 bad args, -2 cap too small,
+ * -3 image too small for the cell grid: the reference divides by zero there). */
+int oracle_extract(orb_oracle *o, const uint8_t *img, int w, int h, size_t stride,
+                   oracle_kp *kps, uint8_t *desc, int cap);
+
+/* stage dumps, valid after oracle_extract */
+int oracle_level_dims(const orb_oracle *o, int level, int *w, int *h);
+const uint8_t *oracle_level_pixels(const orb_oracle *o, int level); /* tightly packed w*h */
+const uint8_t *oracle_level_blurred(const orb_oracle *o, int level); /* tightly packed w*h */
+/* FAST candidates of a level in reference order, coordinates relative to (16,16) */
+int oracle_level_candidates(const orb_oracle *o, int level, int *x, int *y, int *resp, int cap);
+int oracle_level_nkeypoints(const orb_oracle *o, int level);
+
+/* single primitives, exposed for unit tests */
+int oracle_cv_round_f(float v);
+float oracle_fast_atan2(float y, float x);
+void oracle_sincos(float angle_rad, float *s, float *c);
+int oracle_fast_score(const uint8_t *center, int stride, int threshold); /* 0 if not a corner */
+void oracle_resize_linear(const uint8_t *src, int sw, int sh, size_t sstride,
+                          uint8_t *dst, int dw, int dh, size_t dstride);
+void oracle_gaussian_blur7(const uint8_t *src, int w, int h, size_t sstride, uint8_t *dst, size_t dstride);
+int oracle_distribute_octtree(const int *x, const int *y, const int *resp, int n,
+                              int min_x, int max_x, int min_y, int max_y, int nfeat, int *out_idx, int cap);
+
+/* ORBmatcher::DescriptorDistance, src/ORBmatcher.cc:1733-1749 */
+int oracle_hamming(const uint8_t *a, const uint8_t *b);
+
+/* Frame::ComputeStereoMatches, src/Frame.cc:577-751.  L and R must each have run
+ * oracle_extract on the left / right image (their unblurred pyramids are read). */
+int oracle_stereo_match(const orb_oracle *L, const orb_oracle *R,
+                        const oracle_kp *kL, const uint8_t *dL, int nL,
+                        const oracle_kp *kR, const uint8_t *dR, int nR,
+                        float bf, float min_z, float *u_right, float *depth);
+
+/* DBoW2::FeatureVector flattened to CSR */
+typedef struct {
+    int n;                  /* features */
+    const uint8_t *desc;    /* [n][32] */
+    int nnodes;
+    const uint32_t *node_id; /* [nnodes] ascending */
+    const int32_t *node_off; /* [nnodes+1] */
+    const uint32_t *feat;    /* [node_off[nnodes]] ascending inside each node */
+    const uint8_t *flag;     /* [n] meaning depends on the search (see each function) */
+    const float *angle;      /* [n] keypoint angle (degrees) */
+    const float *x, *y;      /* [n] undistorted keypoint position (triangulation only) */
+    const int32_t *octave;   /* [n] (triangulation only) */
+    const float *u_right;    /* [n] (triangulation only), <0 = mono */
+} oracle_featset;
+
+/* ORBmatcher::SearchByBoW(KeyFrame*,Frame&,...), src/ORBmatcher.cc:171-303.
+ * kf.flag[i]!=0 <=> KF feature i has a non-bad MapPoint.  match_f[nF] = KF index or -1. */
+int oracle_search_by_bow_kf_f(const oracle_featset *kf, const oracle_featset *f,
+                              float nnratio, int check_ori, int32_t *match_f);
+/* ORBmatcher::SearchByBoW(KeyFrame*,KeyFrame*,...), src/ORBmatcher.cc:568-702.
+ * flag!=0 <=> non-bad MapPoint on that side.  match12[n1] = KF2 index or -1. */
+int oracle_search_by_bow_kf_kf(const oracle_featset *k1, const oracle_featset *k2,
+                               float nnratio, int check_ori, int32_t *match12);
+/* ORBmatcher::SearchForTriangulation, src/ORBmatcher.cc:704-871 (+CheckDistEpipolarLine :147-164).
+ * flag!=0 <=> the feature already HAS a MapPoint (such features are skipped).
+ * pairs[2*cap] receives (idx1, idx2) sorted by idx1; returns number of pairs. */
+int oracle_search_for_triangulation(const oracle_featset *k1, const oracle_featset *k2,
+                                    const float F12[9], float ex, float ey,
+                                    const float *scale_factors2, const float *level_sigma2_2,
+                                    float nnratio, int check_ori, int only_stereo,
+                                    int32_t *pairs, int cap);
+
+/* ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1687-1728 */
+void oracle_three_maxima(const int *count, int L, int *ind1, int *ind2, int *ind3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
