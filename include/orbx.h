@@ -1,0 +1,182 @@
+/*
+ * orbx.h — C ABI of the MI355X-native ORB front end + Hamming matchers (liborbx.so).
+ *
+ * Drop-in boundary for the ORB-SLAM2 hot path.  The reference has no
+ * FFI; the seam is two C++ classes and one Frame method, so each entry point below names the
+ * reference interface it replaces (paths relative to the reference root).  INTEGRATION.md shows
+ * the C++ adaptor a maintainer adds on the reference side (ORBextractor/ORBmatcher shims).
+ *
+ * Conventions: plain C, no exceptions; every function returns ORBX_OK (0) or a negative
+ * ORBX_E_* code and records a message readable through orbx_last_error() (thread-local).
+ * All buffers are caller-allocated with explicit capacities.  "host" entry points take host
+ * pointers and synchronise; "*_device" entry points take device (HBM) pointers, enqueue on a
+ * HIP stream and return without synchronising (the throughput path).
+ * There is no CPU fallback: without a usable gfx950 device every compute call fails with
+ * ORBX_E_NO_DEVICE.
+ *
+ * Threading (as the reference): one extractor handle is used by one thread
+ * at a time; distinct handles may be used concurrently.
+ */
+#ifndef ORBX_H
+#define ORBX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBX_OK 0
+#define ORBX_E_INVALID (-1)    /* bad argument */
+#define ORBX_E_CAPACITY (-2)   /* an output capacity is too small */
+#define ORBX_E_TOO_SMALL (-3)  /* image smaller than one 30-px FAST cell at some level (reference: div by 0) */
+#define ORBX_E_NO_DEVICE (-4)  /* no gfx950 device / device index out of range */
+#define ORBX_E_HIP (-5)        /* a HIP runtime call failed */
+
+/* == cv::KeyPoint (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id.
+ * Output element type of ORBextractor::operator() (include/ORBextractor.h:74-76). */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orbx_keypoint;
+
+typedef struct orbx_extractor orbx_extractor; /* opaque; owns device pyramid + workspace */
+
+const char *orbx_last_error(void);
+int orbx_device_count(void);
+
+/* ---- ORBextractor (include/ORBextractor.h:58-139, src/ORBextractor.cc:429-534) ---------- */
+
+/* replaces `new ORBextractor(nFeatures, fScaleFactor, nLevels, fIniThFAST, fMinThFAST)`
+ * (src/Tracking.cc:124-130).  device = HIP device index; max_w/max_h/max_batch size the
+ * workspace (images of any size <= max and batches <= max_batch are accepted later). */
+int orbx_extractor_create(orbx_extractor **out, int nfeatures, float scale_factor, int nlevels,
+                          int ini_th_fast, int min_th_fast, int device, int max_w, int max_h, int max_batch);
+void orbx_extractor_destroy(orbx_extractor *e);
+
+/* getters: GetLevels / GetScaleFactor / GetScaleFactors / GetInverseScaleFactors /
+ * GetScaleSigmaSquares / GetInverseScaleSigmaSquares (include/ORBextractor.h:78-98).
+ * Each output array has nlevels entries; NULL pointers are skipped. */
+int orbx_get_levels(const orbx_extractor *e);
+float orbx_get_scale_factor(const orbx_extractor *e);
+int orbx_get_scale_tables(const orbx_extractor *e, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2);
+/* per-level feature quotas mnFeaturesPerLevel (src/ORBextractor.cc:468-493) */
+int orbx_get_features_per_level(const orbx_extractor *e, int *quota);
+/* smallest per-image keypoint capacity that can never overflow (quadtree may return up to
+ * max(quota+2, 4*nIni) per level) */
+int orbx_max_keypoints(const orbx_extractor *e, int w, int h);
+
+/* replaces ORBextractor::operator()(image, mask, keypoints, descriptors)
+ * (src/ORBextractor.cc:1261-1339; caller src/Frame.cc:285-292).  img: 8-bit grey, row stride in
+ * bytes.  kps[cap], desc[cap*32].  An empty image (w==0||h==0) returns ORBX_OK with *n_out = 0
+ * (reference :1264-1265 returns silently). */
+int orbx_extract(orbx_extractor *e, const uint8_t *img, int w, int h, size_t stride,
+                 orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out);
+
+/* B images of one size in one pass (host pointers). kps[B*cap], desc[B*cap*32], n_out[B]. */
+int orbx_extract_batch(orbx_extractor *e, const uint8_t *const *imgs, int batch, int w, int h, size_t stride,
+                       orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out);
+
+/* Throughput path: images already resident in HBM.  Image b starts at d_imgs + b*img_stride and
+ * has row pitch `pitch` bytes; outputs are device buffers d_kps[B*cap], d_desc[B*cap*32],
+ * d_n_out[B].  Enqueued on `stream` (a hipStream_t; NULL = the handle's own stream); returns
+ * before completion.  The input must stay valid until orbx_stereo_match*_device /
+ * orbx_pyramid_level calls that read level 0 have completed (level 0 is read in place). */
+int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, size_t img_stride, size_t pitch,
+                              int batch, int w, int h, void *d_kps, void *d_desc, int cap, void *d_n_out,
+                              void *stream);
+/* wait for everything enqueued on the handle's stream (or `stream`) */
+int orbx_sync(orbx_extractor *e, void *stream);
+
+/* backs the public member mvImagePyramid (include/ORBextractor.h:100): copy level `level` of
+ * image `image_index` of the most recent extract call to host memory (no 19-px border: the
+ * border is never read by the hot path). */
+int orbx_pyramid_level(orbx_extractor *e, int image_index, int level, uint8_t *dst, size_t dst_stride, int *w, int *h);
+
+/* ---- Frame::ComputeStereoMatches (src/Frame.cc:577-751) ---------------------------------- */
+
+/* L and R have each run extract on the left/right image (their pyramids are read).
+ * min_z replaces the `mb` member the reference reads uninitialised; maxD = bf/min_z.
+ * u_right[nL], depth[nL]: -1 where unmatched (mvuRight / mvDepth). */
+int orbx_stereo_match(orbx_extractor *L, orbx_extractor *R,
+                      const orbx_keypoint *kL, const uint8_t *dL, int nL,
+                      const orbx_keypoint *kR, const uint8_t *dR, int nR,
+                      float bf, float min_z, float *u_right, float *depth);
+
+/* Batched, device-resident: pair p uses image (imgL0+p) of handle L and (imgR0+p) of handle R
+ * from their most recent extract_batch calls (L and R may be the same handle).  Keypoints /
+ * descriptors / counts are the device outputs of orbx_extract_batch_device with capacity `cap`.
+ * d_u_right, d_depth: [batch*cap] floats. */
+int orbx_stereo_match_batch_device(orbx_extractor *L, int imgL0, orbx_extractor *R, int imgR0, int batch,
+                                   const void *d_kL, const void *d_dL, const void *d_nL,
+                                   const void *d_kR, const void *d_dR, const void *d_nR, int cap,
+                                   float bf, float min_z, void *d_u_right, void *d_depth, void *stream);
+
+/* ---- ORBmatcher (include/ORBmatcher.h:41-83) ---------------------------------------------- */
+
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1733-1749), host inline popcount */
+int orbx_hamming(const uint8_t *a, const uint8_t *b);
+
+/* One side of a BoW search: descriptors + DBoW2::FeatureVector flattened to CSR
+ * (Thirdparty/DBoW2/DBoW2/FeatureVector.h:21-22: node ids ascending, feature indices ascending
+ * within a node, every feature in at most one node) + per-feature attributes.  Host pointers. */
+typedef struct {
+    int n;                   /* number of features */
+    const uint8_t *desc;     /* [n][32] */
+    int nnodes;
+    const uint32_t *node_id; /* [nnodes] */
+    const int32_t *node_off; /* [nnodes+1] */
+    const uint32_t *feat;    /* [node_off[nnodes]] */
+    const uint8_t *flag;     /* [n] per-search meaning, see below */
+    const float *angle;      /* [n] keypoint angle, degrees */
+    const float *x, *y;      /* [n] undistorted position (triangulation only, else may be NULL) */
+    const int32_t *octave;   /* [n] (triangulation only) */
+    const float *u_right;    /* [n] (triangulation only): <0 = monocular feature */
+} orbx_featset;
+
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (src/ORBmatcher.cc:171-303).
+ * kf->flag[i] != 0 <=> KF feature i holds a non-bad MapPoint; f->flag unused.
+ * match_f[f->n] = matched KF feature index or -1; *nmatches = return value of the reference. */
+int orbx_search_by_bow_kf_f(int device, const orbx_featset *kf, const orbx_featset *f,
+                            float nnratio, int check_orientation, int32_t *match_f, int *nmatches);
+/* many keyframes against one frame in one launch (Tracking::Relocalization loop,
+ * src/Tracking.cc:1661-1682): match_f[nkf][f->n], nmatches[nkf] */
+int orbx_search_by_bow_kf_f_batch(int device, const orbx_featset *kfs, int nkf, const orbx_featset *f,
+                                  float nnratio, int check_orientation, int32_t *match_f, int *nmatches);
+
+/* ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (src/ORBmatcher.cc:568-702).
+ * flag != 0 <=> non-bad MapPoint (both sides).  match12[k1->n] = KF2 feature index or -1. */
+int orbx_search_by_bow_kf_kf(int device, const orbx_featset *k1, const orbx_featset *k2,
+                             float nnratio, int check_orientation, int32_t *match12, int *nmatches);
+
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:704-871) incl. CheckDistEpipolarLine
+ * (:147-164).  flag != 0 <=> the feature already has a MapPoint (skipped).  F12 row-major 3x3;
+ * (ex,ey) = epipole of camera 1 in image 2 (:712-718, computed by the adaptor);
+ * scale_factors2 / level_sigma2_2: KF2's per-level tables [nlevels2].
+ * pairs[2*cap] receives (idx1, idx2) sorted by idx1; *npairs = number found (may exceed cap:
+ * then ORBX_E_CAPACITY). */
+int orbx_search_for_triangulation(int device, const orbx_featset *k1, const orbx_featset *k2,
+                                  const float F12[9], float ex, float ey,
+                                  const float *scale_factors2, const float *level_sigma2_2, int nlevels2,
+                                  int only_stereo, int check_orientation, int32_t *pairs, int cap, int *npairs);
+
+/* ---- measurement hooks (bench.py) ---------------------------------------------------------- */
+
+enum { ORBX_STAGE_RESIZE = 0, ORBX_STAGE_FAST = 1, ORBX_STAGE_TREE = 2, ORBX_STAGE_DESC = 3,
+       ORBX_STAGE_STEREO = 4, ORBX_STAGE_STEREO_CUT = 5, ORBX_STAGE_COUNT = 6 };
+/* enable: record HIP events around every kernel launch of this handle (on the launch stream) */
+int orbx_profile_enable(orbx_extractor *e, int enable);
+/* synchronises, then returns accumulated kernel time (ms) and launch count per stage since the
+ * last reset; arrays of ORBX_STAGE_COUNT entries */
+int orbx_profile_read(orbx_extractor *e, float *ms, int *launches, int reset);
+
+/* debug/inspection (used by the parity tests to localise a mismatch): FAST candidates and
+ * per-level keypoint counts of image `image_index` of the most recent extract call.
+ * x,y are relative to (16,16) like the reference's vToDistributeKeys. */
+int orbx_debug_candidates(orbx_extractor *e, int image_index, int level, int32_t *x, int32_t *y, int32_t *resp, int cap, int *n);
+int orbx_debug_level_counts(orbx_extractor *e, int image_index, int32_t *counts /*[nlevels]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

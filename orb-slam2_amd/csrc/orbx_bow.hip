@@ -1,0 +1,466 @@
+// orbx_bow.hip — ORBmatcher::SearchByBoW (KF,F) / (KF,KF) and SearchForTriangulation for gfx950
+// (reference src/ORBmatcher.cc:171-303, :568-702, :704-871, :147-164, :1687-1728).
+//
+// One 256-thread workgroup per keyframe pair.  The two FeatureVectors (CSR, node ids ascending)
+// are intersected by binary search (same node set as the reference's merge join); every shared
+// vocabulary node is owned by one wave, which walks the first side's features sequentially (the
+// greedy "already claimed" state of :222 / :622 is per node because a feature lives in exactly one
+// node) and spreads the second side's features over its 64 lanes: 256-bit Hamming by popcount,
+// wave min-reductions for best / second best.  Rotation histogram + ComputeThreeMaxima run once
+// per pair in LDS.
+#include "orbx_device.h"
+#include <string.h>
+
+struct DevFeat {
+    int n, nnodes;
+    const uint32_t *desc;     // [n][8]
+    const uint32_t *node_id;  // [nnodes]
+    const int32_t *node_off;  // [nnodes+1]
+    const uint32_t *feat;
+    const uint8_t *flag;
+    const float *angle, *x, *y, *u_right;
+    const int32_t *octave;
+};
+
+struct TriParams { float F[9]; float ex, ey; float sf2[ORBX_MAX_LEVELS]; float sig2[ORBX_MAX_LEVELS]; int only_stereo; };
+
+#define BOW_TH_LOW 50
+#define BOW_HISTO 30
+
+// rotation bin of src/ORBmatcher.cc:253-258 (factor = 1/30 with HISTO_LENGTH = 30: upstream quirk kept)
+__device__ __forceinline__ int rot_bin(float a1, float a2)
+{
+    const float factor = 1.0f / BOW_HISTO;
+    float rot = a1 - a2;
+    if (rot < 0.0f) rot += 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin == BOW_HISTO) bin = 0;
+    return bin;
+}
+
+__device__ __forceinline__ int find_node(const uint32_t *ids, int n, uint32_t key)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (ids[mid] < key) lo = mid + 1; else hi = mid; }
+    return (lo < n && ids[lo] == key) ? lo : -1;
+}
+
+__device__ __forceinline__ void load_desc(const uint32_t *d, long long idx, uint32_t *out)
+{
+    const uint4 *s = reinterpret_cast<const uint4 *>(d + idx * 8);
+    const uint4 v0 = s[0], v1 = s[1];
+    out[0] = v0.x; out[1] = v0.y; out[2] = v0.z; out[3] = v0.w;
+    out[4] = v1.x; out[5] = v1.y; out[6] = v1.z; out[7] = v1.w;
+}
+
+// ComputeThreeMaxima (:1687-1728) on per-bin counts + clearing of the other bins (:282-300).
+// bins[i] = bin of match slot i or 255; match[] entries outside the 3 dominant bins become -1.
+// Returns (in *out_n, by thread 0) the number of surviving matches.
+__device__ void histogram_filter(int32_t *match, const uint8_t *bins, int nslots, int check_ori, int *hist, int *keep3, int *s_cnt, int *out_n)
+{
+    const int tid = threadIdx.x;
+    if (tid < BOW_HISTO) hist[tid] = 0;
+    if (tid == 0) *s_cnt = 0;
+    __syncthreads();
+    if (check_ori) {
+        for (int i = tid; i < nslots; i += 256)
+            if (bins[i] != 255) atomicAdd(&hist[bins[i]], 1);
+        __syncthreads();
+        if (tid == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < BOW_HISTO; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+                else if (s > max3) { max3 = s; i3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+            keep3[0] = i1; keep3[1] = i2; keep3[2] = i3;
+        }
+        __syncthreads();
+    }
+    int local = 0;
+    for (int i = tid; i < nslots; i += 256) {
+        const int b = bins[i];
+        if (b == 255) continue;
+        if (check_ori && b != keep3[0] && b != keep3[1] && b != keep3[2]) match[i] = -1;
+        else local++;
+    }
+    if (local) atomicAdd(s_cnt, local);
+    __syncthreads();
+    if (tid == 0) *out_n = *s_cnt;
+}
+
+extern __shared__ __align__(16) unsigned char bow_smem[];
+
+// MODE 0: SearchByBoW(KF, F)  — match[nB] indexed by the F feature, value = KF feature
+// MODE 1: SearchByBoW(KF, KF) — match[nA] indexed by the KF1 feature, value = KF2 feature
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a, const DevFeat *__restrict__ sides_b,
+                                             int b_shared, float nnratio, int check_ori, int32_t *__restrict__ match_out,
+                                             int match_stride, int *__restrict__ nmatches)
+{
+    __shared__ int hist[BOW_HISTO];
+    __shared__ int keep3[3];
+    __shared__ int s_cnt;
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const DevFeat A = sides_a[pair];
+    const DevFeat B = sides_b[b_shared ? 0 : pair];
+    const int nslots = MODE == 0 ? B.n : A.n;
+    uint8_t *claimed = bow_smem;                 // [B.n]
+    uint8_t *bins = bow_smem + ((B.n + 15) & ~15); // [nslots]
+    int32_t *match = match_out + (long long)pair * match_stride;
+    for (int i = tid; i < B.n; i += 256) claimed[i] = 0;
+    for (int i = tid; i < nslots; i += 256) { bins[i] = 255; match[i] = -1; }
+    __syncthreads();
+    for (int ia = wv; ia < A.nnodes; ia += 4) {
+        const int ib = find_node(B.node_id, B.nnodes, A.node_id[ia]);
+        if (ib < 0) continue;
+        const int b0 = B.node_off[ib], b1 = B.node_off[ib + 1];
+        for (int i1 = A.node_off[ia]; i1 < A.node_off[ia + 1]; i1++) {
+            const int idx1 = (int)A.feat[i1];
+            if (!A.flag[idx1]) continue;
+            uint32_t da[8];
+            load_desc(A.desc, idx1, da);
+            unsigned k1 = 0xFFFFFFFFu; // dist<<20 | position: first index wins ties (strict <, :229-239)
+            int l1 = 256, l2 = 256;
+            for (int j = b0 + lane; j < b1; j += 64) {
+                const int idx2 = (int)B.feat[j];
+                if (claimed[idx2]) continue;
+                if (MODE == 1 && !B.flag[idx2]) continue;
+                uint32_t db[8];
+                load_desc(B.desc, idx2, db);
+                const int dist = hamming256(da, db);
+                if (dist < l1) { l2 = l1; l1 = dist; k1 = ((unsigned)dist << 20) | (unsigned)(j - b0); }
+                else if (dist < l2) l2 = dist;
+            }
+            const unsigned kbest = wave_min_u32(k1);
+            if (kbest == 0xFFFFFFFFu) continue;
+            const int best1 = (int)(kbest >> 20);
+            // second smallest of the multiset: the owner of the winner contributes its own runner-up
+            const unsigned second = wave_min_u32((unsigned)(k1 == kbest ? l2 : l1));
+            const int best2 = (int)second;
+            const bool ok_dist = MODE == 0 ? best1 <= BOW_TH_LOW : best1 < BOW_TH_LOW;
+            if (ok_dist && (float)best1 < nnratio * (float)best2) {
+                const int idx2 = (int)B.feat[b0 + (int)(kbest & 0xFFFFF)];
+                if (lane == 0) {
+                    claimed[idx2] = 1;
+                    const int bin = rot_bin(A.angle[idx1], B.angle[idx2]);
+                    if (MODE == 0) { match[idx2] = idx1; bins[idx2] = (uint8_t)bin; }
+                    else { match[idx1] = idx2; bins[idx1] = (uint8_t)bin; }
+                }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+            }
+        }
+    }
+    __syncthreads();
+    histogram_filter(match, bins, nslots, check_ori, hist, keep3, &s_cnt, nmatches + pair);
+}
+
+// SearchForTriangulation: rows are independent (vbMatched2 is never written in the reference)
+__global__ __launch_bounds__(256) void k_triangulation(const DevFeat *__restrict__ side_a, const DevFeat *__restrict__ side_b,
+                                                       TriParams tp, int check_ori, int32_t *__restrict__ m12,
+                                                       int32_t *__restrict__ pairs, int cap, int *__restrict__ npairs)
+{
+    __shared__ int hist[BOW_HISTO];
+    __shared__ int keep3[3];
+    __shared__ int s_cnt;
+    __shared__ int s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const DevFeat A = side_a[0];
+    const DevFeat B = side_b[0];
+    uint8_t *bins = bow_smem; // [A.n]
+    for (int i = tid; i < A.n; i += 256) { bins[i] = 255; m12[i] = -1; }
+    __syncthreads();
+    for (int ia = wv; ia < A.nnodes; ia += 4) {
+        const int ib = find_node(B.node_id, B.nnodes, A.node_id[ia]);
+        if (ib < 0) continue;
+        const int b0 = B.node_off[ib], b1 = B.node_off[ib + 1];
+        for (int i1 = A.node_off[ia]; i1 < A.node_off[ia + 1]; i1++) {
+            const int idx1 = (int)A.feat[i1];
+            if (A.flag[idx1]) continue;            // already has a MapPoint (:750)
+            const bool stereo1 = A.u_right[idx1] >= 0;
+            if (tp.only_stereo && !stereo1) continue;
+            const float x1 = A.x[idx1], y1 = A.y[idx1];
+            // epipolar line of kp1 in image 2 (:150-152)
+            const float la = x1 * tp.F[0] + y1 * tp.F[3] + tp.F[6];
+            const float lb = x1 * tp.F[1] + y1 * tp.F[4] + tp.F[7];
+            const float lc = x1 * tp.F[2] + y1 * tp.F[5] + tp.F[8];
+            const float den = la * la + lb * lb;
+            uint32_t da[8];
+            load_desc(A.desc, idx1, da);
+            unsigned key = 0xFFFFFFFFu; // dist<<20 | (0xFFFFF - position): min distance, LAST index on ties (:786)
+            for (int j = b0 + lane; j < b1; j += 64) {
+                const int idx2 = (int)B.feat[j];
+                if (B.flag[idx2]) continue;
+                const bool stereo2 = B.u_right[idx2] >= 0;
+                if (tp.only_stereo && !stereo2) continue;
+                uint32_t db[8];
+                load_desc(B.desc, idx2, db);
+                const int dist = hamming256(da, db);
+                if (dist > BOW_TH_LOW) continue;
+                const float x2 = B.x[idx2], y2 = B.y[idx2];
+                const int oct2 = B.octave[idx2];
+                if (!stereo1 && !stereo2) {
+                    const float distex = tp.ex - x2, distey = tp.ey - y2;
+                    if (distex * distex + distey * distey < 100 * tp.sf2[oct2]) continue;
+                }
+                const float num = la * x2 + lb * y2 + lc;
+                if (den == 0) continue;
+                const float dsqr = num * num / den;
+                if (!((double)dsqr < 3.84 * (double)tp.sig2[oct2])) continue;
+                const unsigned k = ((unsigned)dist << 20) | (0xFFFFFu - (unsigned)(j - b0));
+                key = k < key ? k : key;
+            }
+            key = wave_min_u32(key);
+            if (key == 0xFFFFFFFFu) continue;
+            if (lane == 0) {
+                const int idx2 = (int)B.feat[b0 + (int)(0xFFFFFu - (key & 0xFFFFFu))];
+                m12[idx1] = idx2;
+                bins[idx1] = (uint8_t)rot_bin(A.angle[idx1], B.angle[idx2]);
+            }
+        }
+    }
+    __syncthreads();
+    histogram_filter(m12, bins, A.n, check_ori, hist, keep3, &s_cnt, npairs + 1);
+    __syncthreads();
+    // ordered compaction of (idx1, idx2), ascending idx1 (:863-868)
+    const int per = (A.n + 255) >> 8;
+    const int beg = tid * per, end = min(beg + per, A.n);
+    int c = 0;
+    for (int i = beg; i < end; i++) c += m12[i] >= 0;
+    int total;
+    int off = block_excl_scan256(c, &total, s_w);
+    for (int i = beg; i < end; i++)
+        if (m12[i] >= 0) {
+            if (off < cap) { pairs[2 * off] = i; pairs[2 * off + 1] = m12[i]; }
+            off++;
+        }
+    if (tid == 0) npairs[0] = total;
+}
+
+// ---------------------------------------------------------------- host side
+
+struct BowCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint8_t *h_blob = nullptr; size_t h_cap = 0;   // pinned staging
+    uint8_t *d_blob = nullptr; size_t d_cap = 0;
+    int32_t *d_out = nullptr; size_t out_cap = 0;  // match / pairs / counts
+    int32_t *h_out = nullptr; size_t h_out_cap = 0;
+};
+static thread_local BowCtx g_bow[16];
+
+static int bow_ctx(int device, BowCtx **out)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || device >= 16) {
+        orbx_set_error("no usable HIP device %d (liborbx has no CPU fallback)", device);
+        return ORBX_E_NO_DEVICE;
+    }
+    ORBX_HIP(hipSetDevice(device));
+    BowCtx *c = &g_bow[device];
+    if (!c->stream) { ORBX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->device = device; }
+    *out = c;
+    return ORBX_OK;
+}
+
+static int bow_reserve(BowCtx *c, size_t blob, size_t out_ints)
+{
+    if (blob > c->h_cap) {
+        if (c->h_blob) ORBX_HIP(hipHostFree(c->h_blob));
+        c->h_blob = nullptr;
+        ORBX_HIP(hipHostMalloc((void **)&c->h_blob, blob * 2, hipHostMallocDefault));
+        c->h_cap = blob * 2;
+    }
+    if (blob > c->d_cap) {
+        if (c->d_blob) ORBX_HIP(hipFree(c->d_blob));
+        c->d_blob = nullptr;
+        ORBX_HIP(hipMalloc((void **)&c->d_blob, blob * 2));
+        c->d_cap = blob * 2;
+    }
+    if (out_ints > c->out_cap) {
+        if (c->d_out) ORBX_HIP(hipFree(c->d_out));
+        c->d_out = nullptr;
+        ORBX_HIP(hipMalloc((void **)&c->d_out, out_ints * 2 * sizeof(int32_t)));
+        c->out_cap = out_ints * 2;
+    }
+    if (out_ints > c->h_out_cap) {
+        if (c->h_out) ORBX_HIP(hipHostFree(c->h_out));
+        c->h_out = nullptr;
+        ORBX_HIP(hipHostMalloc((void **)&c->h_out, out_ints * 2 * sizeof(int32_t), hipHostMallocDefault));
+        c->h_out_cap = out_ints * 2;
+    }
+    return ORBX_OK;
+}
+
+static size_t a16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+static int feat_validate(const orbx_featset *f, int need_geom)
+{
+    if (!f || f->n < 0 || f->nnodes < 0) return 0;
+    if (f->n >= (1 << 20)) return 0;
+    if (f->n && (!f->desc || !f->flag || !f->angle)) return 0;
+    if (f->nnodes && (!f->node_id || !f->node_off || !f->feat)) return 0;
+    if (need_geom && f->n && (!f->x || !f->y || !f->octave || !f->u_right)) return 0;
+    if (f->nnodes) {
+        if (f->node_off[0] != 0) return 0;
+        for (int i = 0; i < f->nnodes; i++) {
+            if (f->node_off[i + 1] < f->node_off[i]) return 0;
+            if (i && f->node_id[i] <= f->node_id[i - 1]) return 0;
+        }
+        const int m = f->node_off[f->nnodes];
+        for (int i = 0; i < m; i++) if (f->feat[i] >= (uint32_t)f->n) return 0; // indices must be in range: the kernel trusts them
+    }
+    return 1;
+}
+
+static size_t feat_bytes(const orbx_featset *f, int geom)
+{
+    const size_t m = f->nnodes ? (size_t)f->node_off[f->nnodes] : 0;
+    size_t s = a16((size_t)f->n * 32) + a16((size_t)f->nnodes * 4) + a16(((size_t)f->nnodes + 1) * 4) + a16(m * 4) +
+               a16((size_t)f->n) + a16((size_t)f->n * 4);
+    if (geom) s += 4 * a16((size_t)f->n * 4);
+    return s;
+}
+
+// copy one featset into the staging blob at *off; pointers in `d` refer to the device blob
+static void feat_pack(const orbx_featset *f, int geom, uint8_t *h, const uint8_t *dbase, size_t *off, DevFeat *d)
+{
+    auto put = [&](const void *src, size_t bytes) -> const uint8_t * {
+        const uint8_t *dp = dbase + *off;
+        if (bytes && src) memcpy(h + *off, src, bytes);
+        *off += a16(bytes);
+        return dp;
+    };
+    const size_t m = f->nnodes ? (size_t)f->node_off[f->nnodes] : 0;
+    static const int32_t zero_off[1] = { 0 };
+    d->n = f->n; d->nnodes = f->nnodes;
+    d->desc = (const uint32_t *)put(f->desc, (size_t)f->n * 32);
+    d->node_id = (const uint32_t *)put(f->node_id, (size_t)f->nnodes * 4);
+    d->node_off = (const int32_t *)put(f->nnodes ? f->node_off : zero_off, ((size_t)f->nnodes + 1) * 4);
+    d->feat = (const uint32_t *)put(f->feat, m * 4);
+    d->flag = (const uint8_t *)put(f->flag, (size_t)f->n);
+    d->angle = (const float *)put(f->angle, (size_t)f->n * 4);
+    d->x = d->y = d->u_right = nullptr; d->octave = nullptr;
+    if (geom) {
+        d->x = (const float *)put(f->x, (size_t)f->n * 4);
+        d->y = (const float *)put(f->y, (size_t)f->n * 4);
+        d->u_right = (const float *)put(f->u_right, (size_t)f->n * 4);
+        d->octave = (const int32_t *)put(f->octave, (size_t)f->n * 4);
+    }
+}
+
+static int bow_run(int mode, int device, const orbx_featset *as, int na, const orbx_featset *b, int b_shared,
+                   float nnratio, int check_ori, int32_t *match, int *nmatches)
+{
+    if (!as || !b || na < 1 || !match || !nmatches) { orbx_set_error("bow search: null argument"); return ORBX_E_INVALID; }
+    size_t blob = a16(sizeof(DevFeat) * (size_t)(na + 1));
+    int max_b = 0, max_slots = 0;
+    for (int i = 0; i < na; i++) {
+        if (!feat_validate(&as[i], 0)) { orbx_set_error("bow search: malformed feature set %d", i); return ORBX_E_INVALID; }
+        blob += feat_bytes(&as[i], 0);
+        if (mode == 1 && as[i].n > max_slots) max_slots = as[i].n;
+    }
+    if (!feat_validate(b, 0)) { orbx_set_error("bow search: malformed feature set"); return ORBX_E_INVALID; }
+    blob += feat_bytes(b, 0);
+    max_b = b->n;
+    const int stride = mode == 0 ? b->n : max_slots;
+    if (mode == 0) max_slots = b->n;
+    BowCtx *c;
+    int rc = bow_ctx(device, &c);
+    if (rc) return rc;
+    const size_t out_ints = (size_t)na * (stride > 0 ? stride : 1) + na;
+    if ((rc = bow_reserve(c, blob, out_ints))) return rc;
+    DevFeat *hd = (DevFeat *)c->h_blob;
+    size_t off = a16(sizeof(DevFeat) * (size_t)(na + 1));
+    for (int i = 0; i < na; i++) feat_pack(&as[i], 0, c->h_blob, c->d_blob, &off, &hd[i]);
+    feat_pack(b, 0, c->h_blob, c->d_blob, &off, &hd[na]);
+    ORBX_HIP(hipMemcpyAsync(c->d_blob, c->h_blob, off, hipMemcpyHostToDevice, c->stream));
+    const DevFeat *dA = (const DevFeat *)c->d_blob, *dB = dA + na;
+    int32_t *d_match = c->d_out;
+    int *d_n = c->d_out + (size_t)na * (stride > 0 ? stride : 1);
+    const size_t lds = (size_t)((max_b + 15) & ~15) + (size_t)((max_slots + 15) & ~15) + 16;
+    if (lds > 150 * 1024) { orbx_set_error("feature sets too large for LDS"); return ORBX_E_INVALID; }
+    if (mode == 0) {
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_bow<0>, dim3(na), dim3(256), lds, c->stream, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
+    } else {
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_bow<1>, dim3(na), dim3(256), lds, c->stream, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
+    }
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(c->h_out, c->d_out, out_ints * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    ORBX_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < na; i++) {
+        const int cnt = mode == 0 ? b->n : as[i].n;
+        memcpy(match + (size_t)i * stride, c->h_out + (size_t)i * stride, sizeof(int32_t) * cnt);
+        nmatches[i] = c->h_out[(size_t)na * (stride > 0 ? stride : 1) + i];
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_by_bow_kf_f(int device, const orbx_featset *kf, const orbx_featset *f,
+                                       float nnratio, int check_orientation, int32_t *match_f, int *nmatches)
+{
+    return bow_run(0, device, kf, 1, f, 1, nnratio, check_orientation, match_f, nmatches);
+}
+
+extern "C" int orbx_search_by_bow_kf_f_batch(int device, const orbx_featset *kfs, int nkf, const orbx_featset *f,
+                                             float nnratio, int check_orientation, int32_t *match_f, int *nmatches)
+{
+    return bow_run(0, device, kfs, nkf, f, 1, nnratio, check_orientation, match_f, nmatches);
+}
+
+extern "C" int orbx_search_by_bow_kf_kf(int device, const orbx_featset *k1, const orbx_featset *k2,
+                                        float nnratio, int check_orientation, int32_t *match12, int *nmatches)
+{
+    return bow_run(1, device, k1, 1, k2, 1, nnratio, check_orientation, match12, nmatches);
+}
+
+extern "C" int orbx_search_for_triangulation(int device, const orbx_featset *k1, const orbx_featset *k2,
+                                             const float F12[9], float ex, float ey,
+                                             const float *sf2, const float *sig2, int nlevels2,
+                                             int only_stereo, int check_orientation, int32_t *pairs, int cap, int *npairs)
+{
+    if (!k1 || !k2 || !F12 || !sf2 || !sig2 || !pairs || !npairs || cap < 0 || nlevels2 < 1 || nlevels2 > ORBX_MAX_LEVELS) {
+        orbx_set_error("orbx_search_for_triangulation: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    if (!feat_validate(k1, 1) || !feat_validate(k2, 1)) { orbx_set_error("triangulation search: malformed feature set"); return ORBX_E_INVALID; }
+    for (int i = 0; i < k2->n; i++)
+        if (k2->octave[i] < 0 || k2->octave[i] >= nlevels2) { orbx_set_error("octave out of range"); return ORBX_E_INVALID; }
+    BowCtx *c;
+    int rc = bow_ctx(device, &c);
+    if (rc) return rc;
+    const size_t blob = a16(sizeof(DevFeat) * 2) + feat_bytes(k1, 1) + feat_bytes(k2, 1);
+    const size_t out_ints = (size_t)k1->n + 2 * (size_t)cap + 2 + 16;
+    if ((rc = bow_reserve(c, blob, out_ints))) return rc;
+    DevFeat *hd = (DevFeat *)c->h_blob;
+    size_t off = a16(sizeof(DevFeat) * 2);
+    feat_pack(k1, 1, c->h_blob, c->d_blob, &off, &hd[0]);
+    feat_pack(k2, 1, c->h_blob, c->d_blob, &off, &hd[1]);
+    ORBX_HIP(hipMemcpyAsync(c->d_blob, c->h_blob, off, hipMemcpyHostToDevice, c->stream));
+    TriParams tp;
+    memset(&tp, 0, sizeof tp);
+    for (int i = 0; i < 9; i++) tp.F[i] = F12[i];
+    tp.ex = ex; tp.ey = ey; tp.only_stereo = only_stereo;
+    for (int i = 0; i < nlevels2; i++) { tp.sf2[i] = sf2[i]; tp.sig2[i] = sig2[i]; }
+    int32_t *d_m12 = c->d_out, *d_pairs = d_m12 + ((k1->n + 3) & ~3), *d_np = d_pairs + 2 * (size_t)cap;
+    const size_t lds = (size_t)((k1->n + 15) & ~15) + 16;
+    if (lds > 150 * 1024) { orbx_set_error("feature set too large for LDS"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_triangulation), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const DevFeat *dA = (const DevFeat *)c->d_blob;
+    hipLaunchKernelGGL(k_triangulation, dim3(1), dim3(256), lds, c->stream, dA, dA + 1, tp, check_orientation, d_m12, d_pairs, cap, d_np);
+    ORBX_HIP(hipGetLastError());
+    int32_t *h_pairs = c->h_out;
+    ORBX_HIP(hipMemcpyAsync(h_pairs, d_pairs, (2 * (size_t)cap + 2) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    ORBX_HIP(hipStreamSynchronize(c->stream));
+    const int np = h_pairs[2 * (size_t)cap];
+    *npairs = np;
+    memcpy(pairs, h_pairs, sizeof(int32_t) * 2 * (size_t)(np < cap ? np : cap));
+    if (np > cap) { orbx_set_error("pair capacity %d < %d matches", cap, np); return ORBX_E_CAPACITY; }
+    return ORBX_OK;
+}

@@ -1,0 +1,82 @@
+// orbx_common.hip — error reporting, device query, profiling hooks, host Hamming.
+#include "orbx_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void orbx_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *orbx_last_error(void) { return g_err; }
+
+extern "C" int orbx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ORBmatcher::DescriptorDistance (reference src/ORBmatcher.cc:1733-1749): popcount(a XOR b), 256 bits
+extern "C" int orbx_hamming(const uint8_t *a, const uint8_t *b)
+{
+    int d = 0;
+    for (int i = 0; i < 4; i++) {
+        uint64_t x, y;
+        memcpy(&x, a + 8 * i, 8);
+        memcpy(&y, b + 8 * i, 8);
+        d += __builtin_popcountll(x ^ y);
+    }
+    return d;
+}
+
+// ---- per-launch HIP-event timing on the launch stream (bench.py's roofline leg)
+
+void orbx_prof_begin(orbx_extractor *e, int stage, hipStream_t s)
+{
+    if (!e->prof) return;
+    ProfEvent ev;
+    ev.stage = stage;
+    if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
+    hipEventRecord(ev.a, s);
+    e->prof_ev.push_back(ev);
+}
+
+void orbx_prof_end(orbx_extractor *e, hipStream_t s)
+{
+    if (!e->prof || e->prof_ev.empty()) return;
+    hipEventRecord(e->prof_ev.back().b, s);
+}
+
+extern "C" int orbx_profile_enable(orbx_extractor *e, int enable)
+{
+    if (!e) { orbx_set_error("null extractor"); return ORBX_E_INVALID; }
+    e->prof = enable != 0;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_profile_read(orbx_extractor *e, float *ms, int *launches, int reset)
+{
+    if (!e) { orbx_set_error("null extractor"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(hipDeviceSynchronize());
+    for (auto &ev : e->prof_ev) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, ev.a, ev.b) == hipSuccess) { e->prof_ms[ev.stage] += t; e->prof_n[ev.stage]++; }
+        hipEventDestroy(ev.a);
+        hipEventDestroy(ev.b);
+    }
+    e->prof_ev.clear();
+    for (int i = 0; i < ORBX_STAGE_COUNT; i++) {
+        if (ms) ms[i] = e->prof_ms[i];
+        if (launches) launches[i] = e->prof_n[i];
+        if (reset) { e->prof_ms[i] = 0; e->prof_n[i] = 0; }
+    }
+    return ORBX_OK;
+}

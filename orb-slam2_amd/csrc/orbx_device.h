@@ -1,0 +1,142 @@
+// orbx_device.h — wave64 / workgroup helpers and the exact-arithmetic device primitives.
+#pragma once
+#include "orbx_internal.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        int t = __shfl_up(v, d, WAVE);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) { unsigned t = (unsigned)__shfl_xor((int)v, d, WAVE); v = t < v ? t : v; }
+    return v;
+}
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) { unsigned t = (unsigned)__shfl_xor((int)v, d, WAVE); v = t > v ? t : v; }
+    return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread workgroup; s_w = 4 ints of LDS
+__device__ __forceinline__ int block_excl_scan256(int v, int *total, int *s_w)
+{
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const int inc = wave_incl_scan(v);
+    if (lane == WAVE - 1) s_w[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < wv; i++) base += s_w[i];
+    const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// in-place exclusive scan of an LDS array a[0..m) by a 256-thread workgroup; returns the total.
+// Callers must __syncthreads() before (inputs complete); outputs are visible on return.
+__device__ __forceinline__ int lds_excl_scan(int *a, int m, int *s_w)
+{
+    const int per = (m + 255) >> 8;
+    const int beg = threadIdx.x * per;
+    const int end = beg + per < m ? beg + per : m;
+    int s = 0;
+    for (int i = beg; i < end; i++) s += a[i];
+    int tot;
+    int run = block_excl_scan256(s, &tot, s_w);
+    for (int i = beg; i < end; i++) { int t = a[i]; a[i] = run; run += t; }
+    __syncthreads();
+    return tot;
+}
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}
+
+// cv::fastAtan2 (OpenCV 3.x polynomial): fp32, one rounding per operation
+// (the translation unit is compiled with -ffp-contract=off).
+__device__ __forceinline__ float dev_fast_atan2(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float eps = (float)2.2204460492503131e-16;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// Deterministic sin/cos: fp64 Cody-Waite reduction by pi/2 + fixed minimax polynomials on
+// [-pi/4, pi/4], explicit operation order, rounded once to fp32 (SURVEY.md A.6 build rule: the
+// reference's libm cosf/sinf, src/ORBextractor.cc:123, is not reproducible across hosts).
+__device__ __forceinline__ void dev_sincos(float angle_rad, float *s_out, float *c_out)
+{
+    const double INV_PIO2 = 6.36619772367581382433e-01;
+    const double PIO2_HI = 1.57079632673412561417e+00;
+    const double PIO2_LO = 6.07710050650619224932e-11;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double x = (double)angle_rad;
+    double k = rint(x * INV_PIO2);
+    double r = (x - k * PIO2_HI) - k * PIO2_LO;
+    double z = r * r;
+    double ps = S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))));
+    double sn = r + (r * z) * ps;
+    double pc = C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6))));
+    double cs = (1.0 - 0.5 * z) + (z * z) * pc;
+    int q = (int)((long long)k & 3);
+    double s, c;
+    if (q == 0) { s = sn; c = cs; }
+    else if (q == 1) { s = cs; c = -sn; }
+    else if (q == 2) { s = -sn; c = -cs; }
+    else { s = -cs; c = sn; }
+    *s_out = (float)s;
+    *c_out = (float)c;
+}
+
+// cvRound on a float that is known to be small: round-half-to-even
+__device__ __forceinline__ int dev_cv_round(float v) { return (int)rintf(v); }
+
+__device__ __forceinline__ int hamming256(const uint32_t *a, const uint32_t *b)
+{
+    int d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d += __popc(a[i] ^ b[i]);
+    return d;
+}

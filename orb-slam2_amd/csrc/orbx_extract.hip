@@ -1,0 +1,919 @@
+// orbx_extract.hip — ORB extractor for gfx950 (MI355X): pyramid, per-cell FAST-9/16 + NMS,
+// quadtree cull, intensity-centroid orientation, on-patch 7x7 blur and steered rBRIEF-256.
+//
+// Replaces ORBextractor::operator() (reference src/ORBextractor.cc:1261-1339) and everything it
+// calls; bit-exact contract in SURVEY.md Appendix A/B.  Written for wave64 / LDS staging; all
+// arithmetic is integer except fastAtan2 / the pattern rotation (fp32, contraction off) and the
+// shared fp64 sincos.  One launch covers a whole batch of images (grid.y = image).
+#include "orbx_device.h"
+#include "orb_pattern.inc"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+__constant__ signed char c_pat[4][256];   // x0,y0,x1,y1 (src/ORBextractor.cc:160-418, data)
+__constant__ int c_umax[16];              // src/ORBextractor.cc:510-533
+__constant__ int c_gauss[7];              // 8-bit fixed point 7-tap sigma=2 kernel
+
+// ================================================================ K1: pyramid level (E2)
+// cv::resize INTER_LINEAR 8UC1 from level l-1 to level l.  Coefficient tables are
+// computed on the host with the reference's float/double arithmetic; the kernel is pure integer.
+// One thread produces 4 horizontally adjacent pixels and stores one dword.
+__global__ __launch_bounds__(256) void k_resize(const Geom *__restrict__ g, int l, PyrRef pr,
+                                                uint8_t *__restrict__ pyr_w, const int16_t *__restrict__ tabs)
+{
+    const LevelGeom &D = g->lv[l];
+    const LevelGeom &S = g->lv[l - 1];
+    const int b = blockIdx.z;
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (y >= D.h || x4 >= D.pitch) return;
+    int spitch;
+    const uint8_t *src = orbx_level_ptr(pr, S, l - 1, b, &spitch);
+    uint8_t *dst = pyr_w + (long long)b * pr.pyr_stride + D.pyr_off;
+    const int16_t *tx = tabs + D.tab_x, *ty = tabs + D.tab_y;
+    const int sy0 = ty[y], b0 = ty[D.h + y], b1 = ty[2 * D.h + y];
+    const int sy1 = sy0 + 1 < S.h ? sy0 + 1 : S.h - 1;
+    const uint8_t *r0 = src + (long long)sy0 * spitch, *r1 = src + (long long)sy1 * spitch;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = x4 + i;
+        if (x < D.w) {
+            const int sx0 = tx[x], a0 = tx[D.w + x], a1 = tx[2 * D.w + x];
+            const int sx1 = sx0 + 1 < S.w ? sx0 + 1 : S.w - 1;
+            const int t0 = r0[sx0] * a0 + r0[sx1] * a1;
+            const int t1 = r1[sx0] * a0 + r1[sx1] * a1;
+            int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+            v = v < 0 ? 0 : v > 255 ? 255 : v;
+            out |= (uint32_t)v << (8 * i);
+        }
+    }
+    *reinterpret_cast<uint32_t *>(dst + (long long)y * D.pitch + x4) = out;
+}
+
+// ================================================================ K2: FAST per cell (E3)
+// cornerScore<16> without a threshold: max over the 16 arcs of 9 contiguous ring pixels of
+// min(v - x) (A) and of min(x - v) (B).  A pixel is a FAST-9 corner at threshold t iff
+// max(A,B) > t and its OpenCV score is then max(A,B)-1 independent of t, so one
+// score map at minThFAST serves both passes of src/ORBextractor.cc:988-995.
+__device__ __forceinline__ int fast_score_tile(const uint8_t *t, int th)
+{
+    constexpr int P = ORBX_TILE_PITCH;
+    const int v = t[0];
+    const int d0 = v - t[3 * P], d8 = v - t[-3 * P], d4 = v - t[3], d12 = v - t[-3];
+    // any 9-arc contains one pixel of each antipodal pair
+    const bool dark = (d0 > th || d8 > th) && (d4 > th || d12 > th);
+    const bool bright = (d0 < -th || d8 < -th) && (d4 < -th || d12 < -th);
+    if (!(dark || bright)) return 0;
+    int d[16];
+    d[0] = d0; d[4] = d4; d[8] = d8; d[12] = d12;
+    d[1] = v - t[3 * P + 1];  d[2] = v - t[2 * P + 2];   d[3] = v - t[P + 3];
+    d[5] = v - t[-P + 3];     d[6] = v - t[-2 * P + 2];  d[7] = v - t[-3 * P + 1];
+    d[9] = v - t[-3 * P - 1]; d[10] = v - t[-2 * P - 2]; d[11] = v - t[-P - 3];
+    d[13] = v - t[P - 3];     d[14] = v - t[2 * P - 2];  d[15] = v - t[3 * P - 1];
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+    int A = -256, B = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+        A = max(A, lo9);
+        B = min(B, hi9);
+    }
+    const int s = max(A, -B);
+    return s > th ? s - 1 : 0;
+}
+
+// One 256-thread workgroup per (cell, image): stage the cell (+3 px halo) in LDS, score map,
+// in-cell 3x3 strict NMS, iniThFAST/minThFAST selection, ordered (row-major) compaction into the
+// cell's candidate slots.  Candidate = x | y<<12 | score<<24 with (x,y) relative to (16,16).
+__global__ __launch_bounds__(256) void k_fast(const Geom *__restrict__ g, PyrRef pr, int *__restrict__ cell_cnt,
+                                              uint32_t *__restrict__ cand, int ini_th, int min_th)
+{
+    constexpr int P = ORBX_TILE_PITCH, SP = ORBX_SCORE_PITCH;
+    __shared__ __align__(16) uint8_t tile[65 * P];
+    __shared__ __align__(16) uint8_t sc[61 * SP];
+    __shared__ int s_w[4];
+    const int b = blockIdx.y, cell = blockIdx.x, tid = threadIdx.x;
+    int l = 0;
+    while (l + 1 < g->nlevels && cell >= g->lv[l + 1].cell_base) l++;
+    const LevelGeom &L = g->lv[l];
+    const int ci = cell - L.cell_base;
+    const int ci_row = ci / L.n_cols, ci_col = ci - ci_row * L.n_cols;
+    const int max_bx = L.w - ORBX_MIN_BORDER, max_by = L.h - ORBX_MIN_BORDER;
+    const int ini_y = ORBX_MIN_BORDER + ci_row * L.h_cell, ini_x = ORBX_MIN_BORDER + ci_col * L.w_cell;
+    const int max_y = min(ini_y + L.h_cell + 6, max_by), max_x = min(ini_x + L.w_cell + 6, max_bx);
+    int *my_cnt = cell_cnt + (long long)b * g->total_cells + cell;
+    const int tw = max_x - ini_x, th = max_y - ini_y, dw = tw - 6, dh = th - 6;
+    // src/ORBextractor.cc:961-976 skip rules (note the asymmetric 3 / 6)
+    if (ini_y >= max_by - 3 || ini_x >= max_bx - 6 || dw <= 0 || dh <= 0) {
+        if (tid == 0) *my_cnt = 0;
+        return;
+    }
+    int pitch;
+    const uint8_t *img = orbx_level_ptr(pr, L, l, b, &pitch);
+    {
+        const int tx = tid & 63, ty = tid >> 6;
+        for (int r = ty; r < th; r += 4) {
+            const uint8_t *row = img + (long long)(ini_y + r) * pitch + ini_x;
+            for (int c = tx; c < tw; c += 64) tile[r * P + c] = row[c];
+        }
+        uint32_t *z = reinterpret_cast<uint32_t *>(sc);
+        for (int i = tid; i < 61 * SP / 4; i += 256) z[i] = 0;
+    }
+    __syncthreads();
+    const int npx = dw * dh;
+    const unsigned magic = 0xFFFFFFFFu / (unsigned)dw + 1u; // floor(p/dw) = umulhi(p, magic) for p < 2^16
+    for (int p = tid; p < npx; p += 256) {
+        const int py = (int)__umulhi((unsigned)p, magic), px = p - py * dw;
+        const int s = fast_score_tile(tile + (py + 3) * P + px + 3, min_th);
+        sc[(py + 1) * SP + px + 1] = (uint8_t)s;
+    }
+    __syncthreads();
+    // NMS over a contiguous run of pixels per thread so that one block scan yields row-major order
+    const int per = (npx + 255) >> 8; // <= 14
+    const int q0 = tid * per, q1 = min(q0 + per, npx);
+    unsigned bits_m = 0, bits_i = 0;
+    {
+        int py = (int)__umulhi((unsigned)q0, magic), px = q0 - py * dw;
+        for (int q = q0; q < q1; q++) {
+            const uint8_t *c = sc + (py + 1) * SP + px + 1;
+            const int s = c[0];
+            if (s > 0 && s > c[-1] && s > c[1] && s > c[-SP - 1] && s > c[-SP] && s > c[-SP + 1] &&
+                s > c[SP - 1] && s > c[SP] && s > c[SP + 1]) {
+                bits_m |= 1u << (q - q0);
+                if (s >= ini_th) bits_i |= 1u << (q - q0);
+            }
+            if (++px == dw) { px = 0; py++; }
+        }
+    }
+    const int use_ini = __syncthreads_or(bits_i != 0);
+    unsigned sel = use_ini ? bits_i : bits_m;
+    int total;
+    int off = block_excl_scan256(__popc(sel), &total, s_w);
+    uint32_t *slot = cand + (long long)b * g->cand_total + L.cand_off + (long long)ci * L.cand_cap;
+    while (sel) {
+        const int k = __ffs(sel) - 1;
+        sel &= sel - 1;
+        const int q = q0 + k;
+        const int py = (int)__umulhi((unsigned)q, magic), px = q - py * dw;
+        const int s = sc[(py + 1) * SP + px + 1];
+        const int X = ini_x + 3 + px - ORBX_MIN_BORDER, Y = ini_y + 3 + py - ORBX_MIN_BORDER;
+        if (off < L.cand_cap) slot[off] = (uint32_t)X | ((uint32_t)Y << 12) | ((uint32_t)s << 24);
+        off++;
+    }
+    if (tid == 0) *my_cnt = min(total, L.cand_cap);
+}
+
+// ================================================================ K3: quadtree cull (E4)
+// ORBextractor::DistributeOctTree (src/ORBextractor.cc:617-915) as a label-propagation problem:
+// every point carries the id (= list position) of its leaf; a sweep counts the four children of
+// every splitting node with LDS atomics, scans to get the new list positions and relabels the
+// points.  Order algebra (validated against the sequential oracle by tests/quadtree_model.py):
+//   new list = reverse(children of split nodes in processing order, n1..n4) ++ unsplit nodes;
+//   phase 1 processes all nodes with >1 point in list order; phase 2 processes them sorted by
+//   (count desc, list position asc) and stops after the split that reaches N leaves.
+// One 256-thread workgroup per (level, image).
+extern __shared__ __align__(16) unsigned char tree_smem[];
+
+__global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const int *__restrict__ cell_cnt,
+                                              const uint32_t *__restrict__ cand, uint32_t *__restrict__ g_pts,
+                                              uint16_t *__restrict__ g_nid, int *__restrict__ lvl_cnt,
+                                              uint32_t *__restrict__ lvl_kp, int lds_pts_cap, int *__restrict__ err_flag)
+{
+    constexpr int NB = ORBX_NODE_BITS, NMASK = (1 << NB) - 1;
+    const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom &L = g->lv[l];
+    const int cap = g->max_node_cap; // multiple of 4
+    int *cnt = reinterpret_cast<int *>(tree_smem);
+    int *cnt_n = cnt + cap;
+    uint2 *box = reinterpret_cast<uint2 *>(cnt_n + cap);
+    uint2 *box_n = box + cap;
+    int *cc = reinterpret_cast<int *>(box_n + cap); // [4*cap] child counts, then child positions
+    int *a1 = cc + 4 * cap;                         // processing rank of split nodes
+    int *a2 = a1 + cap;                             // children per processed node -> S offsets
+    int *a3 = a2 + cap;                             // unsplit flags -> ranks
+    int *a4 = a3 + cap;                             // phase-2 gains
+    int *ncarr = a4 + cap;                          // non-empty children per node (0 = not split)
+    int *cellpref = ncarr + cap;                    // [max_cells_level + 4]
+    uint32_t *lpts = reinterpret_cast<uint32_t *>(cellpref + ((g->max_cells_level + 4) & ~3));
+    uint16_t *lnid = reinterpret_cast<uint16_t *>(lpts + lds_pts_cap);
+    __shared__ int s_w[4];
+    __shared__ int s_acc;
+
+    int *out_cnt = lvl_cnt + (long long)b * g->nlevels + l;
+    // ---- gather this level's candidates (cell-row-major, in-cell row-major)
+    const int *ccnt = cell_cnt + (long long)b * g->total_cells + L.cell_base;
+    for (int c = tid; c < L.n_cells; c += 256) cellpref[c] = ccnt[c];
+    __syncthreads();
+    const int n = lds_excl_scan(cellpref, L.n_cells, s_w);
+    if (n == 0) {
+        if (tid == 0) *out_cnt = 0;
+        return;
+    }
+    uint32_t *pts;
+    uint16_t *nid;
+    if (n <= lds_pts_cap) { pts = lpts; nid = lnid; }
+    else {
+        pts = g_pts + (long long)b * g->cand_total + L.cand_off;
+        nid = g_nid + (long long)b * g->cand_total + L.cand_off;
+    }
+    {
+        const uint32_t *src = cand + (long long)b * g->cand_total + L.cand_off;
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int c = wv; c < L.n_cells; c += 4) {
+            const int beg = cellpref[c], end = c + 1 < L.n_cells ? cellpref[c + 1] : n;
+            const uint32_t *s = src + (long long)c * L.cand_cap;
+            for (int e = lane; e < end - beg; e += 64) pts[beg + e] = s[e];
+        }
+    }
+    // ---- roots (src/ORBextractor.cc:627-705)
+    const int N = L.quota;
+    for (int k = tid; k < L.n_ini; k += 256) cc[k] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        int r = (int)((float)(pts[i] & 0xFFF) / L.hx);
+        r = r < 0 ? 0 : r >= L.n_ini ? L.n_ini - 1 : r;
+        atomicAdd(&cc[r], 1);
+        nid[i] = (uint16_t)r;
+    }
+    __syncthreads();
+    for (int k = tid; k < L.n_ini; k += 256) a1[k] = cc[k] > 0;
+    __syncthreads();
+    int m = lds_excl_scan(a1, L.n_ini, s_w);
+    for (int k = tid; k < L.n_ini; k += 256)
+        if (cc[k] > 0) {
+            const int id = a1[k];
+            const unsigned x0 = (unsigned)(int)(L.hx * (float)k), x1 = (unsigned)(int)(L.hx * (float)(k + 1));
+            box[id] = make_uint2(x0 | (x1 << 16), 0u | ((unsigned)L.tree_h << 16));
+            cnt[id] = cc[k];
+        }
+    for (int i = tid; i < n; i += 256) nid[i] = (uint16_t)a1[nid[i]];
+    __syncthreads();
+
+    // ---- sweeps
+    bool phase2 = false;
+    for (;;) {
+        const int prev = m;
+        for (int k = tid; k < 4 * m; k += 256) cc[k] = 0;
+        if (tid == 0) s_acc = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) { // classify the points of every splittable node
+            const int id = nid[i] & NMASK;
+            int c = 0;
+            if (cnt[id] > 1) {
+                const uint2 bx = box[id];
+                const int x0 = bx.x & 0xFFFF, x1 = bx.x >> 16, y0 = bx.y & 0xFFFF, y1 = bx.y >> 16;
+                const uint32_t p = pts[i];
+                const int x = p & 0xFFF, y = (p >> 12) & 0xFFF;
+                const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1; // ceil(d/2), DivideNode :553-554
+                c = (x >= x0 + hx ? 1 : 0) + (y >= y0 + hy ? 2 : 0);
+                atomicAdd(&cc[id * 4 + c], 1);
+            }
+            nid[i] = (uint16_t)(id | (c << NB));
+        }
+        __syncthreads();
+        int nsplit;
+        if (!phase2) {
+            for (int k = tid; k < m; k += 256) {
+                const int s = cnt[k] > 1;
+                ncarr[k] = s ? (cc[4 * k] > 0) + (cc[4 * k + 1] > 0) + (cc[4 * k + 2] > 0) + (cc[4 * k + 3] > 0) : 0;
+                a1[k] = s;
+                a3[k] = !s;
+            }
+            __syncthreads();
+            nsplit = lds_excl_scan(a1, m, s_w);
+        } else {
+            // processing order: count desc, list position asc (src/ORBextractor.cc:832-834 with the
+            // address tie-break defined as "created later first" == nearer the list front)
+            int ncand_local = 0;
+            for (int k = tid; k < m; k += 256) {
+                const int ck = cnt[k];
+                int r = -1, ncv = 0;
+                if (ck > 1) {
+                    r = 0;
+                    for (int k2 = 0; k2 < m; k2++) {
+                        const int c2 = cnt[k2];
+                        r += (c2 > ck) || (c2 == ck && k2 < k);
+                    }
+                    ncv = (cc[4 * k] > 0) + (cc[4 * k + 1] > 0) + (cc[4 * k + 2] > 0) + (cc[4 * k + 3] > 0);
+                    ncand_local++;
+                }
+                a1[k] = r;
+                ncarr[k] = ncv;
+            }
+            if (ncand_local) atomicAdd(&s_acc, ncand_local);
+            __syncthreads();
+            const int ncand = s_acc;
+            for (int k = tid; k < m; k += 256)
+                if (a1[k] >= 0) { a2[a1[k]] = ncarr[k] - 1; a4[a1[k]] = ncarr[k] - 1; }
+            __syncthreads();
+            if (tid == 0) s_acc = 0;
+            lds_excl_scan(a2, ncand, s_w);
+            int less = 0;
+            for (int r = tid; r < ncand; r += 256) less += (prev + a2[r] + a4[r] < N);
+            if (less) atomicAdd(&s_acc, less);
+            __syncthreads();
+            nsplit = min(ncand, s_acc + 1);
+            __syncthreads();
+            for (int k = tid; k < m; k += 256) {
+                const bool s = a1[k] >= 0 && a1[k] < nsplit;
+                if (!s) ncarr[k] = 0;
+                a3[k] = !s;
+            }
+            if (tid == 0) s_acc = 0;
+            __syncthreads();
+        }
+        for (int k = tid; k < m; k += 256)
+            if (ncarr[k] > 0) a2[a1[k]] = ncarr[k];
+        __syncthreads();
+        const int S = lds_excl_scan(a2, nsplit, s_w);
+        const int U = lds_excl_scan(a3, m, s_w);
+        if (S + U > cap) { // cannot happen (SURVEY.md A.4 bound); never write out of bounds
+            if (tid == 0) { atomicExch(err_flag, 1); *out_cnt = 0; }
+            return;
+        }
+        int expand_local = 0;
+        for (int k = tid; k < m; k += 256) {
+            if (ncarr[k] > 0) {
+                const uint2 bx = box[k];
+                const int x0 = bx.x & 0xFFFF, x1 = bx.x >> 16, y0 = bx.y & 0xFFFF, y1 = bx.y >> 16;
+                const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
+                int pos = S - 1 - a2[a1[k]];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int q = cc[4 * k + c];
+                    if (q > 0) {
+                        const unsigned cx0 = (c & 1) ? x0 + hx : x0, cx1 = (c & 1) ? x1 : x0 + hx;
+                        const unsigned cy0 = (c & 2) ? y0 + hy : y0, cy1 = (c & 2) ? y1 : y0 + hy;
+                        box_n[pos] = make_uint2(cx0 | (cx1 << 16), cy0 | (cy1 << 16));
+                        cnt_n[pos] = q;
+                        expand_local += q > 1;
+                        cc[4 * k + c] = pos;
+                        pos--;
+                    }
+                }
+            } else {
+                const int pos = S + a3[k];
+                box_n[pos] = box[k];
+                cnt_n[pos] = cnt[k];
+                cc[4 * k] = cc[4 * k + 1] = cc[4 * k + 2] = cc[4 * k + 3] = pos;
+            }
+        }
+        if (expand_local) atomicAdd(&s_acc, expand_local);
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const int v = nid[i];
+            nid[i] = (uint16_t)cc[(v & NMASK) * 4 + (v >> NB)];
+        }
+        m = S + U;
+        { int *t = cnt; cnt = cnt_n; cnt_n = t; }
+        { uint2 *t = box; box = box_n; box_n = t; }
+        const int n_to_expand = s_acc;
+        __syncthreads();
+        if (m >= N || m == prev) break;                          // :803-806, :883-884
+        if (!phase2 && m + 3 * n_to_expand > N) phase2 = true;   // :814
+    }
+
+    // ---- one keypoint per leaf: max response, first in list order wins ties (:895-912)
+    unsigned *best = reinterpret_cast<unsigned *>(cc);
+    for (int k = tid; k < m; k += 256) best[k] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256)
+        atomicMax(&best[nid[i] & NMASK], ((pts[i] >> 24) << 24) | (0xFFFFFFu - (unsigned)i));
+    __syncthreads();
+    uint32_t *okp = lvl_kp + (long long)b * g->kp_total + L.kp_off;
+    for (int k = tid; k < m; k += 256) {
+        const uint32_t p = pts[0xFFFFFFu - (best[k] & 0xFFFFFFu)];
+        const unsigned x = (p & 0xFFF) + ORBX_MIN_BORDER, y = ((p >> 12) & 0xFFF) + ORBX_MIN_BORDER;
+        if (k < L.kp_cap) okp[k] = x | (y << 12) | (p & 0xFF000000u);
+    }
+    if (tid == 0) *out_cnt = min(m, L.kp_cap);
+}
+
+// ================================================================ K4: orientation + blur + rBRIEF (E5-E8)
+// One wave per keypoint.  The 43x43 unblurred patch is staged in LDS with BORDER_REFLECT_101 at
+// the image edge (the reference blurs a clone of the level, src/ORBextractor.cc:1312-1314), the
+// intensity centroid is taken on it (IC_Angle, :83-111), the 7x7 sigma=2 fixed-point Gaussian is
+// applied to the patch only (never materialising the blurred level), and the 256 steered pairs are
+// compared with one ballot per 64 pairs (computeOrbDescriptor, :116-157).
+__global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef pr, const int *__restrict__ lvl_cnt,
+                                             const uint32_t *__restrict__ lvl_kp, orbx_keypoint *__restrict__ out_kps,
+                                             uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap)
+{
+    __shared__ uint8_t raw[43 * 44];
+    __shared__ uint16_t hb[43 * 38];
+    __shared__ uint8_t bl[37 * 40];
+    const int slot = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    int l = 0;
+    while (l + 1 < g->nlevels && slot >= g->lv[l + 1].kp_off) l++;
+    const LevelGeom &L = g->lv[l];
+    const int *lc = lvl_cnt + (long long)b * g->nlevels;
+    int off = 0, total = 0;
+    for (int i = 0; i < g->nlevels; i++) { const int c = lc[i]; if (i < l) off += c; total += c; }
+    if (slot == 0 && lane == 0) out_n[b] = total < cap ? total : cap;
+    const int j = slot - L.kp_off;
+    if (j >= lc[l]) return;
+    const int idx = off + j;
+    if (idx >= cap) return;
+    const uint32_t p = lvl_kp[(long long)b * g->kp_total + slot];
+    const int x = p & 0xFFF, y = (p >> 12) & 0xFFF, resp = p >> 24;
+    int pitch;
+    const uint8_t *img = orbx_level_ptr(pr, L, l, b, &pitch);
+    for (int e = lane; e < 43 * 43; e += 64) {
+        const int r = e / 43, c = e - r * 43;
+        raw[r * 44 + c] = img[(long long)reflect101(y - 21 + r, L.h) * pitch + reflect101(x - 21 + c, L.w)];
+    }
+    __syncthreads();
+    // IC_Angle: lane = (row v+15, half); integer moments, order-independent
+    int m10 = 0, m01 = 0;
+    if (lane < 62) {
+        const int v = (lane >> 1) - 15, dmax = c_umax[v < 0 ? -v : v];
+        const int u0 = (lane & 1) ? 0 : -dmax, u1 = (lane & 1) ? dmax : -1;
+        const uint8_t *row = raw + (21 + v) * 44 + 21;
+        int rs = 0;
+        for (int u = u0; u <= u1; u++) { const int I = row[u]; rs += I; m10 += u * I; }
+        m01 = v * rs;
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    const float angle = dev_fast_atan2((float)m01, (float)m10);
+    // separable blur on the patch
+    for (int e = lane; e < 43 * 37; e += 64) {
+        const int r = e / 37, c = e - r * 37;
+        const uint8_t *s = raw + r * 44 + c;
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) acc += c_gauss[k] * s[k];
+        hb[r * 38 + c] = (uint16_t)acc;
+    }
+    __syncthreads();
+    for (int e = lane; e < 37 * 37; e += 64) {
+        const int r = e / 37, c = e - r * 37;
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) acc += c_gauss[k] * hb[(r + k) * 38 + c];
+        const int v = (acc + (1 << 15)) >> 16;
+        bl[r * 40 + c] = (uint8_t)(v > 255 ? 255 : v);
+    }
+    __syncthreads();
+    const float factor_pi = (float)(3.14159265358979323846 / 180.f);
+    float sn, cs;
+    dev_sincos(angle * factor_pi, &sn, &cs);
+    const float a = cs, bb = sn;
+    unsigned long long words[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+        const int pi = lane + 64 * jj;
+        const float x0 = (float)c_pat[0][pi], y0 = (float)c_pat[1][pi], x1 = (float)c_pat[2][pi], y1 = (float)c_pat[3][pi];
+        const int r0 = dev_cv_round(x0 * bb + y0 * a), q0 = dev_cv_round(x0 * a - y0 * bb);
+        const int r1 = dev_cv_round(x1 * bb + y1 * a), q1 = dev_cv_round(x1 * a - y1 * bb);
+        const int t0 = bl[(18 + r0) * 40 + 18 + q0], t1 = bl[(18 + r1) * 40 + 18 + q1];
+        words[jj] = __ballot(t0 < t1);
+    }
+    if (lane == 0) {
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(out_desc + ((long long)b * cap + idx) * 32);
+        d[0] = words[0]; d[1] = words[1]; d[2] = words[2]; d[3] = words[3];
+        orbx_keypoint kp;
+        kp.x = (float)x; kp.y = (float)y;
+        if (l != 0) { kp.x *= L.scale; kp.y *= L.scale; } // :1326-1334
+        kp.size = (float)L.patch_size;
+        kp.angle = angle;
+        kp.response = (float)resp;
+        kp.octave = l;
+        kp.class_id = -1;
+        out_kps[(long long)b * cap + idx] = kp;
+    }
+}
+
+// ================================================================ host side
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// cv::resize coefficient tables, reference call site src/ORBextractor.cc:1366
+static void linear_tables(int ssize, int dsize, int16_t *ofs, int16_t *c0, int16_t *c1)
+{
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1. / inv_scale;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floor((double)f);
+        f -= s;
+        if (s < 0) { f = 0; s = 0; }
+        if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        int v0 = orbx_cv_round((1.f - f) * 2048), v1 = orbx_cv_round(f * 2048);
+        ofs[d] = (int16_t)s;
+        c0[d] = (int16_t)(v0 < -32768 ? -32768 : v0 > 32767 ? 32767 : v0);
+        c1[d] = (int16_t)(v1 < -32768 ? -32768 : v1 > 32767 ? 32767 : v1);
+    }
+}
+
+template <class T>
+static int ensure(T **p, size_t *cap, size_t need)
+{
+    if (need <= *cap && *p) return ORBX_OK;
+    if (*p) { ORBX_HIP(hipFree(*p)); *p = nullptr; *cap = 0; }
+    ORBX_HIP(hipMalloc((void **)p, need ? need : 16));
+    *cap = need;
+    return ORBX_OK;
+}
+
+static size_t tree_lds_bytes(const Geom &G, int lds_pts_cap)
+{
+    const size_t cap = G.max_node_cap;
+    return cap * (4 + 4 + 8 + 8 + 16 + 4 * 5) + (size_t)((G.max_cells_level + 4) & ~3) * 4 + (size_t)lds_pts_cap * 6 + 64;
+}
+static const int kLdsPtsCap = 12288;
+
+int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
+{
+    if (e->geom.w == w && e->geom.h == h) return ORBX_OK;
+    if (w > e->max_w || h > e->max_h || w > ORBX_MAX_DIM || h > ORBX_MAX_DIM) {
+        orbx_set_error("image %dx%d exceeds the extractor's maximum %dx%d", w, h, e->max_w, e->max_h);
+        return ORBX_E_INVALID;
+    }
+    Geom G;
+    memset(&G, 0, sizeof G);
+    G.nlevels = e->nlevels; G.w = w; G.h = h;
+    size_t tab_units = 0;
+    for (int l = 0; l < e->nlevels; l++) {
+        LevelGeom &L = G.lv[l];
+        L.w = orbx_cv_round((float)w * e->isf[l]);   // src/ORBextractor.cc:1353
+        L.h = orbx_cv_round((float)h * e->isf[l]);
+        const int min_b = ORBX_MIN_BORDER, max_bx = L.w - ORBX_EDGE + 3, max_by = L.h - ORBX_EDGE + 3;
+        const float width = (float)(max_bx - min_b), height = (float)(max_by - min_b);
+        if (max_bx - min_b < 30 || max_by - min_b < 30) {
+            orbx_set_error("level %d (%dx%d) is smaller than one 30-px FAST cell", l, L.w, L.h);
+            return ORBX_E_TOO_SMALL;
+        }
+        L.n_cols = (int)(width / 30.f);               // :946-951
+        L.n_rows = (int)(height / 30.f);
+        L.w_cell = (int)ceilf(width / L.n_cols);
+        L.h_cell = (int)ceilf(height / L.n_rows);
+        if (L.w_cell > 59 || L.h_cell > 59) { orbx_set_error("internal: cell larger than 59"); return ORBX_E_INVALID; }
+        L.n_cells = L.n_cols * L.n_rows;
+        L.cell_base = G.total_cells;
+        G.total_cells += L.n_cells;
+        L.cand_cap = ((L.w_cell + 1) / 2) * ((L.h_cell + 1) / 2); // strict 3x3 maxima cannot be adjacent
+        L.cand_off = G.cand_total;
+        G.cand_total += (long long)L.n_cells * L.cand_cap;
+        L.quota = e->quota[l];
+        L.tree_w = max_bx - min_b; L.tree_h = max_by - min_b;
+        L.n_ini = (int)roundf((float)L.tree_w / L.tree_h); // :627
+        if (L.n_ini < 1) { orbx_set_error("level %d: aspect ratio gives zero quadtree roots (reference divides by zero)", l); return ORBX_E_TOO_SMALL; }
+        L.hx = (float)L.tree_w / L.n_ini;                  // :628
+        int nc = L.quota + 3 > 4 * L.n_ini ? L.quota + 3 : 4 * L.n_ini;
+        L.node_cap = (nc + 4 + 3) & ~3;
+        if (L.node_cap >= (1 << ORBX_NODE_BITS)) { orbx_set_error("nfeatures too large for the quadtree kernel"); return ORBX_E_INVALID; }
+        L.kp_cap = L.node_cap; L.kp_off = G.kp_total; G.kp_total += L.kp_cap;
+        L.scale = e->sf[l];
+        L.patch_size = (int)(31 * e->sf[l]);               // :1023
+        if (l >= 1) {
+            L.pitch = (int)align_up(L.w, 64);
+            L.pyr_off = G.pyr_bytes;
+            G.pyr_bytes += (long long)L.pitch * L.h;
+            L.tab_x = (int)tab_units; tab_units += 3 * (size_t)L.w;
+            L.tab_y = (int)tab_units; tab_units += 3 * (size_t)L.h;
+        }
+        if (L.n_cells > G.max_cells_level) G.max_cells_level = L.n_cells;
+        if (L.node_cap > G.max_node_cap) G.max_node_cap = L.node_cap;
+    }
+    G.pyr_bytes = (long long)align_up((size_t)G.pyr_bytes, 256);
+    // resize tables
+    std::vector<int16_t> tabs(tab_units ? tab_units : 1);
+    for (int l = 1; l < e->nlevels; l++) {
+        LevelGeom &L = G.lv[l];
+        const LevelGeom &S = G.lv[l - 1];
+        linear_tables(S.w, L.w, &tabs[L.tab_x], &tabs[L.tab_x + L.w], &tabs[L.tab_x + 2 * L.w]);
+        linear_tables(S.h, L.h, &tabs[L.tab_y], &tabs[L.tab_y + L.h], &tabs[L.tab_y + 2 * L.h]);
+    }
+    if (tree_lds_bytes(G, kLdsPtsCap) > 160 * 1024) { orbx_set_error("nfeatures too large for the quadtree kernel's LDS"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(hipStreamSynchronize(e->stream));
+    const size_t B = e->max_batch;
+    int rc;
+    if ((rc = ensure(&e->d_tabs, &e->tabs_cap, tabs.size() * 2))) return rc;
+    if ((rc = ensure(&e->d_pyr, &e->pyr_cap, (size_t)G.pyr_bytes * B))) return rc;
+    if ((rc = ensure(&e->d_cell_cnt, &e->cell_cnt_cap, (size_t)G.total_cells * B * 4))) return rc;
+    if ((rc = ensure(&e->d_cand, &e->cand_cap, (size_t)G.cand_total * B * 4))) return rc;
+    {
+        size_t need = (size_t)G.cand_total * B;
+        if (need > e->tree_cap || !e->d_tree_pts) {
+            if (e->d_tree_pts) ORBX_HIP(hipFree(e->d_tree_pts));
+            if (e->d_tree_nid) ORBX_HIP(hipFree(e->d_tree_nid));
+            e->d_tree_pts = nullptr; e->d_tree_nid = nullptr;
+            ORBX_HIP(hipMalloc((void **)&e->d_tree_pts, need * 4));
+            ORBX_HIP(hipMalloc((void **)&e->d_tree_nid, need * 2));
+            e->tree_cap = need;
+        }
+    }
+    if ((rc = ensure(&e->d_lvl_kp, &e->lvl_kp_cap, (size_t)G.kp_total * B * 4))) return rc;
+    ORBX_HIP(hipMemcpy(e->d_tabs, tabs.data(), tabs.size() * 2, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(e->d_geom, &G, sizeof G, hipMemcpyHostToDevice));
+    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)tree_lds_bytes(G, kLdsPtsCap)));
+    e->geom = G;
+    return ORBX_OK;
+}
+
+static int upload_constants(orbx_extractor *e)
+{
+    signed char pat[4][256];
+    memcpy(pat[0], ORB_PAT_X0, 256); memcpy(pat[1], ORB_PAT_Y0, 256);
+    memcpy(pat[2], ORB_PAT_X1, 256); memcpy(pat[3], ORB_PAT_Y1, 256);
+    ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pat), pat, sizeof pat));
+    ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), e->umax, sizeof(int) * 16));
+    // cv::getGaussianKernel(7, 2, CV_32F) -> 8-bit fixed point
+    float cf[7]; double sum = 0; const double scale2x = -0.5 / (2.0 * 2.0);
+    for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)exp(scale2x * x * x); sum += cf[i]; }
+    sum = 1. / sum;
+    int taps[7];
+    for (int i = 0; i < 7; i++) { cf[i] = (float)(cf[i] * sum); taps[i] = (int)lrint((double)cf[i] * 256.0); }
+    ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), taps, sizeof taps));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extractor_create(orbx_extractor **out, int nfeatures, float scale_factor, int nlevels,
+                                     int ini_th, int min_th, int device, int max_w, int max_h, int max_batch)
+{
+    if (!out) { orbx_set_error("out is NULL"); return ORBX_E_INVALID; }
+    *out = nullptr;
+    if (nfeatures < 1 || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || !(scale_factor > 1.0f) || max_batch < 1 ||
+        max_w < 1 || max_h < 1 || ini_th < 1 || min_th < 1 || ini_th > 255 || min_th > ini_th) {
+        orbx_set_error("orbx_extractor_create: invalid parameter");
+        return ORBX_E_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) {
+        orbx_set_error("no usable HIP device (requested %d of %d); liborbx has no CPU fallback", device, ndev);
+        return ORBX_E_NO_DEVICE;
+    }
+    ORBX_HIP(hipSetDevice(device));
+    orbx_extractor *e = new orbx_extractor();
+    e->device = device; e->nfeatures = nfeatures; e->nlevels = nlevels; e->ini_th = ini_th; e->min_th = min_th;
+    e->scale_factor = scale_factor; e->max_w = max_w; e->max_h = max_h; e->max_batch = max_batch;
+    // src/ORBextractor.cc:436-461
+    e->sf[0] = 1.0f; e->sig2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) { e->sf[i] = (float)(e->sf[i - 1] * e->scale_factor); e->sig2[i] = e->sf[i] * e->sf[i]; }
+    for (int i = 0; i < nlevels; i++) { e->isf[i] = 1.0f / e->sf[i]; e->isig2[i] = 1.0f / e->sig2[i]; }
+    // :468-493
+    float factor = (float)(1.0f / e->scale_factor);
+    float n_desired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; l++) { e->quota[l] = orbx_cv_round(n_desired); sum += e->quota[l]; n_desired *= factor; }
+    e->quota[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+    // :510-533
+    {
+        int v, v0, vmax = (int)floor(15 * sqrtf(2.f) / 2 + 1), vmin = (int)ceil(15 * sqrtf(2.f) / 2);
+        const double hp2 = 15 * 15;
+        for (v = 0; v <= vmax; ++v) e->umax[v] = (int)lrint(sqrt(hp2 - v * v));
+        for (v = 15, v0 = 0; v >= vmin; --v) { while (e->umax[v0] == e->umax[v0 + 1]) ++v0; e->umax[v] = v0; ++v0; }
+    }
+    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) { orbx_set_error("hipStreamCreate failed: %s", hipGetErrorString(he)); delete e; return ORBX_E_HIP; }
+    int rc = upload_constants(e);
+    if (rc == ORBX_OK && hipMalloc((void **)&e->d_geom, sizeof(Geom)) != hipSuccess) { orbx_set_error("hipMalloc failed"); rc = ORBX_E_HIP; }
+    if (rc == ORBX_OK && hipMalloc((void **)&e->d_lvl_cnt, sizeof(int) * (size_t)max_batch * nlevels + 16) != hipSuccess) { orbx_set_error("hipMalloc failed"); rc = ORBX_E_HIP; }
+    if (rc != ORBX_OK) { orbx_extractor_destroy(e); return rc; }
+    // last int of d_lvl_cnt is the kernel error flag
+    hipMemset(e->d_lvl_cnt, 0, sizeof(int) * (size_t)max_batch * nlevels + 16);
+    *out = e;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_extractor_destroy(orbx_extractor *e)
+{
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (auto &ev : e->prof_ev) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+    void *ptrs[] = { e->d_geom, e->d_tabs, e->d_pyr, e->d_stage_in, e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid,
+                     e->d_lvl_cnt, e->d_lvl_kp, e->d_out_kps, e->d_out_desc, e->d_out_n, e->d_out_ur, e->d_out_depth, e->d_st_dist };
+    for (void *p : ptrs) if (p) hipFree(p);
+    for (void *p : e->scratch) if (p) hipFree(p);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int orbx_get_levels(const orbx_extractor *e) { return e ? e->nlevels : ORBX_E_INVALID; }
+extern "C" float orbx_get_scale_factor(const orbx_extractor *e) { return e ? (float)e->scale_factor : 0.f; }
+extern "C" int orbx_get_scale_tables(const orbx_extractor *e, float *s, float *is, float *g2, float *ig2)
+{
+    if (!e) { orbx_set_error("null extractor"); return ORBX_E_INVALID; }
+    for (int i = 0; i < e->nlevels; i++) {
+        if (s) s[i] = e->sf[i];
+        if (is) is[i] = e->isf[i];
+        if (g2) g2[i] = e->sig2[i];
+        if (ig2) ig2[i] = e->isig2[i];
+    }
+    return ORBX_OK;
+}
+extern "C" int orbx_get_features_per_level(const orbx_extractor *e, int *q)
+{
+    if (!e || !q) { orbx_set_error("null argument"); return ORBX_E_INVALID; }
+    for (int i = 0; i < e->nlevels; i++) q[i] = e->quota[i];
+    return ORBX_OK;
+}
+
+extern "C" int orbx_max_keypoints(const orbx_extractor *e, int w, int h)
+{
+    if (!e || w < 1 || h < 1) { orbx_set_error("invalid argument"); return ORBX_E_INVALID; }
+    int total = 0;
+    for (int l = 0; l < e->nlevels; l++) {
+        const int lw = orbx_cv_round((float)w * e->isf[l]), lh = orbx_cv_round((float)h * e->isf[l]);
+        const int tw = lw - 32, th = lh - 32;
+        if (tw < 30 || th < 30) { orbx_set_error("image too small"); return ORBX_E_TOO_SMALL; }
+        const int n_ini = (int)roundf((float)tw / th);
+        const int nc = e->quota[l] + 3 > 4 * n_ini ? e->quota[l] + 3 : 4 * n_ini;
+        total += (nc + 4 + 3) & ~3;
+    }
+    return total;
+}
+
+extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, size_t img_stride, size_t pitch,
+                                         int batch, int w, int h, void *d_kps, void *d_desc, int cap, void *d_n_out,
+                                         void *stream)
+{
+    if (!e || !d_imgs || !d_kps || !d_desc || !d_n_out || batch < 1 || batch > e->max_batch || w < 1 || h < 1 ||
+        pitch < (size_t)w || (batch > 1 && img_stride < pitch * (size_t)h)) {
+        orbx_set_error("orbx_extract_batch_device: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    ORBX_HIP(hipSetDevice(e->device));
+    int rc = orbx_prepare_geometry(e, w, h);
+    if (rc) return rc;
+    const Geom &G = e->geom;
+    if (cap < G.kp_total) {
+        orbx_set_error("keypoint capacity %d < orbx_max_keypoints() = %d", cap, G.kp_total);
+        return ORBX_E_CAPACITY;
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    PyrRef pr;
+    pr.img0 = (const uint8_t *)d_imgs; pr.img0_stride = (long long)img_stride; pr.img0_pitch = (int)pitch;
+    pr.pyr = e->d_pyr; pr.pyr_stride = G.pyr_bytes;
+    e->last_img0 = pr.img0; e->last_img_stride = img_stride; e->last_pitch = pitch; e->last_batch = batch;
+
+    for (int l = 1; l < G.nlevels; l++) {
+        const LevelGeom &L = G.lv[l];
+        dim3 grid((L.pitch / 4 + 63) / 64, (L.h + 3) / 4, batch), block(64, 4);
+        orbx_prof_begin(e, ORBX_STAGE_RESIZE, s);
+        hipLaunchKernelGGL(k_resize, grid, block, 0, s, e->d_geom, l, pr, e->d_pyr, e->d_tabs);
+        orbx_prof_end(e, s);
+    }
+    orbx_prof_begin(e, ORBX_STAGE_FAST, s);
+    hipLaunchKernelGGL(k_fast, dim3(G.total_cells, batch), dim3(256), 0, s, e->d_geom, pr, e->d_cell_cnt, e->d_cand,
+                       e->ini_th, e->min_th);
+    orbx_prof_end(e, s);
+    int *err_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;
+    orbx_prof_begin(e, ORBX_STAGE_TREE, s);
+    hipLaunchKernelGGL(k_tree, dim3(G.nlevels, batch), dim3(256), tree_lds_bytes(G, kLdsPtsCap), s, e->d_geom,
+                       e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, kLdsPtsCap, err_flag);
+    orbx_prof_end(e, s);
+    orbx_prof_begin(e, ORBX_STAGE_DESC, s);
+    hipLaunchKernelGGL(k_desc, dim3(G.kp_total, batch), dim3(64), 0, s, e->d_geom, pr, e->d_lvl_cnt, e->d_lvl_kp,
+                       (orbx_keypoint *)d_kps, (uint8_t *)d_desc, (int *)d_n_out, cap);
+    orbx_prof_end(e, s);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+extern "C" int orbx_sync(orbx_extractor *e, void *stream)
+{
+    if (!e) { orbx_set_error("null extractor"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(hipStreamSynchronize(stream ? (hipStream_t)stream : e->stream));
+    int flag = 0;
+    ORBX_HIP(hipMemcpy(&flag, e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) { orbx_set_error("quadtree kernel reported a node-table overflow"); return ORBX_E_CAPACITY; }
+    return ORBX_OK;
+}
+
+int orbx_ensure_out_staging(orbx_extractor *e, int batch, int cap)
+{
+    if (e->d_out_kps && e->out_cap >= cap && e->out_batch >= batch) return ORBX_OK;
+    void **ps[] = { &e->d_out_kps, &e->d_out_desc, &e->d_out_n, (void **)&e->d_out_ur, (void **)&e->d_out_depth };
+    for (void **p : ps) if (*p) { ORBX_HIP(hipFree(*p)); *p = nullptr; }
+    const size_t n = (size_t)batch * cap;
+    ORBX_HIP(hipMalloc(&e->d_out_kps, n * sizeof(orbx_keypoint)));
+    ORBX_HIP(hipMalloc(&e->d_out_desc, n * 32));
+    ORBX_HIP(hipMalloc(&e->d_out_n, sizeof(int) * batch));
+    ORBX_HIP(hipMalloc((void **)&e->d_out_ur, n * 4));
+    ORBX_HIP(hipMalloc((void **)&e->d_out_depth, n * 4));
+    e->out_cap = cap; e->out_batch = batch;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch(orbx_extractor *e, const uint8_t *const *imgs, int batch, int w, int h, size_t stride,
+                                  orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out)
+{
+    if (!e || !imgs || !kps || !desc || !n_out || batch < 1 || batch > e->max_batch || w < 0 || h < 0) {
+        orbx_set_error("orbx_extract_batch: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    if (w == 0 || h == 0) { for (int i = 0; i < batch; i++) n_out[i] = 0; return ORBX_OK; } // reference :1264
+    if (stride < (size_t)w) { orbx_set_error("stride < width"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipSetDevice(e->device));
+    int rc = orbx_prepare_geometry(e, w, h);
+    if (rc) return rc;
+    const int need = e->geom.kp_total;
+    if (cap < need) { orbx_set_error("keypoint capacity %d < orbx_max_keypoints() = %d", cap, need); return ORBX_E_CAPACITY; }
+    const size_t pitch = align_up(w, 64), img_bytes = pitch * h;
+    if ((rc = ensure(&e->d_stage_in, &e->stage_in_cap, img_bytes * e->max_batch))) return rc;
+    if ((rc = orbx_ensure_out_staging(e, e->max_batch, need))) return rc;
+    for (int i = 0; i < batch; i++) {
+        if (!imgs[i]) { orbx_set_error("imgs[%d] is NULL", i); return ORBX_E_INVALID; }
+        ORBX_HIP(hipMemcpy2DAsync(e->d_stage_in + img_bytes * i, pitch, imgs[i], stride, w, h, hipMemcpyHostToDevice, e->stream));
+    }
+    rc = orbx_extract_batch_device(e, e->d_stage_in, img_bytes, pitch, batch, w, h, e->d_out_kps, e->d_out_desc, need, e->d_out_n, nullptr);
+    if (rc) return rc;
+    ORBX_HIP(hipMemcpyAsync(n_out, e->d_out_n, sizeof(int) * batch, hipMemcpyDeviceToHost, e->stream));
+    rc = orbx_sync(e, nullptr);
+    if (rc) return rc;
+    for (int i = 0; i < batch; i++) {
+        ORBX_HIP(hipMemcpyAsync(kps + (size_t)i * cap, (orbx_keypoint *)e->d_out_kps + (size_t)i * need,
+                                sizeof(orbx_keypoint) * n_out[i], hipMemcpyDeviceToHost, e->stream));
+        ORBX_HIP(hipMemcpyAsync(desc + (size_t)i * cap * 32, (uint8_t *)e->d_out_desc + (size_t)i * need * 32,
+                                (size_t)32 * n_out[i], hipMemcpyDeviceToHost, e->stream));
+    }
+    ORBX_HIP(hipStreamSynchronize(e->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract(orbx_extractor *e, const uint8_t *img, int w, int h, size_t stride,
+                            orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out)
+{
+    const uint8_t *imgs[1] = { img };
+    if (!img && w > 0 && h > 0) { orbx_set_error("img is NULL"); return ORBX_E_INVALID; }
+    return orbx_extract_batch(e, imgs, 1, w, h, stride, kps, desc, cap, n_out);
+}
+
+extern "C" int orbx_pyramid_level(orbx_extractor *e, int image_index, int level, uint8_t *dst, size_t dst_stride, int *w, int *h)
+{
+    if (!e || !e->geom.w || !e->last_img0 || level < 0 || level >= e->nlevels || image_index < 0 || image_index >= e->last_batch) {
+        orbx_set_error("orbx_pyramid_level: no pyramid / bad index");
+        return ORBX_E_INVALID;
+    }
+    const LevelGeom &L = e->geom.lv[level];
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    if (!dst) return ORBX_OK;
+    if (dst_stride < (size_t)L.w) { orbx_set_error("dst_stride < level width"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(hipStreamSynchronize(e->stream));
+    const uint8_t *src; size_t pitch;
+    if (level == 0) { src = e->last_img0 + e->last_img_stride * image_index; pitch = e->last_pitch; }
+    else { src = e->d_pyr + (size_t)e->geom.pyr_bytes * image_index + L.pyr_off; pitch = L.pitch; }
+    ORBX_HIP(hipMemcpy2D(dst, dst_stride, src, pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_debug_level_counts(orbx_extractor *e, int image_index, int32_t *counts)
+{
+    if (!e || !counts || image_index < 0 || image_index >= e->last_batch) { orbx_set_error("bad argument"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(hipStreamSynchronize(e->stream));
+    ORBX_HIP(hipMemcpy(counts, e->d_lvl_cnt + (size_t)image_index * e->nlevels, sizeof(int) * e->nlevels, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_debug_candidates(orbx_extractor *e, int image_index, int level, int32_t *x, int32_t *y, int32_t *resp, int cap, int *n)
+{
+    if (!e || !n || !e->geom.w || level < 0 || level >= e->nlevels || image_index < 0 || image_index >= e->last_batch) {
+        orbx_set_error("bad argument");
+        return ORBX_E_INVALID;
+    }
+    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(hipStreamSynchronize(e->stream));
+    const Geom &G = e->geom;
+    const LevelGeom &L = G.lv[level];
+    std::vector<int> cnt(L.n_cells);
+    std::vector<uint32_t> slots((size_t)L.n_cells * L.cand_cap);
+    ORBX_HIP(hipMemcpy(cnt.data(), e->d_cell_cnt + (size_t)image_index * G.total_cells + L.cell_base, sizeof(int) * L.n_cells, hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpy(slots.data(), e->d_cand + (size_t)image_index * G.cand_total + L.cand_off, slots.size() * 4, hipMemcpyDeviceToHost));
+    int k = 0;
+    for (int c = 0; c < L.n_cells; c++)
+        for (int i = 0; i < cnt[c]; i++, k++)
+            if (k < cap && x && y && resp) {
+                const uint32_t p = slots[(size_t)c * L.cand_cap + i];
+                x[k] = p & 0xFFF; y[k] = (p >> 12) & 0xFFF; resp[k] = p >> 24;
+            }
+    *n = k;
+    return ORBX_OK;
+}
+
+int orbx_scratch(orbx_extractor *e, int slot, size_t bytes, void **out)
+{
+    if (bytes > e->scratch_cap[slot] || !e->scratch[slot]) {
+        if (e->scratch[slot]) { ORBX_HIP(hipFree(e->scratch[slot])); e->scratch[slot] = nullptr; e->scratch_cap[slot] = 0; }
+        ORBX_HIP(hipMalloc(&e->scratch[slot], bytes ? bytes : 16));
+        e->scratch_cap[slot] = bytes;
+    }
+    *out = e->scratch[slot];
+    return ORBX_OK;
+}

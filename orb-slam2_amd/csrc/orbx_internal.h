@@ -1,0 +1,105 @@
+// orbx_internal.h — shared host/device definitions of liborbx (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/orbx.h"
+
+#define ORBX_MAX_LEVELS 16
+#define ORBX_EDGE 19          // EDGE_THRESHOLD, reference src/ORBextractor.cc:74
+#define ORBX_MIN_BORDER 16    // EDGE_THRESHOLD-3, src/ORBextractor.cc:934
+#define ORBX_TILE_PITCH 72    // LDS pitch of a FAST cell tile (cell side <= 59 + 6 halo)
+#define ORBX_SCORE_PITCH 64   // LDS pitch of a FAST cell score tile (detect side <= 59 + 2)
+#define ORBX_MAX_DIM 4096     // packed candidate = x | y<<12 | score<<24
+#define ORBX_NODE_BITS 14     // quadtree node id bits inside the per-point label
+
+// Geometry of one pyramid level for one image size (host computes, device reads).
+struct LevelGeom {
+    int w, h, pitch;        // pitch in bytes of the stored level (levels >= 1)
+    long long pyr_off;      // byte offset of the level inside one image's pyramid block (levels >= 1)
+    int n_cols, n_rows, w_cell, h_cell; // FAST cell grid, src/ORBextractor.cc:944-951
+    int cell_base, n_cells; // index range of this level's cells in the per-image cell arrays
+    int cand_cap;           // candidate slots per cell
+    long long cand_off;     // first slot (u32 units) of this level in the per-image candidate block
+    int quota;              // mnFeaturesPerLevel
+    int n_ini; float hx;    // quadtree roots, src/ORBextractor.cc:627-628
+    int tree_w, tree_h;     // maxBorder - minBorder
+    int node_cap;           // max simultaneous quadtree leaves (+slack)
+    int kp_off, kp_cap;     // slot range in the per-image per-level keypoint staging
+    float scale;            // mvScaleFactor[level]
+    int patch_size;         // (int)(31*scale)
+    int tab_x, tab_y;       // offsets (int16 units) of the resize tables [ofs|c0|c1] x 3*w / 3*h
+};
+
+struct Geom {
+    int nlevels, w, h;
+    int total_cells;        // per image
+    long long cand_total;   // per image, u32 units
+    int kp_total;           // per image staging slots
+    long long pyr_bytes;    // per image, levels >= 1
+    int max_cells_level;    // max n_cells over levels
+    int max_node_cap;
+    LevelGeom lv[ORBX_MAX_LEVELS];
+};
+
+struct ProfEvent { hipEvent_t a, b; int stage; };
+
+struct orbx_extractor {
+    int device;
+    int nfeatures, nlevels, ini_th, min_th;
+    double scale_factor;
+    int max_w, max_h, max_batch;
+    float sf[ORBX_MAX_LEVELS], isf[ORBX_MAX_LEVELS], sig2[ORBX_MAX_LEVELS], isig2[ORBX_MAX_LEVELS];
+    int quota[ORBX_MAX_LEVELS];
+    int umax[16];
+
+    hipStream_t stream;
+    // geometry of the current image size
+    Geom geom;           // host copy (geom.w == 0: none yet)
+    Geom *d_geom;        // device copy
+    int16_t *d_tabs; size_t tabs_cap;      // resize tables
+    // workspace (sized for max_w x max_h x max_batch)
+    uint8_t *d_pyr; size_t pyr_cap;        // levels >= 1, all images
+    uint8_t *d_stage_in; size_t stage_in_cap; // host-API input staging (level 0)
+    int *d_cell_cnt; size_t cell_cnt_cap;
+    uint32_t *d_cand; size_t cand_cap;
+    uint32_t *d_tree_pts; uint16_t *d_tree_nid; size_t tree_cap; // overflow scratch of the quadtree
+    int *d_lvl_cnt;                        // [max_batch][nlevels]
+    uint32_t *d_lvl_kp; size_t lvl_kp_cap; // [max_batch][kp_total]
+    // host-API output staging
+    void *d_out_kps, *d_out_desc, *d_out_n; int out_cap; int out_batch;
+    float *d_out_ur, *d_out_depth;
+    // stereo scratch
+    int *d_st_dist; size_t st_cap;         // SAD per left keypoint (or -1)
+    void *scratch[8]; size_t scratch_cap[8]; // host-API upload buffers
+    // state of the most recent extract
+    const uint8_t *last_img0; size_t last_img_stride, last_pitch; int last_batch;
+    // profiling
+    bool prof; std::vector<ProfEvent> prof_ev; float prof_ms[ORBX_STAGE_COUNT]; int prof_n[ORBX_STAGE_COUNT];
+};
+
+void orbx_set_error(const char *fmt, ...);
+#define ORBX_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    orbx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return ORBX_E_HIP; } } while (0)
+
+// host-side exact arithmetic helpers shared by the .hip files
+static inline int orbx_cv_round(float v) { return (int)lrintf(v); }
+
+int orbx_prepare_geometry(orbx_extractor *e, int w, int h);
+void orbx_prof_begin(orbx_extractor *e, int stage, hipStream_t s);
+void orbx_prof_end(orbx_extractor *e, hipStream_t s);
+int orbx_ensure_out_staging(orbx_extractor *e, int batch, int cap);
+int orbx_scratch(orbx_extractor *e, int slot, size_t bytes, void **out);
+
+// level-0 / level-l pixel pointer of image b (device side helper)
+struct PyrRef {
+    const uint8_t *img0; long long img0_stride; int img0_pitch;
+    const uint8_t *pyr; long long pyr_stride;
+};
+__device__ __forceinline__ const uint8_t *orbx_level_ptr(const PyrRef &p, const LevelGeom &L, int level, int b, int *pitch)
+{
+    if (level == 0) { *pitch = p.img0_pitch; return p.img0 + (long long)b * p.img0_stride; }
+    *pitch = L.pitch;
+    return p.pyr + (long long)b * p.pyr_stride + L.pyr_off;
+}

@@ -1,0 +1,267 @@
+// orbx_stereo.hip — Frame::ComputeStereoMatches (reference src/Frame.cc:577-751) for gfx950.
+//
+// K5 k_stereo: one wave per left keypoint.  Coarse stage: all right keypoints are tested 64 at a
+// time against the row band / octave / disparity-range predicates of :594-604,:644-649 (no row
+// table is built; the predicate is evaluated directly), 256-bit Hamming with v_bcnt, wave min of
+// (dist<<16 | iR) reproduces "first minimum in ascending iR" (:654-658).  Fine stage: 11x11
+// centre-subtracted L1 SAD over 11 shifts on the unblurred pyramids (:666-703), parabola (:709-716),
+// disparity / depth (:719-733) by the same wave.
+// K6 k_stereo_cut: per pair, radix-select the median SAD and drop matches >= 1.5*1.4*median (:737-750).
+#include "orbx_device.h"
+
+struct StereoTabs { float sf[ORBX_MAX_LEVELS]; float isf[ORBX_MAX_LEVELS]; };
+
+// pixel of the reference's padded pyramid image: the 19-px margin is BORDER_REFLECT_101 of the level
+__device__ __forceinline__ int lvl_px(const uint8_t *img, int pitch, int w, int h, int x, int y)
+{
+    return img[(long long)reflect101(y, h) * pitch + reflect101(x, w)];
+}
+
+__global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrRef prL, PyrRef prR, int img_l0, int img_r0,
+                                                const orbx_keypoint *__restrict__ kL, const uint32_t *__restrict__ dL,
+                                                const int *__restrict__ nL, const orbx_keypoint *__restrict__ kR,
+                                                const uint32_t *__restrict__ dR, const int *__restrict__ nR, int cap,
+                                                float bf, float max_d, StereoTabs tabs, float *__restrict__ u_right,
+                                                float *__restrict__ depth, int *__restrict__ st_dist)
+{
+    const int p = blockIdx.y, lane = threadIdx.x & 63;
+    const int il = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_l = nL[p], n_r = nR[p];
+    if (il >= n_l) return; // wave-uniform
+    const long long ol = (long long)p * cap + il;
+    const orbx_keypoint *kr = kR + (long long)p * cap;
+    const uint32_t *dr = dR + (long long)p * cap * 8;
+    const orbx_keypoint kp = kL[ol];
+    const int level_l = kp.octave;
+    const float vl = kp.y, ul = kp.x;
+    const int n_rows = g->lv[0].h;
+    const int row = (int)vl;
+    const float min_u = ul - max_d, max_u = ul; // minD = 0
+    float out_u = -1.0f, out_z = -1.0f;
+    int out_sad = -1;
+    unsigned best = 0xFFFFFFFFu;
+    if (row >= 0 && row < n_rows && !(max_u < 0)) {
+        uint32_t a[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) a[i] = dL[ol * 8 + i];
+        for (int base = 0; base < n_r; base += 64) {
+            const int ir = base + lane;
+            if (ir < n_r) {
+                const orbx_keypoint q = kr[ir];
+                const float r = 2.0f * tabs.sf[q.octave];
+                const int maxr = (int)ceilf(q.y + r), minr = (int)floorf(q.y - r);
+                if (row >= minr && row <= maxr && q.octave >= level_l - 1 && q.octave <= level_l + 1 &&
+                    q.x >= min_u && q.x <= max_u) {
+                    uint32_t bq[8];
+                    const uint4 *src = reinterpret_cast<const uint4 *>(dr + (long long)ir * 8);
+                    const uint4 v0 = src[0], v1 = src[1];
+                    bq[0] = v0.x; bq[1] = v0.y; bq[2] = v0.z; bq[3] = v0.w;
+                    bq[4] = v1.x; bq[5] = v1.y; bq[6] = v1.z; bq[7] = v1.w;
+                    const int dist = hamming256(a, bq);
+                    if (dist < 100) { // bestDist starts at TH_HIGH, strict <
+                        const unsigned key = ((unsigned)dist << 16) | (unsigned)ir;
+                        best = key < best ? key : best;
+                    }
+                }
+            }
+        }
+        best = wave_min_u32(best);
+    }
+    const int best_dist = best == 0xFFFFFFFFu ? 100 : (int)(best >> 16);
+    if (best_dist < 75) { // thOrbDist = (TH_HIGH+TH_LOW)/2
+        const int best_r = (int)(best & 0xFFFF);
+        const float ur0 = kr[best_r].x;
+        const float sfac = tabs.isf[level_l];
+        const float sul = roundf(kp.x * sfac), svl = roundf(kp.y * sfac), sur0 = roundf(ur0 * sfac);
+        const LevelGeom &LV = g->lv[level_l];
+        const float iniu = sur0 + 5 - 5, endu = sur0 + 5 + 5 + 1;
+        if (!(iniu < 0 || endu >= (float)LV.w)) {
+            int pl, prr;
+            const uint8_t *imL = orbx_level_ptr(prL, LV, level_l, img_l0 + p, &pl);
+            const uint8_t *imR = orbx_level_ptr(prR, LV, level_l, img_r0 + p, &prr);
+            const int cy = (int)svl, cxl = (int)sul;
+            const int lc = lvl_px(imL, pl, LV.w, LV.h, cxl, cy);
+            // each lane owns window pixels e = lane and lane+64 (< 121)
+            const int e0 = lane, e1 = lane + 64;
+            const int dy0 = e0 / 11 - 5, dx0 = e0 % 11 - 5;
+            const int dy1 = e1 / 11 - 5, dx1 = e1 % 11 - 5;
+            const int il0 = lvl_px(imL, pl, LV.w, LV.h, cxl + dx0, cy + dy0) - lc;
+            const int il1 = e1 < 121 ? lvl_px(imL, pl, LV.w, LV.h, cxl + dx1, cy + dy1) - lc : 0;
+            int best_sad = 0x7FFFFFFF, best_inc = 0;
+            int dists[11];
+#pragma unroll
+            for (int inc = -5; inc <= 5; inc++) {
+                const int cxr = (int)(sur0 + (float)inc);
+                const int rc = lvl_px(imR, prr, LV.w, LV.h, cxr, cy);
+                int s = abs(il0 - (lvl_px(imR, prr, LV.w, LV.h, cxr + dx0, cy + dy0) - rc));
+                if (e1 < 121) s += abs(il1 - (lvl_px(imR, prr, LV.w, LV.h, cxr + dx1, cy + dy1) - rc));
+                s = wave_sum(s);
+                dists[inc + 5] = s;
+                if (s < best_sad) { best_sad = s; best_inc = inc; }
+            }
+            if (!(best_inc == -5 || best_inc == 5)) {
+                float d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+                for (int k = 1; k < 10; k++)
+                    if (k == best_inc + 5) { d1 = (float)dists[k - 1]; d2 = (float)dists[k]; d3 = (float)dists[k + 1]; }
+                const float delta = (d1 - d3) / (2.0f * (d1 + d3 - 2.0f * d2));
+                if (!(delta < -1 || delta > 1)) {
+                    float best_ur = tabs.sf[level_l] * ((float)sur0 + (float)best_inc + delta);
+                    float disparity = ul - best_ur;
+                    if (disparity >= 0 && disparity < max_d) {
+                        if (disparity <= 0) { disparity = 0.01f; best_ur = (float)((double)ul - 0.01); }
+                        out_z = bf / disparity;
+                        out_u = best_ur;
+                        out_sad = best_sad;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) { u_right[ol] = out_u; depth[ol] = out_z; st_dist[ol] = out_sad; }
+}
+
+// one 256-thread workgroup per stereo pair
+__global__ __launch_bounds__(256) void k_stereo_cut(const int *__restrict__ nL, int cap, float *__restrict__ u_right,
+                                                    float *__restrict__ depth, const int *__restrict__ st_dist)
+{
+    __shared__ int hist[256];
+    __shared__ int s_sel, s_rem, s_cnt;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int n_l = nL[p];
+    const long long o = (long long)p * cap;
+    hist[tid] = 0;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    int local = 0;
+    for (int i = tid; i < n_l; i += 256) {
+        const int d = st_dist[o + i];
+        if (d >= 0) { atomicAdd(&hist[d >> 8], 1); local++; }
+    }
+    if (local) atomicAdd(&s_cnt, local);
+    __syncthreads();
+    const int nvd = s_cnt;
+    if (nvd == 0) return; // reference indexes an empty vector here; nothing to cut
+    const int kth = nvd / 2; // vDistIdx[size/2] of the ascending sort
+    if (tid == 0) {
+        int acc = 0, b = 0;
+        for (; b < 256; b++) { if (acc + hist[b] > kth) break; acc += hist[b]; }
+        s_sel = b; s_rem = kth - acc;
+    }
+    __syncthreads();
+    const int hi = s_sel, rem = s_rem;
+    __syncthreads();
+    hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n_l; i += 256) {
+        const int d = st_dist[o + i];
+        if (d >= 0 && (d >> 8) == hi) atomicAdd(&hist[d & 255], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0, b = 0;
+        for (; b < 256; b++) { if (acc + hist[b] > rem) break; acc += hist[b]; }
+        s_sel = (hi << 8) | b;
+    }
+    __syncthreads();
+    const float median = (float)s_sel;
+    const float th_dist = 1.5f * 1.4f * median;
+    for (int i = tid; i < n_l; i += 256) {
+        const int d = st_dist[o + i];
+        if (d >= 0 && !((float)d < th_dist)) { u_right[o + i] = -1.0f; depth[o + i] = -1.0f; }
+    }
+}
+
+static int same_geometry(const orbx_extractor *L, const orbx_extractor *R)
+{
+    if (L->nlevels != R->nlevels || L->geom.w != R->geom.w || L->geom.h != R->geom.h || L->geom.w == 0) return 0;
+    for (int i = 0; i < L->nlevels; i++) if (L->sf[i] != R->sf[i]) return 0;
+    return 1;
+}
+
+extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orbx_extractor *R, int img_r0, int batch,
+                                              const void *d_kL, const void *d_dL, const void *d_nL,
+                                              const void *d_kR, const void *d_dR, const void *d_nR, int cap,
+                                              float bf, float min_z, void *d_u_right, void *d_depth, void *stream)
+{
+    if (!L || !R || !d_kL || !d_dL || !d_nL || !d_kR || !d_dR || !d_nR || !d_u_right || !d_depth || batch < 1 || cap < 1 ||
+        img_l0 < 0 || img_r0 < 0 || img_l0 + batch > L->last_batch || img_r0 + batch > R->last_batch || !(min_z > 0)) {
+        orbx_set_error("orbx_stereo_match_batch_device: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    if (L->device != R->device || !same_geometry(L, R)) {
+        orbx_set_error("left and right extractors differ in device, image size or scale tables");
+        return ORBX_E_INVALID;
+    }
+    if (cap >= 65536) { orbx_set_error("cap must be < 65536"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipSetDevice(L->device));
+    hipStream_t s = stream ? (hipStream_t)stream : L->stream;
+    const size_t need = (size_t)batch * cap * sizeof(int);
+    if (need > L->st_cap || !L->d_st_dist) {
+        ORBX_HIP(hipStreamSynchronize(s));
+        if (L->d_st_dist) ORBX_HIP(hipFree(L->d_st_dist));
+        L->d_st_dist = nullptr;
+        ORBX_HIP(hipMalloc((void **)&L->d_st_dist, need));
+        L->st_cap = need;
+    }
+    PyrRef pl, pr;
+    pl.img0 = L->last_img0; pl.img0_stride = (long long)L->last_img_stride; pl.img0_pitch = (int)L->last_pitch;
+    pl.pyr = L->d_pyr; pl.pyr_stride = L->geom.pyr_bytes;
+    pr.img0 = R->last_img0; pr.img0_stride = (long long)R->last_img_stride; pr.img0_pitch = (int)R->last_pitch;
+    pr.pyr = R->d_pyr; pr.pyr_stride = R->geom.pyr_bytes;
+    StereoTabs tabs;
+    for (int i = 0; i < ORBX_MAX_LEVELS; i++) { tabs.sf[i] = L->sf[i]; tabs.isf[i] = L->isf[i]; }
+    const float max_d = bf / min_z; // src/Frame.cc:609
+    orbx_prof_begin(L, ORBX_STAGE_STEREO, s);
+    hipLaunchKernelGGL(k_stereo, dim3((cap + 3) / 4, batch), dim3(256), 0, s, L->d_geom, pl, pr, img_l0, img_r0,
+                       (const orbx_keypoint *)d_kL, (const uint32_t *)d_dL, (const int *)d_nL,
+                       (const orbx_keypoint *)d_kR, (const uint32_t *)d_dR, (const int *)d_nR, cap, bf, max_d, tabs,
+                       (float *)d_u_right, (float *)d_depth, L->d_st_dist);
+    orbx_prof_end(L, s);
+    orbx_prof_begin(L, ORBX_STAGE_STEREO_CUT, s);
+    hipLaunchKernelGGL(k_stereo_cut, dim3(batch), dim3(256), 0, s, (const int *)d_nL, cap, (float *)d_u_right,
+                       (float *)d_depth, L->d_st_dist);
+    orbx_prof_end(L, s);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+extern "C" int orbx_stereo_match(orbx_extractor *L, orbx_extractor *R,
+                                 const orbx_keypoint *kL, const uint8_t *dL, int nL,
+                                 const orbx_keypoint *kR, const uint8_t *dR, int nR,
+                                 float bf, float min_z, float *u_right, float *depth)
+{
+    if (!L || !R || nL < 0 || nR < 0 || (nL && (!kL || !dL || !u_right || !depth)) || (nR && (!kR || !dR))) {
+        orbx_set_error("orbx_stereo_match: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    if (nL == 0) return ORBX_OK;
+    if (!L->last_img0 || !R->last_img0) { orbx_set_error("run orbx_extract on both eyes first"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipSetDevice(L->device));
+    ORBX_HIP(hipStreamSynchronize(R->stream)); // the right pyramid was produced on R's stream
+    const int cap = nL > nR ? nL : (nR > 0 ? nR : 1);
+    void *bkL, *bdL, *bkR, *bdR, *bn, *bu, *bz;
+    int rc;
+    if ((rc = orbx_scratch(L, 0, sizeof(orbx_keypoint) * cap, &bkL)) || (rc = orbx_scratch(L, 1, 32 * (size_t)cap, &bdL)) ||
+        (rc = orbx_scratch(L, 2, sizeof(orbx_keypoint) * cap, &bkR)) || (rc = orbx_scratch(L, 3, 32 * (size_t)cap, &bdR)) ||
+        (rc = orbx_scratch(L, 4, 2 * sizeof(int), &bn)) || (rc = orbx_scratch(L, 5, 4 * (size_t)cap, &bu)) ||
+        (rc = orbx_scratch(L, 6, 4 * (size_t)cap, &bz)))
+        return rc;
+    const int counts[2] = { nL, nR };
+    hipStream_t s = L->stream;
+    ORBX_HIP(hipMemcpyAsync(bkL, kL, sizeof(orbx_keypoint) * nL, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(bdL, dL, 32 * (size_t)nL, hipMemcpyHostToDevice, s));
+    if (nR) {
+        ORBX_HIP(hipMemcpyAsync(bkR, kR, sizeof(orbx_keypoint) * nR, hipMemcpyHostToDevice, s));
+        ORBX_HIP(hipMemcpyAsync(bdR, dR, 32 * (size_t)nR, hipMemcpyHostToDevice, s));
+    }
+    ORBX_HIP(hipMemcpyAsync(bn, counts, sizeof counts, hipMemcpyHostToDevice, s));
+    const int save_l = L->last_batch, save_r = R->last_batch;
+    rc = orbx_stereo_match_batch_device(L, 0, R, 0, 1, bkL, bdL, bn, bkR, bdR, (int *)bn + 1, cap, bf, min_z, bu, bz, s);
+    (void)save_l; (void)save_r;
+    if (rc) return rc;
+    ORBX_HIP(hipMemcpyAsync(u_right, bu, 4 * (size_t)nL, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(depth, bz, 4 * (size_t)nL, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    return ORBX_OK;
+}

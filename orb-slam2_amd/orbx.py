@@ -1,0 +1,280 @@
+"""ctypes binding of liborbx.so + mirror classes named after the reference's C++ interface."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liborbx.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])  # == cv::KeyPoint, 28 B
+STAGES = ("resize", "fast", "tree", "desc", "stereo", "stereo_cut")
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"orbx error {code}: {msg}")
+        self.code = code
+
+
+class FeatSet(C.Structure):
+    """orbx_featset (include/orbx.h)"""
+    _fields_ = [("n", C.c_int), ("desc", C.c_void_p), ("nnodes", C.c_int), ("node_id", C.c_void_p),
+                ("node_off", C.c_void_p), ("feat", C.c_void_p), ("flag", C.c_void_p), ("angle", C.c_void_p),
+                ("x", C.c_void_p), ("y", C.c_void_p), ("octave", C.c_void_p), ("u_right", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib_path():
+    return _SO
+
+
+def lib():
+    """Load liborbx.so; fail loudly if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise OrbxError(-4, f"{_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(_SO)
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    ip, fp = C.POINTER(C.c_int), C.POINTER(C.c_float)
+    L.orbx_last_error.restype = C.c_char_p
+    L.orbx_device_count.restype = i
+    L.orbx_extractor_create.argtypes = [C.POINTER(vp), i, f, i, i, i, i, i, i, i]
+    L.orbx_extractor_destroy.argtypes = [vp]
+    L.orbx_extractor_destroy.restype = None
+    L.orbx_get_levels.argtypes = [vp]
+    L.orbx_get_scale_factor.argtypes = [vp]
+    L.orbx_get_scale_factor.restype = f
+    L.orbx_get_scale_tables.argtypes = [vp, vp, vp, vp, vp]
+    L.orbx_get_features_per_level.argtypes = [vp, vp]
+    L.orbx_max_keypoints.argtypes = [vp, i, i]
+    L.orbx_extract.argtypes = [vp, vp, i, i, sz, vp, vp, i, ip]
+    L.orbx_extract_batch.argtypes = [vp, vp, i, i, i, sz, vp, vp, i, vp]
+    L.orbx_extract_batch_device.argtypes = [vp, vp, sz, sz, i, i, i, vp, vp, i, vp, vp]
+    L.orbx_sync.argtypes = [vp, vp]
+    L.orbx_pyramid_level.argtypes = [vp, i, i, vp, sz, ip, ip]
+    L.orbx_stereo_match.argtypes = [vp, vp, vp, vp, i, vp, vp, i, f, f, vp, vp]
+    L.orbx_stereo_match_batch_device.argtypes = [vp, i, vp, i, i, vp, vp, vp, vp, vp, vp, i, f, f, vp, vp, vp]
+    L.orbx_hamming.argtypes = [vp, vp]
+    FS = C.POINTER(FeatSet)
+    L.orbx_search_by_bow_kf_f.argtypes = [i, FS, FS, f, i, vp, ip]
+    L.orbx_search_by_bow_kf_f_batch.argtypes = [i, FS, i, FS, f, i, vp, vp]
+    L.orbx_search_by_bow_kf_kf.argtypes = [i, FS, FS, f, i, vp, ip]
+    L.orbx_search_for_triangulation.argtypes = [i, FS, FS, vp, f, f, vp, vp, i, i, i, vp, i, ip]
+    L.orbx_profile_enable.argtypes = [vp, i]
+    L.orbx_profile_read.argtypes = [vp, vp, vp, i]
+    L.orbx_debug_candidates.argtypes = [vp, i, i, vp, vp, vp, i, ip]
+    L.orbx_debug_level_counts.argtypes = [vp, i, vp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise OrbxError(rc, lib().orbx_last_error().decode(errors="replace"))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def make_featset(fs):
+    """dict(desc[n,32]u8, node_id u32, node_off i32, feat u32, flag u8, angle f32[, x, y, octave, u_right])
+    -> (FeatSet, keepalive dict)"""
+    keep = {}
+
+    def arr(k, dt):
+        v = fs.get(k)
+        if v is None:
+            return None
+        keep[k] = np.ascontiguousarray(v, dtype=dt)
+        return keep[k].ctypes.data
+
+    s = FeatSet()
+    s.desc = arr("desc", np.uint8)
+    s.n = len(keep["desc"])
+    s.node_id = arr("node_id", np.uint32); s.node_off = arr("node_off", np.int32); s.feat = arr("feat", np.uint32)
+    s.nnodes = len(keep["node_id"])
+    s.flag = arr("flag", np.uint8); s.angle = arr("angle", np.float32)
+    s.x = arr("x", np.float32); s.y = arr("y", np.float32)
+    s.octave = arr("octave", np.int32); s.u_right = arr("u_right", np.float32)
+    return s, keep
+
+
+class ORBextractor:
+    """Mirror of ORB_SLAM2::ORBextractor (reference include/ORBextractor.h:58-139).
+
+    ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) as in src/Tracking.cc:124-130;
+    `device`, `max_size`, `max_batch` size the HBM workspace.
+    """
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device=0, max_size=(4096, 4096), max_batch=1):
+        self._L = lib()
+        self._h = C.c_void_p()
+        self.nfeatures, self.nlevels, self.max_batch, self.device = nfeatures, nlevels, max_batch, device
+        _check(self._L.orbx_extractor_create(C.byref(self._h), nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST,
+                                             device, max_size[0], max_size[1], max_batch))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.orbx_extractor_destroy(h)
+            self._h = None
+
+    # -- getters (include/ORBextractor.h:78-98)
+    def GetLevels(self): return self._L.orbx_get_levels(self._h)
+    def GetScaleFactor(self): return self._L.orbx_get_scale_factor(self._h)
+
+    def _tables(self):
+        t = [np.zeros(self.nlevels, np.float32) for _ in range(4)]
+        _check(self._L.orbx_get_scale_tables(self._h, *[_p(a) for a in t]))
+        return t
+
+    def GetScaleFactors(self): return self._tables()[0]
+    def GetInverseScaleFactors(self): return self._tables()[1]
+    def GetScaleSigmaSquares(self): return self._tables()[2]
+    def GetInverseScaleSigmaSquares(self): return self._tables()[3]
+
+    def GetFeaturesPerLevel(self):
+        q = np.zeros(self.nlevels, np.int32)
+        _check(self._L.orbx_get_features_per_level(self._h, _p(q)))
+        return q
+
+    def max_keypoints(self, w, h):
+        n = self._L.orbx_max_keypoints(self._h, w, h)
+        if n < 0:
+            _check(n)
+        return n
+
+    # -- operator() (include/ORBextractor.h:74-76): image -> (keypoints, descriptors)
+    def __call__(self, image, mask=None):
+        image = np.asarray(image)
+        if image.size == 0:
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        if image.dtype != np.uint8 or image.ndim != 2:
+            raise OrbxError(-1, "image must be 2-D uint8 (CV_8UC1, reference src/ORBextractor.cc:1269)")
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        h, w = image.shape
+        cap = self.max_keypoints(w, h)
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int()
+        _check(self._L.orbx_extract(self._h, _p(image), w, h, image.strides[0], _p(kps), _p(desc), cap, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, images):
+        """list/array of equally sized uint8 images -> list of (keypoints, descriptors)"""
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        h, w = imgs[0].shape
+        B = len(imgs)
+        cap = self.max_keypoints(w, h)
+        ptrs = (C.c_void_p * B)(*[im.ctypes.data for im in imgs])
+        kps = np.zeros((B, cap), KP_DTYPE); desc = np.zeros((B, cap, 32), np.uint8); n = np.zeros(B, np.int32)
+        _check(self._L.orbx_extract_batch(self._h, ptrs, B, w, h, imgs[0].strides[0], _p(kps), _p(desc), cap, _p(n)))
+        return [(kps[i, :n[i]].copy(), desc[i, :n[i]].copy()) for i in range(B)]
+
+    def extract_batch_device(self, d_imgs, img_stride, pitch, batch, w, h, d_kps, d_desc, cap, d_n, stream=None):
+        """device pointers (ints); asynchronous on `stream` (None = the handle's own)"""
+        _check(self._L.orbx_extract_batch_device(self._h, d_imgs, img_stride, pitch, batch, w, h, d_kps, d_desc, cap, d_n, stream))
+
+    def sync(self, stream=None):
+        _check(self._L.orbx_sync(self._h, stream))
+
+    # -- mvImagePyramid (include/ORBextractor.h:100)
+    def pyramid_level(self, level, image_index=0):
+        w, h = C.c_int(), C.c_int()
+        _check(self._L.orbx_pyramid_level(self._h, image_index, level, None, 0, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        _check(self._L.orbx_pyramid_level(self._h, image_index, level, _p(out), out.strides[0], C.byref(w), C.byref(h)))
+        return out
+
+    @property
+    def mvImagePyramid(self):
+        return [self.pyramid_level(l) for l in range(self.nlevels)]
+
+    # -- inspection / measurement
+    def debug_candidates(self, level, image_index=0):
+        n = C.c_int()
+        _check(self._L.orbx_debug_candidates(self._h, image_index, level, None, None, None, 0, C.byref(n)))
+        x = np.zeros(n.value, np.int32); y = np.zeros(n.value, np.int32); r = np.zeros(n.value, np.int32)
+        _check(self._L.orbx_debug_candidates(self._h, image_index, level, _p(x), _p(y), _p(r), n.value, C.byref(n)))
+        return x, y, r
+
+    def debug_level_counts(self, image_index=0):
+        c = np.zeros(self.nlevels, np.int32)
+        _check(self._L.orbx_debug_level_counts(self._h, image_index, _p(c)))
+        return c
+
+    def profile_enable(self, on=True):
+        _check(self._L.orbx_profile_enable(self._h, int(on)))
+
+    def profile_read(self, reset=True):
+        ms = np.zeros(len(STAGES), np.float32); n = np.zeros(len(STAGES), np.int32)
+        _check(self._L.orbx_profile_read(self._h, _p(ms), _p(n), int(reset)))
+        return {s: (float(ms[i]), int(n[i])) for i, s in enumerate(STAGES)}
+
+
+def ComputeStereoMatches(extractorLeft, extractorRight, mvKeys, mDescriptors, mvKeysRight, mDescriptorsRight, mbf, mb):
+    """Mirror of Frame::ComputeStereoMatches (reference src/Frame.cc:577-751) -> (mvuRight, mvDepth).
+    `mb` is the stereo baseline in metres (minZ); the reference reads it uninitialised."""
+    kL = np.ascontiguousarray(mvKeys, dtype=KP_DTYPE); kR = np.ascontiguousarray(mvKeysRight, dtype=KP_DTYPE)
+    dL = np.ascontiguousarray(mDescriptors, dtype=np.uint8); dR = np.ascontiguousarray(mDescriptorsRight, dtype=np.uint8)
+    ur = np.full(len(kL), -1, np.float32); dp = np.full(len(kL), -1, np.float32)
+    _check(lib().orbx_stereo_match(extractorLeft._h, extractorRight._h, _p(kL), _p(dL), len(kL), _p(kR), _p(dR), len(kR),
+                                   mbf, mb, _p(ur), _p(dp)))
+    return ur, dp
+
+
+def stereo_match_batch_device(L, imgL0, R, imgR0, batch, d_kL, d_dL, d_nL, d_kR, d_dR, d_nR, cap, bf, min_z, d_ur, d_depth, stream=None):
+    _check(lib().orbx_stereo_match_batch_device(L._h, imgL0, R._h, imgR0, batch, d_kL, d_dL, d_nL, d_kR, d_dR, d_nR, cap,
+                                                bf, min_z, d_ur, d_depth, stream))
+
+
+class ORBmatcher:
+    """Mirror of ORB_SLAM2::ORBmatcher (reference include/ORBmatcher.h:41-103) for the searches on the
+    north-star path.  Feature sets are dicts as accepted by make_featset()."""
+    TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30  # src/ORBmatcher.cc:37-39
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self.mfNNratio, self.mbCheckOrientation, self.device = float(nnratio), bool(checkOri), device
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+        return lib().orbx_hamming(_p(a), _p(b))
+
+    def SearchByBoW(self, pKF, other, frame=None):
+        """SearchByBoW(pKF, F) when `other` is a frame feature set (kind='frame', default) ->
+        (match_f, nmatches); SearchByBoW(pKF1, pKF2) when other['kind']=='keyframe' -> (match12, nmatches)."""
+        a, ka = make_featset(pKF); b, kb = make_featset(other)
+        n = C.c_int()
+        if other.get("kind", "frame") == "keyframe":
+            out = np.full(a.n, -1, np.int32)
+            _check(lib().orbx_search_by_bow_kf_kf(self.device, C.byref(a), C.byref(b), self.mfNNratio, int(self.mbCheckOrientation), _p(out), C.byref(n)))
+        else:
+            out = np.full(b.n, -1, np.int32)
+            _check(lib().orbx_search_by_bow_kf_f(self.device, C.byref(a), C.byref(b), self.mfNNratio, int(self.mbCheckOrientation), _p(out), C.byref(n)))
+        return out, n.value
+
+    def SearchByBoWBatch(self, keyframes, F):
+        """Relocalization loop (src/Tracking.cc:1661-1682): every keyframe against one frame."""
+        sets = [make_featset(k) for k in keyframes]
+        arr = (FeatSet * len(sets))(*[s[0] for s in sets])
+        b, kb = make_featset(F)
+        out = np.full((len(sets), b.n), -1, np.int32); n = np.zeros(len(sets), np.int32)
+        _check(lib().orbx_search_by_bow_kf_f_batch(self.device, arr, len(sets), C.byref(b), self.mfNNratio, int(self.mbCheckOrientation), _p(out), _p(n)))
+        return out, n
+
+    def SearchForTriangulation(self, pKF1, pKF2, F12, ex, ey, scaleFactors2, levelSigma2_2, bOnlyStereo=False):
+        a, ka = make_featset(pKF1); b, kb = make_featset(pKF2)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sf = np.ascontiguousarray(scaleFactors2, np.float32); sg = np.ascontiguousarray(levelSigma2_2, np.float32)
+        cap = max(a.n, 1)
+        pairs = np.zeros((cap, 2), np.int32); n = C.c_int()
+        _check(lib().orbx_search_for_triangulation(self.device, C.byref(a), C.byref(b), _p(F), ex, ey, _p(sf), _p(sg), len(sf),
+                                                   int(bOnlyStereo), int(self.mbCheckOrientation), _p(pairs), cap, C.byref(n)))
+        return pairs[:n.value].copy()

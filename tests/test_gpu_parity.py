@@ -1,0 +1,288 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Bar: bit-exact (integer / byte / index work; the fp32 fields of cv::KeyPoint are compared
+by bit pattern as well)."""
+import numpy as np
+import pytest
+
+from tools import synth
+
+pytestmark = pytest.mark.gpu
+
+ORB = dict(scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7)
+
+
+def _extractor(pkg, nfeatures, w, h, nlevels=8, max_batch=1):
+    return pkg.ORBextractor(nfeatures, 1.2, nlevels, 20, 7, device=0, max_size=(w, h), max_batch=max_batch)
+
+
+def _check_stages(ex, orc, img, tag):
+    """compare stage by stage so that a failure names the first stage that diverges"""
+    kps, desc = ex(img)
+    okps, odesc = orc.extract(img)
+    for l in range(orc.nlevels):
+        g = ex.pyramid_level(l)
+        o = orc.level(l)
+        assert g.shape == o.shape, f"{tag}: level {l} shape {g.shape} vs {o.shape}"
+        bad = np.argwhere(g != o)
+        assert len(bad) == 0, f"{tag}: pyramid level {l}: {len(bad)} pixels differ, first at {bad[:3].tolist()}"
+    for l in range(orc.nlevels):
+        gx, gy, gr = ex.debug_candidates(l)
+        ox, oy, orr = orc.candidates(l)
+        assert len(gx) == len(ox), f"{tag}: level {l}: {len(gx)} FAST candidates vs oracle {len(ox)}"
+        assert (gx == ox).all() and (gy == oy).all(), f"{tag}: level {l}: candidate positions/order differ"
+        assert (gr == orr).all(), f"{tag}: level {l}: candidate responses differ"
+    gc = ex.debug_level_counts()
+    oc = np.array([orc.nkeypoints(l) for l in range(orc.nlevels)])
+    assert (gc == oc).all(), f"{tag}: keypoints per level {gc.tolist()} vs oracle {oc.tolist()}"
+    assert len(kps) == len(okps)
+    for f in ("x", "y", "octave", "response", "size", "class_id"):
+        bad = np.nonzero(kps[f] != okps[f])[0]
+        assert len(bad) == 0, f"{tag}: keypoint field {f} differs at {bad[:5].tolist()} (quadtree selection/order)"
+    bad = np.nonzero(kps["angle"].view(np.uint32) != okps["angle"].view(np.uint32))[0]
+    assert len(bad) == 0, f"{tag}: angle bits differ at {bad[:5].tolist()}: {kps['angle'][bad[:3]]} vs {okps['angle'][bad[:3]]}"
+    bad = np.nonzero((desc != odesc).any(axis=1))[0]
+    assert len(bad) == 0, f"{tag}: {len(bad)} descriptors differ, first {bad[:5].tolist()}"
+    assert kps.tobytes() == okps.tobytes()
+    return kps, desc
+
+
+@pytest.mark.parametrize("w,h,nf,seed", [(320, 240, 500, 1), (640, 480, 1000, 2), (752, 480, 1000, 3), (1241, 376, 2000, 4)])
+def test_extract_stage_parity(pkg, oracle, w, h, nf, seed):
+    img = synth.image(seed, w, h)
+    ex = _extractor(pkg, nf, w, h)
+    orc = oracle.Oracle(nf, 1.2, 8, 20, 7)
+    _check_stages(ex, orc, img, f"{w}x{h}")
+
+
+def test_extract_fhd_4000(pkg, oracle):
+    img = synth.image(5, 1920, 1080, nshapes=4000)
+    ex = _extractor(pkg, 4000, 1920, 1080)
+    orc = oracle.Oracle(4000, 1.2, 8, 20, 7)
+    assert (ex.GetFeaturesPerLevel() == orc.features_per_level()).all()
+    _check_stages(ex, orc, img, "fhd")
+
+
+def test_tables_match_oracle(pkg, oracle):
+    ex = _extractor(pkg, 2000, 640, 480)
+    orc = oracle.Oracle(2000, 1.2, 8, 20, 7)
+    assert ex.GetLevels() == 8
+    assert ex.GetScaleFactors().tobytes() == orc.scale_factors().tobytes()
+    assert ex.GetInverseScaleFactors().tobytes() == orc.inv_scale_factors().tobytes()
+    assert ex.GetScaleSigmaSquares().tobytes() == orc.level_sigma2().tobytes()
+    assert ex.GetInverseScaleSigmaSquares().tobytes() == orc.inv_level_sigma2().tobytes()
+    assert (ex.GetFeaturesPerLevel() == orc.features_per_level()).all()
+
+
+@pytest.mark.parametrize("kind", ["flat", "low_contrast", "noise", "checker", "dense_corners"])
+def test_extract_edge_images(pkg, oracle, kind):
+    """empty-ish / degenerate inputs: no corners, minThFAST fallback everywhere, saturated corner density"""
+    w, h = 400, 300
+    rng = np.random.default_rng(7)
+    if kind == "flat":
+        img = np.full((h, w), 128, np.uint8)
+    elif kind == "low_contrast":
+        img = (synth.image(9, w, h).astype(np.float32) * 0.12 + 100).astype(np.uint8)
+    elif kind == "noise":
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    elif kind == "checker":
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = (((xx // 6 + yy // 6) & 1) * 200 + 20).astype(np.uint8)
+    else:
+        img = rng.integers(0, 2, (h, w), dtype=np.uint8) * 255
+    ex = _extractor(pkg, 800, w, h)
+    orc = oracle.Oracle(800, 1.2, 8, 20, 7)
+    kps, desc = _check_stages(ex, orc, img, kind)
+    if kind == "flat":
+        assert len(kps) == 0
+
+
+def test_extract_empty_and_errors(pkg):
+    ex = _extractor(pkg, 500, 640, 480)
+    kps, desc = ex(np.zeros((0, 0), np.uint8))
+    assert len(kps) == 0 and desc.shape == (0, 32)
+    with pytest.raises(pkg.OrbxError):      # level 7 smaller than one FAST cell: reference divides by zero
+        ex(np.zeros((120, 160), np.uint8))
+    with pytest.raises(pkg.OrbxError):      # larger than the workspace
+        ex(np.zeros((600, 800), np.uint8))
+    with pytest.raises(pkg.OrbxError):      # not CV_8UC1
+        ex(np.zeros((480, 640), np.float32))
+
+
+def test_small_image_fewer_levels(pkg, oracle):
+    img = synth.image(21, 160, 120, nshapes=300)
+    ex = _extractor(pkg, 300, 160, 120, nlevels=4)
+    orc = oracle.Oracle(300, 1.2, 4, 20, 7)
+    _check_stages(ex, orc, img, "160x120/4 levels")
+
+
+def test_strided_input(pkg, oracle):
+    big = synth.image(31, 800, 500)
+    view = big[10:490, 40:680]          # 640x480 view with row stride 800
+    ex = _extractor(pkg, 1000, 640, 480)
+    kps, desc = ex(view)
+    okps, odesc = oracle.Oracle(1000, 1.2, 8, 20, 7).extract(np.ascontiguousarray(view))
+    assert kps.tobytes() == okps.tobytes() and desc.tobytes() == odesc.tobytes()
+
+
+def test_batch_equals_single(pkg, oracle):
+    seq = synth.sequence(41, 640, 480, 6)
+    ex = _extractor(pkg, 1000, 640, 480, max_batch=8)
+    res = ex.extract_batch(list(seq))
+    orc = oracle.Oracle(1000, 1.2, 8, 20, 7)
+    for i, (k, d) in enumerate(res):
+        ok, od = orc.extract(seq[i])
+        assert k.tobytes() == ok.tobytes(), f"frame {i}"
+        assert d.tobytes() == od.tobytes(), f"frame {i}"
+    # the same handle, reused for a different size and back (geometry cache)
+    k2, d2 = ex(synth.image(42, 320, 240))
+    ok2, od2 = oracle.Oracle(1000, 1.2, 8, 20, 7).extract(synth.image(42, 320, 240))
+    assert k2.tobytes() == ok2.tobytes() and d2.tobytes() == od2.tobytes()
+
+
+def test_idempotent_and_deterministic(pkg):
+    img = synth.image(51, 752, 480)
+    ex = _extractor(pkg, 1000, 752, 480)
+    a = ex(img); b = ex(img)
+    assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+
+
+# ------------------------------------------------------------------------------- stereo
+
+def _stereo_case(pkg, oracle, seed, w, h, nf):
+    left, right, disp = synth.stereo_pair(seed, w, h)
+    exL, exR = _extractor(pkg, nf, w, h), _extractor(pkg, nf, w, h)
+    kL, dL = exL(left); kR, dR = exR(right)
+    oL, oR = oracle.Oracle(nf, 1.2, 8, 20, 7), oracle.Oracle(nf, 1.2, 8, 20, 7)
+    okL, odL = oL.extract(left); okR, odR = oR.extract(right)
+    assert kL.tobytes() == okL.tobytes() and kR.tobytes() == okR.tobytes()
+    bf, b = 386.1448, 386.1448 / 718.856  # Examples/Stereo/KITTI00-02.yaml:8,25
+    ur, dp = pkg.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, bf, b)
+    our, odp = oracle.stereo_match(oL, oR, okL, odL, okR, odR, bf, b)
+    return ur, dp, our, odp, kL, disp
+
+
+@pytest.mark.parametrize("seed,w,h,nf", [(61, 640, 480, 1000), (62, 1241, 376, 2000)])
+def test_stereo_parity(pkg, oracle, seed, w, h, nf):
+    ur, dp, our, odp, kL, disp = _stereo_case(pkg, oracle, seed, w, h, nf)
+    bad = np.nonzero(ur.view(np.uint32) != our.view(np.uint32))[0]
+    assert len(bad) == 0, f"uRight differs at {bad[:5].tolist()}: {ur[bad[:5]]} vs {our[bad[:5]]}"
+    assert dp.tobytes() == odp.tobytes()
+    assert (ur >= 0).sum() > 50  # the test is not vacuous
+    # size-independent property: recovered disparities agree with the generator's disparity field
+    ok = ur >= 0
+    d_true = disp[np.clip(kL["y"].astype(int), 0, len(disp) - 1)]
+    assert (np.abs((kL["x"] - ur)[ok] - d_true[ok]) < 2.0).mean() > 0.8
+
+
+def test_stereo_no_matches(pkg, oracle):
+    """right eye unrelated to the left: (almost) nothing survives; empty accepted set must not fault"""
+    w, h = 640, 480
+    exL, exR = _extractor(pkg, 500, w, h), _extractor(pkg, 500, w, h)
+    left = synth.image(71, w, h); right = np.full((h, w), 90, np.uint8)
+    right[200:240, 300:340] = 200
+    kL, dL = exL(left); kR, dR = exR(right)
+    oL, oR = oracle.Oracle(500, 1.2, 8, 20, 7), oracle.Oracle(500, 1.2, 8, 20, 7)
+    okL, odL = oL.extract(left); okR, odR = oR.extract(right)
+    ur, dp = pkg.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, 386.1448, 0.5372)
+    our, odp = oracle.stereo_match(oL, oR, okL, odL, okR, odR, 386.1448, 0.5372)
+    assert ur.tobytes() == our.tobytes() and dp.tobytes() == odp.tobytes()
+
+
+# ------------------------------------------------------------------------------- BoW matchers
+
+def _bow_sets(pkg, oracle, seed, n_kf=3, flip=0.05):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    img = synth.image(seed, 752, 480)
+    ex = _extractor(pkg, 1000, 752, 480)
+    k, d = ex(img)
+    voc = synth.Vocab2(seed + 1); voc.seed_from(d, rng)
+
+    def mk(desc, kp, flag):
+        ids, off, feat = voc.feature_vector(desc)
+        return dict(desc=desc, node_id=ids, node_off=off, feat=feat, flag=flag, angle=kp["angle"],
+                    x=kp["x"], y=kp["y"], octave=kp["octave"], u_right=np.where(rng.random(len(kp)) < 0.3, 5.0, -1.0).astype(np.float32))
+    frame = mk(d, k, np.zeros(len(d), np.uint8))
+    kfs = []
+    for i in range(n_kf):
+        perm = rng.permutation(len(d))
+        dk = synth.flip_bits(rng, d, flip)[perm]
+        kk = k[perm].copy()
+        kk["angle"] = (kk["angle"] + rng.normal(0, 4 + 20 * i, len(kk)).astype(np.float32)) % np.float32(360)
+        kfs.append(mk(dk, kk, (rng.random(len(d)) < 0.6).astype(np.uint8)))
+    return frame, kfs, ex
+
+
+@pytest.mark.parametrize("ratio,ori", [(0.7, True), (0.75, True), (0.9, False)])
+def test_search_by_bow_kf_f(pkg, oracle, ratio, ori):
+    frame, kfs, _ = _bow_sets(pkg, oracle, 81)
+    m = pkg.ORBmatcher(ratio, ori)
+    for i, kf in enumerate(kfs):
+        got, n = m.SearchByBoW(kf, frame)
+        exp, en = oracle.search_by_bow_kf_f(kf, frame, ratio, ori)
+        assert n == en, f"kf {i}: nmatches {n} vs {en}"
+        assert (got == exp).all(), f"kf {i}: {np.nonzero(got != exp)[0][:5].tolist()}"
+        assert n > 20
+    got, n = m.SearchByBoWBatch(kfs, frame)
+    for i, kf in enumerate(kfs):
+        exp, en = oracle.search_by_bow_kf_f(kf, frame, ratio, ori)
+        assert n[i] == en and (got[i] == exp).all()
+
+
+def test_search_by_bow_kf_kf(pkg, oracle):
+    frame, kfs, _ = _bow_sets(pkg, oracle, 82)
+    m = pkg.ORBmatcher(0.75, True)
+    for a in range(len(kfs)):
+        b = dict(kfs[(a + 1) % len(kfs)]); b["kind"] = "keyframe"
+        got, n = m.SearchByBoW(kfs[a], b)
+        exp, en = oracle.search_by_bow_kf_kf(kfs[a], b, 0.75, True)
+        assert n == en and (got == exp).all()
+        assert n > 10
+
+
+@pytest.mark.parametrize("only_stereo,ori", [(False, False), (False, True), (True, False)])
+def test_search_for_triangulation(pkg, oracle, only_stereo, ori):
+    frame, kfs, ex = _bow_sets(pkg, oracle, 83, flip=0.03)
+    a, b = kfs[0], dict(frame)
+    a = dict(a); a["flag"] = (np.arange(len(a["desc"])) % 3 == 0).astype(np.uint8)   # "already has a MapPoint"
+    b["flag"] = (np.arange(len(b["desc"])) % 5 == 0).astype(np.uint8)
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)   # pure x-translation: epipolar lines are rows
+    F12 = F12 + np.float32(2e-7) * np.arange(9, dtype=np.float32).reshape(3, 3)
+    sf, sg = ex.GetScaleFactors(), ex.GetScaleSigmaSquares()
+    m = pkg.ORBmatcher(0.6, ori)
+    got = m.SearchForTriangulation(a, b, F12, 300.0, 200.0, sf, sg, bOnlyStereo=only_stereo)
+    exp = oracle.search_for_triangulation(a, b, F12, 300.0, 200.0, sf, sg, 0.6, ori, only_stereo)
+    assert got.shape == exp.shape, f"{got.shape} vs {exp.shape}"
+    assert (got == exp).all()
+    if not only_stereo:
+        assert len(got) > 10
+
+
+def test_bow_edge_cases(pkg, oracle):
+    """disjoint vocab nodes, empty feature vector, all-flags-off"""
+    frame, kfs, _ = _bow_sets(pkg, oracle, 84, n_kf=1)
+    kf = kfs[0]
+    m = pkg.ORBmatcher(0.75, True)
+    # no valid map points
+    k0 = dict(kf); k0["flag"] = np.zeros(len(kf["desc"]), np.uint8)
+    got, n = m.SearchByBoW(k0, frame)
+    assert n == 0 and (got == -1).all()
+    # disjoint node ids
+    k1 = dict(kf); k1["node_id"] = kf["node_id"] + np.uint32(100000)
+    got, n = m.SearchByBoW(k1, frame)
+    exp, en = oracle.search_by_bow_kf_f(k1, frame, 0.75, True)
+    assert n == en == 0 and (got == exp).all()
+    # empty feature vector on one side
+    k2 = dict(kf); k2["node_id"] = np.zeros(0, np.uint32); k2["node_off"] = np.zeros(1, np.int32); k2["feat"] = np.zeros(0, np.uint32)
+    got, n = m.SearchByBoW(k2, frame)
+    assert n == 0 and (got == -1).all()
+    # malformed CSR is rejected, not trusted
+    k3 = dict(kf); k3["feat"] = kf["feat"].copy(); k3["feat"][0] = 10 ** 6
+    with pytest.raises(pkg.OrbxError):
+        m.SearchByBoW(k3, frame)
+
+
+def test_hamming_host(pkg, oracle):
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, (200, 32), dtype=np.uint8); b = rng.integers(0, 256, (200, 32), dtype=np.uint8)
+    for i in range(200):
+        assert pkg.ORBmatcher.DescriptorDistance(a[i], b[i]) == oracle.hamming(a[i], b[i]) == int(np.unpackbits(a[i] ^ b[i]).sum())
