@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of ORB extract + match on MI355X (BASELINE.json metric).
+
+Workload (config.workload): KITTI-shape stereo, 1241x376, ORBextractor.nFeatures=1000 per eye,
+8 levels, scale 1.2, FAST 20/7.  One FRAME = one stereo pair = extract(left) + extract(right) +
+ComputeStereoMatches.  A step = one batch of `--batch` frames (2*batch images in one set of
+launches); inputs are synthetic (tools/synth.py) and already resident in HBM when timing starts.
+
+`python bench.py --gpus N --steps K --warmup W`; for N>1 launch under torch.distributed.run (one
+rank per GPU, independent camera streams per GPU, RCCL only for the start/stop barrier and the
+MAX-reduction of the elapsed time) -> "scaling": "weak".
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (largest share of the HIP-event
+time measured live on the launch stream during the timed region) by its ALGORITHMIC bytes
+(DESIGN.md section "Kernels"); `cpu_baseline` times the CPU oracle (oracle/, a port: the reference
+itself needs OpenCV and cannot be built) on a bounded sample of the same workload on rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, NFEAT, NLEVELS = 1241, 376, 1000, 8
+BF, FX = 386.1448, 718.856          # reference Examples/Stereo/KITTI00-02.yaml:8,25
+MIN_Z = BF / FX                     # mb = mbf/fx (src/Frame.cc:118)
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def level_pixels(w, h, nlevels=NLEVELS, sf=1.2):
+    """P_l per level with the reference's float arithmetic (src/ORBextractor.cc:436-461,1353)"""
+    s = np.float32(1.0); out = []
+    for l in range(nlevels):
+        inv = np.float32(1.0) / s
+        out.append(int(np.rint(np.float32(w) * inv)) * int(np.rint(np.float32(h) * inv)))
+        s = np.float32(np.float64(s) * np.float64(np.float32(sf)))
+    return out
+
+
+def algorithmic_bytes(stage, n_images, n_pairs, nkp_avg):
+    """bytes one launch set of `stage` must move for n_images images (Kernels)"""
+    P = level_pixels(W, H)
+    if stage == "resize":      # read level l-1, write level l, l = 1..7 (7 launches per step)
+        return n_images * (sum(P[:-1]) + sum(P[1:]))
+    if stage == "fast":        # every level read once; candidates out (4 B each) not counted
+        return n_images * sum(P)
+    if stage == "tree":        # candidates in (4 B), kept keypoints out (4 B): ~3x quota
+        return n_images * 4 * (4 * NFEAT)
+    if stage == "desc":        # 43x43 patch in, 28 B keypoint + 32 B descriptor out
+        return n_images * nkp_avg * (43 * 43 + 60)
+    if stage == "stereo":      # SURVEY 8d B_stereo
+        return n_pairs * (60 * 2 * nkp_avg + 8 * nkp_avg + nkp_avg * (121 + 21 * 11))
+    return n_pairs * nkp_avg * 12
+
+
+def cpu_baseline(frames):
+    """the CPU oracle driven like the reference: stereo = 2 threads (L/R), src/Frame.cc:82-85"""
+    from oracle import oracle_py
+    oL, oR = oracle_py.Oracle(NFEAT, 1.2, NLEVELS, 20, 7), oracle_py.Oracle(NFEAT, 1.2, NLEVELS, 20, 7)
+    times = []
+    for left, right in frames:
+        res = {}
+        t0 = time.perf_counter()
+        tl = threading.Thread(target=lambda: res.__setitem__("l", oL.extract(left)))
+        tr = threading.Thread(target=lambda: res.__setitem__("r", oR.extract(right)))
+        tl.start(); tr.start(); tl.join(); tr.join()
+        oracle_py.stereo_match(oL, oR, res["l"][0], res["l"][1], res["r"][0], res["r"][1], BF, MIN_Z)
+        times.append(time.perf_counter() - t0)
+    times = np.array(times)
+    return {"value": round(float(len(times) / times.sum()), 3), "unit": "frames/s", "cores": 2, "kind": "port",
+            "sample": f"{len(times)} stereo frames {W}x{H} @{NFEAT} feats through oracle/liborb_oracle.so "
+                      f"(-O3 -march=native), L/R extraction on 2 threads, median {np.median(times) * 1e3:.1f} ms/frame",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="stereo frames per step per GPU")
+    ap.add_argument("--cpu-frames", type=int, default=60, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs (tiled to the batch)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    pkg = ge.load_pkg()
+    pkg.lib()  # fails loudly if liborbx.so is missing: there is no fallback path
+    from tools import synth
+
+    B = args.batch
+    pairs = [synth.stereo_pair(1000 + 97 * rank + i, W, H)[:2] for i in range(args.distinct)]
+    pitch = (W + 63) // 64 * 64
+    host = np.zeros((2 * B, H, pitch), np.uint8)
+    for i in range(B):
+        host[i, :, :W] = pairs[i % len(pairs)][0]
+        host[B + i, :, :W] = pairs[i % len(pairs)][1]
+    imgs = torch.from_numpy(host).to(dev)
+
+    ex = pkg.ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local, max_size=(W, H), max_batch=2 * B)
+    cap = ex.max_keypoints(W, H)
+    kps = torch.zeros((2 * B, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((2 * B, cap, 32), dtype=torch.uint8, device=dev)
+    nout = torch.zeros(2 * B, dtype=torch.int32, device=dev)
+    ur = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+    dp = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    sp = stream.cuda_stream
+    orbx = pkg.orbx
+
+    def step():
+        ex.extract_batch_device(imgs.data_ptr(), H * pitch, pitch, 2 * B, W, H, kps.data_ptr(), desc.data_ptr(), cap, nout.data_ptr(), sp)
+        orbx.stereo_match_batch_device(ex, 0, ex, B, B, kps.data_ptr(), desc.data_ptr(), nout.data_ptr(),
+                                       kps[B:].data_ptr(), desc[B:].data_ptr(), nout[B:].data_ptr(), cap,
+                                       BF, MIN_Z, ur.data_ptr(), dp.data_ptr(), sp)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        stream.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ex.profile_read(reset=True)
+    ex.profile_enable(True)           # HIP events on the launch stream, around every kernel of the timed steps
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ex.profile_enable(False)
+    prof = ex.profile_read(reset=True)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ex.sync(sp)
+
+    n_h = nout.cpu().numpy()
+    nkp_avg = float(n_h.mean())
+    matched = float((ur.cpu().numpy() >= 0).sum() / B)
+    frames = B * args.steps * world
+    value = frames / elapsed
+
+    # dominant kernel + roofline (per launch: total stage time / launches; resize = 7 launches per step)
+    stage_ms = {k: v[0] for k, v in prof.items()}
+    dom = max(stage_ms, key=stage_ms.get)
+    launches = max(prof[dom][1], 1)
+    avg_ms = stage_ms[dom] / launches
+    per_step_launches = launches / args.steps
+    bytes_per_launch = algorithmic_bytes(dom, 2 * B, B, nkp_avg) / per_step_launches
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in stage_ms.items()}}
+
+    out = {"metric": "frames/sec ORB extract+match, 1241x376 @1000 feats; bit-exact vs CPU", "value": round(value, 2),
+           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": f"KITTI-shape stereo {W}x{H}, nFeatures={NFEAT}/eye, 8 levels, FAST 20/7: "
+                                  "extract(L)+extract(R)+ComputeStereoMatches; 1 frame = 1 stereo pair",
+                      "frames_per_step_per_gpu": B, "images_per_step_per_gpu": 2 * B,
+                      "keypoints_per_image": round(nkp_avg, 1), "stereo_matches_per_frame": round(matched, 1),
+                      "parallelism": f"{world} independent camera-stream batches, one per GPU"},
+           "roofline": roofline}
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        out["cpu_baseline"] = cpu_baseline([pairs[i % len(pairs)] for i in range(args.cpu_frames)])
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
