@@ -93,22 +93,20 @@ def main():
     import torch.distributed as dist
     import __graft_entry__ as ge
 
-    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    pkg = ge.load_pkg()
+    st = pkg.streams
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if args.gpus > 1 or world > 1:
-        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    rank, world = st.init("nccl", device_id=dev)   # "nccl" is RCCL on ROCm; no-op for a single process
+    assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
 
-    pkg = ge.load_pkg()
     pkg.lib()  # fails loudly if liborbx.so is missing: there is no fallback path
     from tools import synth
 
     B = args.batch
-    pairs = [synth.stereo_pair(1000 + 97 * rank + i, W, H)[:2] for i in range(args.distinct)]
+    stream_id = st.owned_streams(rank, world)[0]      # one camera stream per GPU
+    pairs = [synth.stereo_pair(st.stream_seed(stream_id) + i, W, H)[:2] for i in range(args.distinct)]
     pitch = (W + 63) // 64 * 64
     host = np.zeros((2 * B, H, pitch), np.uint8)
     for i in range(B):
@@ -133,36 +131,24 @@ def main():
                                        kps[B:].data_ptr(), desc[B:].data_ptr(), nout[B:].data_ptr(), cap,
                                        BF, MIN_Z, ur.data_ptr(), dp.data_ptr(), sp)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    def local_sync():
         stream.synchronize()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    barrier()
+    local_sync()
     ex.profile_read(reset=True)
     ex.profile_enable(True)           # HIP events on the launch stream, around every kernel of the timed steps
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = st.timed_steps(step, args.steps, local_sync, world, device=dev)   # barrier + sync both sides, MAX over ranks
     ex.profile_enable(False)
     prof = ex.profile_read(reset=True)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     ex.sync(sp)
 
     n_h = nout.cpu().numpy()
     nkp_avg = float(n_h.mean())
     matched = float((ur.cpu().numpy() >= 0).sum() / B)
-    frames = B * args.steps * world
-    value = frames / elapsed
+    value = st.aggregate_rate(B, args.steps, world, elapsed)
 
     # dominant kernel + roofline (per launch: total stage time / launches; resize = 7 launches per step)
     stage_ms = {k: v[0] for k, v in prof.items()}

@@ -11,6 +11,7 @@ There is NO CPU fallback: importing works without a GPU (so that the ABI can be 
 every compute call raises OrbxError unless liborbx.so is built and a gfx950 device is present.
 The directory name contains a '-', so load it with importlib (see tests/conftest.py: load_pkg()).
 """
+from . import orbx, streams
 from .orbx import (OrbxError, KP_DTYPE, lib, lib_path, ORBextractor, ORBmatcher, ComputeStereoMatches,
                    FeatSet, make_featset, STAGES)
 
