@@ -54,53 +54,68 @@ __global__ __launch_bounds__(256) void k_resize(const Geom *__restrict__ g, int 
 }
 
 // ================================================================ K2: FAST per cell (E3)
-// cornerScore<16> without a threshold: max over the 16 arcs of 9 contiguous ring pixels of
-// min(v - x) (A) and of min(x - v) (B).  A pixel is a FAST-9 corner at threshold t iff
-// max(A,B) > t and its OpenCV score is then max(A,B)-1 independent of t, so one
-// score map at minThFAST serves both passes of src/ORBextractor.cc:988-995.
-__device__ __forceinline__ int fast_score_tile(const uint8_t *t, int th)
+// cornerScore<16> without a threshold: with x_k the 16 ring pixels, A = max over the 16 arcs of 9
+// contiguous ring pixels of min(v - x) = v - min_arcs(max_arc x) and B = max_arcs(min_arc x) - v.
+// A pixel is a FAST-9 corner at threshold t iff max(A,B) > t and its OpenCV score is then
+// max(A,B)-1 independent of t, so one score map at minThFAST serves both passes of
+// src/ORBextractor.cc:988-995.  The sliding 9-window max/min over the circular ring is a doubling
+// network (2,4,8,+1) evaluated on packed u16 pairs (v_pk_max_u16 / v_pk_min_u16).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u16x2 pk(unsigned lo, unsigned hi)
+{
+    const unsigned v = lo | (hi << 16);
+    return __builtin_bit_cast(u16x2, v);
+}
+
+__device__ __forceinline__ int fast_score_full(const uint8_t *t, int th)
 {
     constexpr int P = ORBX_TILE_PITCH;
     const int v = t[0];
-    const int d0 = v - t[3 * P], d8 = v - t[-3 * P], d4 = v - t[3], d12 = v - t[-3];
-    // any 9-arc contains one pixel of each antipodal pair
-    const bool dark = (d0 > th || d8 > th) && (d4 > th || d12 > th);
-    const bool bright = (d0 < -th || d8 < -th) && (d4 < -th || d12 < -th);
-    if (!(dark || bright)) return 0;
-    int d[16];
-    d[0] = d0; d[4] = d4; d[8] = d8; d[12] = d12;
-    d[1] = v - t[3 * P + 1];  d[2] = v - t[2 * P + 2];   d[3] = v - t[P + 3];
-    d[5] = v - t[-P + 3];     d[6] = v - t[-2 * P + 2];  d[7] = v - t[-3 * P + 1];
-    d[9] = v - t[-3 * P - 1]; d[10] = v - t[-2 * P - 2]; d[11] = v - t[-P - 3];
-    d[13] = v - t[P - 3];     d[14] = v - t[2 * P - 2];  d[15] = v - t[3 * P - 1];
-    int lo2[16], hi2[16], lo4[16], hi4[16];
+    unsigned x[16];
+    x[0] = t[3 * P];      x[1] = t[3 * P + 1];  x[2] = t[2 * P + 2];   x[3] = t[P + 3];
+    x[4] = t[3];          x[5] = t[-P + 3];     x[6] = t[-2 * P + 2];  x[7] = t[-3 * P + 1];
+    x[8] = t[-3 * P];     x[9] = t[-3 * P - 1]; x[10] = t[-2 * P - 2]; x[11] = t[-P - 3];
+    x[12] = t[-3];        x[13] = t[P - 3];     x[14] = t[2 * P - 2];  x[15] = t[3 * P - 1];
+    u16x2 E[8], O[8], hi[8], lo[8], h2[8], l2[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+    for (int i = 0; i < 8; i++) { E[i] = pk(x[2 * i], x[2 * i + 1]); O[i] = pk(x[2 * i + 1], x[(2 * i + 2) & 15]); }
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
-    int A = -256, B = 256;
+    for (int i = 0; i < 8; i++) { hi[i] = __builtin_elementwise_max(E[i], O[i]); lo[i] = __builtin_elementwise_min(E[i], O[i]); }
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-        A = max(A, lo9);
-        B = min(B, hi9);
-    }
-    const int s = max(A, -B);
+    for (int i = 0; i < 8; i++) { h2[i] = __builtin_elementwise_max(hi[i], hi[(i + 1) & 7]); l2[i] = __builtin_elementwise_min(lo[i], lo[(i + 1) & 7]); }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { hi[i] = __builtin_elementwise_max(h2[i], h2[(i + 2) & 7]); lo[i] = __builtin_elementwise_min(l2[i], l2[(i + 2) & 7]); }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { h2[i] = __builtin_elementwise_max(hi[i], E[(i + 4) & 7]); l2[i] = __builtin_elementwise_min(lo[i], E[(i + 4) & 7]); }
+    // h2 = max over each 9-arc, l2 = min over each 9-arc (two arcs per register)
+#pragma unroll
+    for (int i = 0; i < 4; i++) { h2[i] = __builtin_elementwise_min(h2[i], h2[i + 4]); l2[i] = __builtin_elementwise_max(l2[i], l2[i + 4]); }
+#pragma unroll
+    for (int i = 0; i < 2; i++) { h2[i] = __builtin_elementwise_min(h2[i], h2[i + 2]); l2[i] = __builtin_elementwise_max(l2[i], l2[i + 2]); }
+    const u16x2 hm = __builtin_elementwise_min(h2[0], h2[1]), lm = __builtin_elementwise_max(l2[0], l2[1]);
+    const int min_of_max = min((int)hm.x, (int)hm.y), max_of_min = max((int)lm.x, (int)lm.y);
+    const int s = max(v - min_of_max, max_of_min - v);
     return s > th ? s - 1 : 0;
 }
 
-// One 256-thread workgroup per (cell, image): stage the cell (+3 px halo) in LDS, score map,
-// in-cell 3x3 strict NMS, iniThFAST/minThFAST selection, ordered (row-major) compaction into the
-// cell's candidate slots.  Candidate = x | y<<12 | score<<24 with (x,y) relative to (16,16).
-__global__ __launch_bounds__(256) void k_fast(const Geom *__restrict__ g, PyrRef pr, int *__restrict__ cell_cnt,
-                                              uint32_t *__restrict__ cand, int ini_th, int min_th)
+// One wave (64-thread workgroup) per (cell, image) -- no workgroup barriers, many independent cells
+// in flight per CU.  The cell (+3 px halo) is staged in LDS with aligned dword loads; a 4-point
+// pretest (any 9-arc holds two adjacent compass pixels) compacts the candidate pixels into an LDS
+// list so that the full 16-point network runs on dense lanes; then in-cell 3x3 strict NMS with one
+// ballot per 64 pixels (kept in LDS), iniThFAST/minThFAST selection and ordered (row-major)
+// emission into the cell's candidate slots.  Candidate = x | y<<12 | score<<24, (x,y) relative to (16,16).
+extern __shared__ __align__(16) unsigned char fast_smem[];
+
+__global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, PyrRef pr, int *__restrict__ cell_cnt,
+                                             uint32_t *__restrict__ cand, int ini_th, int min_th)
 {
     constexpr int P = ORBX_TILE_PITCH, SP = ORBX_SCORE_PITCH;
-    __shared__ __align__(16) uint8_t tile[65 * P];
-    __shared__ __align__(16) uint8_t sc[61 * SP];
-    __shared__ int s_w[4];
-    const int b = blockIdx.y, cell = blockIdx.x, tid = threadIdx.x;
+    uint8_t *tile = fast_smem;
+    uint8_t *sc = fast_smem + g->fast_lds_sc;
+    uint16_t *list = reinterpret_cast<uint16_t *>(fast_smem + g->fast_lds_list);
+    unsigned long long *masks = reinterpret_cast<unsigned long long *>(fast_smem + g->fast_lds_mask);
+    const int b = blockIdx.y, cell = blockIdx.x, lane = threadIdx.x;
     int l = 0;
     while (l + 1 < g->nlevels && cell >= g->lv[l + 1].cell_base) l++;
     const LevelGeom &L = g->lv[l];
@@ -113,62 +128,95 @@ __global__ __launch_bounds__(256) void k_fast(const Geom *__restrict__ g, PyrRef
     const int tw = max_x - ini_x, th = max_y - ini_y, dw = tw - 6, dh = th - 6;
     // src/ORBextractor.cc:961-976 skip rules (note the asymmetric 3 / 6)
     if (ini_y >= max_by - 3 || ini_x >= max_bx - 6 || dw <= 0 || dh <= 0) {
-        if (tid == 0) *my_cnt = 0;
+        if (lane == 0) *my_cnt = 0;
         return;
     }
     int pitch;
     const uint8_t *img = orbx_level_ptr(pr, L, l, b, &pitch);
-    {
-        const int tx = tid & 63, ty = tid >> 6;
-        for (int r = ty; r < th; r += 4) {
-            const uint8_t *row = img + (long long)(ini_y + r) * pitch + ini_x;
-            for (int c = tx; c < tw; c += 64) tile[r * P + c] = row[c];
+    int xo; // tile column of image column ini_x
+    if ((((uintptr_t)img | (unsigned)pitch) & 3) == 0) {
+        xo = ini_x & 3;
+        const int ndw = (tw + xo + 3) >> 2; // <= 17 dwords per row
+        const unsigned mg = 0xFFFFFFFFu / (unsigned)ndw + 1u;
+        const uint8_t *src = img + (long long)ini_y * pitch + (ini_x - xo);
+        for (int i = lane; i < th * ndw; i += 64) {
+            const int r = (int)__umulhi((unsigned)i, mg), c = i - r * ndw;
+            reinterpret_cast<uint32_t *>(tile + r * P)[c] = *reinterpret_cast<const uint32_t *>(src + (long long)r * pitch + 4 * c);
         }
+    } else {
+        xo = 0;
+        for (int r = 0; r < th; r++) {
+            const uint8_t *row = img + (long long)(ini_y + r) * pitch + ini_x;
+            for (int c = lane; c < tw; c += 64) tile[r * P + c] = row[c];
+        }
+    }
+    {
         uint32_t *z = reinterpret_cast<uint32_t *>(sc);
-        for (int i = tid; i < 61 * SP / 4; i += 256) z[i] = 0;
+        for (int i = lane; i < (dh + 2) * (SP / 4); i += 64) z[i] = 0;
     }
     __syncthreads();
     const int npx = dw * dh;
     const unsigned magic = 0xFFFFFFFFu / (unsigned)dw + 1u; // floor(p/dw) = umulhi(p, magic) for p < 2^16
-    for (int p = tid; p < npx; p += 256) {
-        const int py = (int)__umulhi((unsigned)p, magic), px = p - py * dw;
-        const int s = fast_score_tile(tile + (py + 3) * P + px + 3, min_th);
-        sc[(py + 1) * SP + px + 1] = (uint8_t)s;
+    const uint8_t *t0 = tile + 3 * P + xo + 3;
+    int nlist = 0;
+    for (int p0 = 0; p0 < npx; p0 += 64) {
+        const int p = p0 + lane;
+        bool pass = false;
+        if (p < npx) {
+            const int py = (int)__umulhi((unsigned)p, magic), px = p - py * dw;
+            const uint8_t *t = t0 + py * P + px;
+            const int v = t[0];
+            const int d0 = v - t[3 * P], d8 = v - t[-3 * P], d4 = v - t[3], d12 = v - t[-3];
+            pass = ((d0 > min_th || d8 > min_th) && (d4 > min_th || d12 > min_th)) ||
+                   ((d0 < -min_th || d8 < -min_th) && (d4 < -min_th || d12 < -min_th));
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) list[nlist + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (uint16_t)p;
+        nlist += __popcll(m);
     }
     __syncthreads();
-    // NMS over a contiguous run of pixels per thread so that one block scan yields row-major order
-    const int per = (npx + 255) >> 8; // <= 14
-    const int q0 = tid * per, q1 = min(q0 + per, npx);
-    unsigned bits_m = 0, bits_i = 0;
-    {
-        int py = (int)__umulhi((unsigned)q0, magic), px = q0 - py * dw;
-        for (int q = q0; q < q1; q++) {
+    for (int i = lane; i < nlist; i += 64) {
+        const int p = list[i];
+        const int py = (int)__umulhi((unsigned)p, magic), px = p - py * dw;
+        sc[(py + 1) * SP + px + 1] = (uint8_t)fast_score_full(t0 + py * P + px, min_th);
+    }
+    __syncthreads();
+    // NMS: one ballot per 64 consecutive (row-major) pixels; masks stay in LDS for the emission pass
+    const int nchunk = (npx + 63) >> 6;
+    unsigned long long any_ini = 0;
+    for (int ch = 0; ch < nchunk; ch++) {
+        const int q = ch * 64 + lane;
+        bool is_max = false, is_ini = false;
+        if (q < npx) {
+            const int py = (int)__umulhi((unsigned)q, magic), px = q - py * dw;
             const uint8_t *c = sc + (py + 1) * SP + px + 1;
             const int s = c[0];
-            if (s > 0 && s > c[-1] && s > c[1] && s > c[-SP - 1] && s > c[-SP] && s > c[-SP + 1] &&
-                s > c[SP - 1] && s > c[SP] && s > c[SP + 1]) {
-                bits_m |= 1u << (q - q0);
-                if (s >= ini_th) bits_i |= 1u << (q - q0);
-            }
-            if (++px == dw) { px = 0; py++; }
+            is_max = s > 0 && s > c[-1] && s > c[1] && s > c[-SP - 1] && s > c[-SP] && s > c[-SP + 1] &&
+                     s > c[SP - 1] && s > c[SP] && s > c[SP + 1];
+            is_ini = is_max && s >= ini_th;
         }
+        const unsigned long long mm = __ballot(is_max), mi = __ballot(is_ini);
+        if (lane == 0) { masks[2 * ch] = mm; masks[2 * ch + 1] = mi; }
+        any_ini |= mi;
     }
-    const int use_ini = __syncthreads_or(bits_i != 0);
-    unsigned sel = use_ini ? bits_i : bits_m;
-    int total;
-    int off = block_excl_scan256(__popc(sel), &total, s_w);
+    __syncthreads();
+    const int pick = any_ini ? 1 : 0; // the cell falls back to minThFAST only if iniThFAST kept nothing (:991-995)
     uint32_t *slot = cand + (long long)b * g->cand_total + L.cand_off + (long long)ci * L.cand_cap;
-    while (sel) {
-        const int k = __ffs(sel) - 1;
-        sel &= sel - 1;
-        const int q = q0 + k;
-        const int py = (int)__umulhi((unsigned)q, magic), px = q - py * dw;
-        const int s = sc[(py + 1) * SP + px + 1];
-        const int X = ini_x + 3 + px - ORBX_MIN_BORDER, Y = ini_y + 3 + py - ORBX_MIN_BORDER;
-        if (off < L.cand_cap) slot[off] = (uint32_t)X | ((uint32_t)Y << 12) | ((uint32_t)s << 24);
-        off++;
+    int off = 0;
+    for (int ch = 0; ch < nchunk; ch++) {
+        const unsigned long long sel = masks[2 * ch + pick];
+        if (sel == 0) continue;
+        if ((sel >> lane) & 1ull) {
+            const int q = ch * 64 + lane;
+            const int py = (int)__umulhi((unsigned)q, magic), px = q - py * dw;
+            const int s = sc[(py + 1) * SP + px + 1];
+            const int X = ini_x + 3 + px - ORBX_MIN_BORDER, Y = ini_y + 3 + py - ORBX_MIN_BORDER;
+            const int o = off + __builtin_amdgcn_mbcnt_hi((unsigned)(sel >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sel, 0));
+            if (o < L.cand_cap) slot[o] = (uint32_t)X | ((uint32_t)Y << 12) | ((uint32_t)s << 24);
+        }
+        off += __popcll(sel);
     }
-    if (tid == 0) *my_cnt = min(total, L.cand_cap);
+    if (lane == 0) *my_cnt = min(off, L.cand_cap);
 }
 
 // ================================================================ K3: quadtree cull (E4)
@@ -585,6 +633,19 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         if (L.node_cap > G.max_node_cap) G.max_node_cap = L.node_cap;
     }
     G.pyr_bytes = (long long)align_up((size_t)G.pyr_bytes, 256);
+    {   // LDS carve of k_fast, sized by the largest cell over the levels
+        int max_th = 0, max_dh = 0, max_npx = 0;
+        for (int l = 0; l < e->nlevels; l++) {
+            const LevelGeom &L = G.lv[l];
+            if (L.h_cell + 6 > max_th) max_th = L.h_cell + 6;
+            if (L.h_cell > max_dh) max_dh = L.h_cell;
+            if (L.w_cell * L.h_cell > max_npx) max_npx = L.w_cell * L.h_cell;
+        }
+        G.fast_lds_sc = (int)align_up((size_t)max_th * ORBX_TILE_PITCH + 8, 16);
+        G.fast_lds_list = G.fast_lds_sc + (int)align_up((size_t)(max_dh + 2) * ORBX_SCORE_PITCH, 16);
+        G.fast_lds_mask = G.fast_lds_list + (int)align_up((size_t)max_npx * 2 + 16, 16);
+        G.fast_lds_bytes = G.fast_lds_mask + 16 * ((max_npx + 63) / 64) + 16;
+    }
     // resize tables
     std::vector<int16_t> tabs(tab_units ? tab_units : 1);
     for (int l = 1; l < e->nlevels; l++) {
@@ -767,7 +828,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
         orbx_prof_end(e, s);
     }
     orbx_prof_begin(e, ORBX_STAGE_FAST, s);
-    hipLaunchKernelGGL(k_fast, dim3(G.total_cells, batch), dim3(256), 0, s, e->d_geom, pr, e->d_cell_cnt, e->d_cand,
+    hipLaunchKernelGGL(k_fast, dim3(G.total_cells, batch), dim3(64), G.fast_lds_bytes, s, e->d_geom, pr, e->d_cell_cnt, e->d_cand,
                        e->ini_th, e->min_th);
     orbx_prof_end(e, s);
     int *err_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;

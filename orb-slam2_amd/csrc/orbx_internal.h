@@ -40,6 +40,7 @@ struct Geom {
     long long pyr_bytes;    // per image, levels >= 1
     int max_cells_level;    // max n_cells over levels
     int max_node_cap;
+    int fast_lds_sc, fast_lds_list, fast_lds_mask, fast_lds_bytes; // LDS carve of k_fast
     LevelGeom lv[ORBX_MAX_LEVELS];
 };
 
