@@ -455,9 +455,10 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
                                              const uint32_t *__restrict__ lvl_kp, orbx_keypoint *__restrict__ out_kps,
                                              uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap)
 {
-    __shared__ uint8_t raw[43 * 44];
-    __shared__ uint16_t hb[43 * 38];
-    __shared__ uint8_t bl[37 * 40];
+    constexpr int RP = 48, HP = 40, BP = 40; // LDS pitches: raw bytes, row-pass u16, blurred bytes
+    __shared__ __align__(16) uint8_t raw[43 * RP + 16];
+    __shared__ __align__(16) uint16_t hb[43 * HP];
+    __shared__ __align__(16) uint8_t bl[37 * BP];
     const int slot = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     int l = 0;
     while (l + 1 < g->nlevels && slot >= g->lv[l + 1].kp_off) l++;
@@ -474,17 +475,29 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     const int x = p & 0xFFF, y = (p >> 12) & 0xFFF, resp = p >> 24;
     int pitch;
     const uint8_t *img = orbx_level_ptr(pr, L, l, b, &pitch);
-    for (int e = lane; e < 43 * 43; e += 64) {
-        const int r = e / 43, c = e - r * 43;
-        raw[r * 44 + c] = img[(long long)reflect101(y - 21 + r, L.h) * pitch + reflect101(x - 21 + c, L.w)];
+    // ---- stage the 43x43 patch; xo = LDS column of patch column 0
+    int xo = (x - 21) & 3;
+    const int x0a = x - 21 - xo;
+    if (x >= 21 && x + 21 < L.w && y >= 21 && y + 21 < L.h && x0a + 48 <= pitch && (((uintptr_t)img | (unsigned)pitch) & 3) == 0) {
+        const uint8_t *src = img + (long long)(y - 21) * pitch + x0a;
+        for (int i = lane; i < 43 * 12; i += 64) {
+            const int r = i / 12, c = i - r * 12;
+            reinterpret_cast<uint32_t *>(raw)[i] = *reinterpret_cast<const uint32_t *>(src + (long long)r * pitch + 4 * c);
+        }
+    } else { // image edge (BORDER_REFLECT_101 of the cloned level, :1312-1314) or unaligned input
+        xo = 0;
+        for (int e = lane; e < 43 * 43; e += 64) {
+            const int r = e / 43, c = e - r * 43;
+            raw[r * RP + c] = img[(long long)reflect101(y - 21 + r, L.h) * pitch + reflect101(x - 21 + c, L.w)];
+        }
     }
     __syncthreads();
-    // IC_Angle: lane = (row v+15, half); integer moments, order-independent
+    // ---- IC_Angle: lane = (row v+15, half); integer moments, order-independent
     int m10 = 0, m01 = 0;
     if (lane < 62) {
         const int v = (lane >> 1) - 15, dmax = c_umax[v < 0 ? -v : v];
         const int u0 = (lane & 1) ? 0 : -dmax, u1 = (lane & 1) ? dmax : -1;
-        const uint8_t *row = raw + (21 + v) * 44 + 21;
+        const uint8_t *row = raw + (21 + v) * RP + xo + 21;
         int rs = 0;
         for (int u = u0; u <= u1; u++) { const int I = row[u]; rs += I; m10 += u * I; }
         m01 = v * rs;
@@ -492,23 +505,40 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
     const float angle = dev_fast_atan2((float)m01, (float)m10);
-    // separable blur on the patch
-    for (int e = lane; e < 43 * 37; e += 64) {
-        const int r = e / 37, c = e - r * 37;
-        const uint8_t *s = raw + r * 44 + c;
-        int acc = 0;
+    // ---- row pass: 4 outputs per item from 4 aligned dwords, v_dot4_u32_u8 against the packed taps
+    const unsigned T0 = (unsigned)c_gauss[0] | ((unsigned)c_gauss[1] << 8) | ((unsigned)c_gauss[2] << 16) | ((unsigned)c_gauss[3] << 24);
+    const unsigned T1 = (unsigned)c_gauss[4] | ((unsigned)c_gauss[5] << 8) | ((unsigned)c_gauss[6] << 16);
+    for (int i = lane; i < 43 * 10; i += 64) {
+        const int r = i / 10, gq = i - r * 10;
+        const uint32_t *d = reinterpret_cast<const uint32_t *>(raw + r * RP) + gq;
+        const unsigned D0 = d[0], D1 = d[1], D2 = d[2], D3 = d[3];
+        const unsigned W0 = __builtin_amdgcn_alignbyte(D1, D0, xo), W1 = __builtin_amdgcn_alignbyte(D2, D1, xo),
+                       W2 = __builtin_amdgcn_alignbyte(D3, D2, xo);
+        unsigned o[4];
+        o[0] = __builtin_amdgcn_udot4(W0, T0, __builtin_amdgcn_udot4(W1, T1, 0u, false), false);
 #pragma unroll
-        for (int k = 0; k < 7; k++) acc += c_gauss[k] * s[k];
-        hb[r * 38 + c] = (uint16_t)acc;
+        for (int k = 1; k < 4; k++)
+            o[k] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, k), T0,
+                                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, k), T1, 0u, false), false);
+        uint2 st;
+        st.x = o[0] | (o[1] << 16);
+        st.y = o[2] | (o[3] << 16);
+        *reinterpret_cast<uint2 *>(hb + r * HP + 4 * gq) = st;
     }
     __syncthreads();
-    for (int e = lane; e < 37 * 37; e += 64) {
-        const int r = e / 37, c = e - r * 37;
-        int acc = 0;
+    // ---- column pass: lane = column, 43 row-pass values slide through registers
+    if (lane < 37) {
+        unsigned a[43];
 #pragma unroll
-        for (int k = 0; k < 7; k++) acc += c_gauss[k] * hb[(r + k) * 38 + c];
-        const int v = (acc + (1 << 15)) >> 16;
-        bl[r * 40 + c] = (uint8_t)(v > 255 ? 255 : v);
+        for (int r = 0; r < 43; r++) a[r] = hb[r * HP + lane];
+        const unsigned g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];
+#pragma unroll
+        for (int r = 0; r < 37; r++) {
+            // taps are symmetric (c_gauss[k] == c_gauss[6-k]); sums stay below 2^25
+            const unsigned acc = (a[r] + a[r + 6]) * g0 + (a[r + 1] + a[r + 5]) * g1 + (a[r + 2] + a[r + 4]) * g2 + a[r + 3] * g3;
+            const unsigned v = (acc + (1u << 15)) >> 16;
+            bl[r * BP + lane] = (uint8_t)(v > 255u ? 255u : v);
+        }
     }
     __syncthreads();
     const float factor_pi = (float)(3.14159265358979323846 / 180.f);
@@ -522,7 +552,7 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
         const float x0 = (float)c_pat[0][pi], y0 = (float)c_pat[1][pi], x1 = (float)c_pat[2][pi], y1 = (float)c_pat[3][pi];
         const int r0 = dev_cv_round(x0 * bb + y0 * a), q0 = dev_cv_round(x0 * a - y0 * bb);
         const int r1 = dev_cv_round(x1 * bb + y1 * a), q1 = dev_cv_round(x1 * a - y1 * bb);
-        const int t0 = bl[(18 + r0) * 40 + 18 + q0], t1 = bl[(18 + r1) * 40 + 18 + q1];
+        const int t0 = bl[(18 + r0) * BP + 18 + q0], t1 = bl[(18 + r1) * BP + 18 + q1];
         words[jj] = __ballot(t0 < t1);
     }
     if (lane == 0) {
