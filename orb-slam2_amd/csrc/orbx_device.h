@@ -67,6 +67,13 @@ __device__ __forceinline__ int lds_excl_scan(int *a, int m, int *s_w)
     return tot;
 }
 
+// floor(i / d) for 0 <= i < 2^16, 1 <= d < 2^16 by multiply-high (d == 1 would overflow the magic)
+struct FastDiv {
+    unsigned magic; bool one;
+    __device__ __forceinline__ explicit FastDiv(int d) : magic(0xFFFFFFFFu / (unsigned)d + 1u), one(d == 1) {}
+    __device__ __forceinline__ int div(int i) const { return one ? i : (int)__umulhi((unsigned)i, magic); }
+};
+
 __device__ __forceinline__ int reflect101(int i, int n)
 {
     if (i < 0) i = -i;

@@ -19,15 +19,93 @@ __constant__ int c_gauss[7];              // 8-bit fixed point 7-tap sigma=2 ker
 // ================================================================ K1: pyramid level (E2)
 // cv::resize INTER_LINEAR 8UC1 from level l-1 to level l.  Coefficient tables are
 // computed on the host with the reference's float/double arithmetic; the kernel is pure integer.
-// One thread produces 4 horizontally adjacent pixels and stores one dword.
+// A 256-thread workgroup produces a 128x32 output tile: the source rectangle it needs (<= 156x41)
+// is staged in LDS with coalesced aligned dword loads, each thread then computes a 4x4 block
+// (x tables loaded once per thread) and stores one dword per row.
+#define RS_TW 128
+#define RS_TH 32
+#define RS_PITCH 176 // LDS bytes per staged source row (>= 156 + 3 + alignment)
+#define RS_ROWS 42
+
 __global__ __launch_bounds__(256) void k_resize(const Geom *__restrict__ g, int l, PyrRef pr,
                                                 uint8_t *__restrict__ pyr_w, const int16_t *__restrict__ tabs)
+{
+    __shared__ __align__(16) uint8_t src_t[RS_ROWS * RS_PITCH];
+    const LevelGeom &D = g->lv[l];
+    const LevelGeom &S = g->lv[l - 1];
+    const int b = blockIdx.z, tid = threadIdx.x;
+    const int x_t = blockIdx.x * RS_TW, y_t = blockIdx.y * RS_TH;
+    int spitch;
+    const uint8_t *src = orbx_level_ptr(pr, S, l - 1, b, &spitch);
+    uint8_t *dst = pyr_w + (long long)b * pr.pyr_stride + D.pyr_off;
+    const int16_t *tx = tabs + D.tab_x, *ty = tabs + D.tab_y;
+    const int x_last = min(x_t + RS_TW, D.w) - 1, y_last = min(y_t + RS_TH, D.h) - 1;
+    const int sx_min = tx[x_t], sx_max = min(tx[x_last] + 1, S.w - 1);
+    const int sy_min = ty[y_t], sy_max = min(ty[y_last] + 1, S.h - 1);
+    const int nrows = sy_max - sy_min + 1;
+    int sxa; // source column held in LDS column 0
+    if ((((uintptr_t)src | (unsigned)spitch) & 3) == 0) {
+        sxa = sx_min & ~3;
+        const int ndw = ((sx_max - sxa) >> 2) + 1; // <= 41
+        const FastDiv fd(ndw);
+        const uint8_t *s0 = src + (long long)sy_min * spitch + sxa;
+        for (int i = tid; i < nrows * ndw; i += 256) {
+            const int r = fd.div(i), c = i - r * ndw;
+            reinterpret_cast<uint32_t *>(src_t + r * RS_PITCH)[c] = *reinterpret_cast<const uint32_t *>(s0 + (long long)r * spitch + 4 * c);
+        }
+    } else {
+        sxa = sx_min;
+        const int nb = sx_max - sxa + 1;
+        const FastDiv fd(nb);
+        const uint8_t *s0 = src + (long long)sy_min * spitch + sxa;
+        for (int i = tid; i < nrows * nb; i += 256) {
+            const int r = fd.div(i), c = i - r * nb;
+            src_t[r * RS_PITCH + c] = s0[(long long)r * spitch + c];
+        }
+    }
+    __syncthreads();
+    const int x4 = x_t + (tid & 31) * 4, y4 = y_t + (tid >> 5) * 4;
+    if (x4 >= D.pitch) return;
+    int o0[4], o1[4], a0[4], a1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = min(x4 + i, D.w - 1);
+        const int sx0 = tx[x];
+        o0[i] = sx0 - sxa;
+        o1[i] = min(sx0 + 1, S.w - 1) - sxa;
+        a0[i] = tx[D.w + x];
+        a1[i] = tx[2 * D.w + x];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int y = y4 + j;
+        if (y >= D.h) break;
+        const int sy0 = ty[y], b0 = ty[D.h + y], b1 = ty[2 * D.h + y];
+        const uint8_t *r0 = src_t + (sy0 - sy_min) * RS_PITCH;
+        const uint8_t *r1 = src_t + (min(sy0 + 1, S.h - 1) - sy_min) * RS_PITCH;
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int t0 = r0[o0[i]] * a0[i] + r0[o1[i]] * a1[i];
+            const int t1 = r1[o0[i]] * a0[i] + r1[o1[i]] * a1[i];
+            int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+            v = v < 0 ? 0 : v > 255 ? 255 : v;
+            out |= (uint32_t)v << (8 * i);
+        }
+        *reinterpret_cast<uint32_t *>(dst + (long long)y * D.pitch + x4) = out;
+    }
+}
+
+// Fallback for scale factors whose source rectangle does not fit the LDS tile of k_resize
+// (ORB-SLAM2 always uses 1.2): same arithmetic straight from global memory, 4 pixels per thread.
+__global__ __launch_bounds__(256) void k_resize_direct(const Geom *__restrict__ g, int l, PyrRef pr,
+                                                       uint8_t *__restrict__ pyr_w, const int16_t *__restrict__ tabs)
 {
     const LevelGeom &D = g->lv[l];
     const LevelGeom &S = g->lv[l - 1];
     const int b = blockIdx.z;
-    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (y >= D.h || x4 >= D.pitch) return;
     int spitch;
     const uint8_t *src = orbx_level_ptr(pr, S, l - 1, b, &spitch);
@@ -137,10 +215,10 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, PyrRef 
     if ((((uintptr_t)img | (unsigned)pitch) & 3) == 0) {
         xo = ini_x & 3;
         const int ndw = (tw + xo + 3) >> 2; // <= 17 dwords per row
-        const unsigned mg = 0xFFFFFFFFu / (unsigned)ndw + 1u;
+        const FastDiv fd(ndw);
         const uint8_t *src = img + (long long)ini_y * pitch + (ini_x - xo);
         for (int i = lane; i < th * ndw; i += 64) {
-            const int r = (int)__umulhi((unsigned)i, mg), c = i - r * ndw;
+            const int r = fd.div(i), c = i - r * ndw;
             reinterpret_cast<uint32_t *>(tile + r * P)[c] = *reinterpret_cast<const uint32_t *>(src + (long long)r * pitch + 4 * c);
         }
     } else {
@@ -156,14 +234,14 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, PyrRef 
     }
     __syncthreads();
     const int npx = dw * dh;
-    const unsigned magic = 0xFFFFFFFFu / (unsigned)dw + 1u; // floor(p/dw) = umulhi(p, magic) for p < 2^16
+    const FastDiv fdw(dw);
     const uint8_t *t0 = tile + 3 * P + xo + 3;
     int nlist = 0;
     for (int p0 = 0; p0 < npx; p0 += 64) {
         const int p = p0 + lane;
         bool pass = false;
         if (p < npx) {
-            const int py = (int)__umulhi((unsigned)p, magic), px = p - py * dw;
+            const int py = fdw.div(p), px = p - py * dw;
             const uint8_t *t = t0 + py * P + px;
             const int v = t[0];
             const int d0 = v - t[3 * P], d8 = v - t[-3 * P], d4 = v - t[3], d12 = v - t[-3];
@@ -177,7 +255,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, PyrRef 
     __syncthreads();
     for (int i = lane; i < nlist; i += 64) {
         const int p = list[i];
-        const int py = (int)__umulhi((unsigned)p, magic), px = p - py * dw;
+        const int py = fdw.div(p), px = p - py * dw;
         sc[(py + 1) * SP + px + 1] = (uint8_t)fast_score_full(t0 + py * P + px, min_th);
     }
     __syncthreads();
@@ -188,7 +266,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, PyrRef 
         const int q = ch * 64 + lane;
         bool is_max = false, is_ini = false;
         if (q < npx) {
-            const int py = (int)__umulhi((unsigned)q, magic), px = q - py * dw;
+            const int py = fdw.div(q), px = q - py * dw;
             const uint8_t *c = sc + (py + 1) * SP + px + 1;
             const int s = c[0];
             is_max = s > 0 && s > c[-1] && s > c[1] && s > c[-SP - 1] && s > c[-SP] && s > c[-SP + 1] &&
@@ -208,7 +286,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, PyrRef 
         if (sel == 0) continue;
         if ((sel >> lane) & 1ull) {
             const int q = ch * 64 + lane;
-            const int py = (int)__umulhi((unsigned)q, magic), px = q - py * dw;
+            const int py = fdw.div(q), px = q - py * dw;
             const int s = sc[(py + 1) * SP + px + 1];
             const int X = ini_x + 3 + px - ORBX_MIN_BORDER, Y = ini_y + 3 + py - ORBX_MIN_BORDER;
             const int o = off + __builtin_amdgcn_mbcnt_hi((unsigned)(sel >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sel, 0));
@@ -684,6 +762,23 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         linear_tables(S.w, L.w, &tabs[L.tab_x], &tabs[L.tab_x + L.w], &tabs[L.tab_x + 2 * L.w]);
         linear_tables(S.h, L.h, &tabs[L.tab_y], &tabs[L.tab_y + L.h], &tabs[L.tab_y + 2 * L.h]);
     }
+    for (int l = 1; l < e->nlevels; l++) { // does every 128x32 tile's source rectangle fit k_resize's LDS tile?
+        LevelGeom &L = G.lv[l];
+        const LevelGeom &S = G.lv[l - 1];
+        const int16_t *tx = &tabs[L.tab_x], *ty = &tabs[L.tab_y];
+        bool ok = true;
+        for (int x0 = 0; x0 < L.w && ok; x0 += RS_TW) {
+            const int xl = (x0 + RS_TW < L.w ? x0 + RS_TW : L.w) - 1;
+            const int smax = tx[xl] + 1 < S.w - 1 ? tx[xl] + 1 : S.w - 1;
+            if (((smax - (tx[x0] & ~3)) / 4 + 1) * 4 > RS_PITCH) ok = false;
+        }
+        for (int y0 = 0; y0 < L.h && ok; y0 += RS_TH) {
+            const int yl = (y0 + RS_TH < L.h ? y0 + RS_TH : L.h) - 1;
+            const int smax = ty[yl] + 1 < S.h - 1 ? ty[yl] + 1 : S.h - 1;
+            if (smax - ty[y0] + 1 > RS_ROWS) ok = false;
+        }
+        L.resize_lds = ok ? 1 : 0;
+    }
     if (tree_lds_bytes(G, kLdsPtsCap) > 160 * 1024) { orbx_set_error("nfeatures too large for the quadtree kernel's LDS"); return ORBX_E_INVALID; }
     ORBX_HIP(hipSetDevice(e->device));
     ORBX_HIP(hipStreamSynchronize(e->stream));
@@ -852,9 +947,13 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
 
     for (int l = 1; l < G.nlevels; l++) {
         const LevelGeom &L = G.lv[l];
-        dim3 grid((L.pitch / 4 + 63) / 64, (L.h + 3) / 4, batch), block(64, 4);
         orbx_prof_begin(e, ORBX_STAGE_RESIZE, s);
-        hipLaunchKernelGGL(k_resize, grid, block, 0, s, e->d_geom, l, pr, e->d_pyr, e->d_tabs);
+        if (L.resize_lds)
+            hipLaunchKernelGGL(k_resize, dim3((L.w + RS_TW - 1) / RS_TW, (L.h + RS_TH - 1) / RS_TH, batch), dim3(256), 0, s,
+                               e->d_geom, l, pr, e->d_pyr, e->d_tabs);
+        else
+            hipLaunchKernelGGL(k_resize_direct, dim3((L.pitch / 4 + 63) / 64, (L.h + 3) / 4, batch), dim3(256), 0, s,
+                               e->d_geom, l, pr, e->d_pyr, e->d_tabs);
         orbx_prof_end(e, s);
     }
     orbx_prof_begin(e, ORBX_STAGE_FAST, s);

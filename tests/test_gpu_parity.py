@@ -62,6 +62,23 @@ def test_extract_fhd_4000(pkg, oracle):
     _check_stages(ex, orc, img, "fhd")
 
 
+def test_one_pixel_wide_cells(pkg, oracle):
+    """783 / 814 give a last FAST cell that is exactly 7 px wide / high: one detectable column / row"""
+    img = synth.image(6, 783, 814, nshapes=2500)
+    ex = _extractor(pkg, 1500, 783, 814)
+    orc = oracle.Oracle(1500, 1.2, 8, 20, 7)
+    _check_stages(ex, orc, img, "783x814")
+
+
+@pytest.mark.parametrize("sf,nlevels", [(1.5, 4), (1.1, 6), (1.9, 3)])
+def test_other_scale_factors(pkg, oracle, sf, nlevels):
+    """non-default scaleFactor: resize tables, quotas and (for large factors) the non-LDS resize path"""
+    img = synth.image(7, 640, 480)
+    ex = pkg.ORBextractor(800, sf, nlevels, 20, 7, device=0, max_size=(640, 480))
+    orc = oracle.Oracle(800, sf, nlevels, 20, 7)
+    _check_stages(ex, orc, img, f"sf={sf}")
+
+
 def test_tables_match_oracle(pkg, oracle):
     ex = _extractor(pkg, 2000, 640, 480)
     orc = oracle.Oracle(2000, 1.2, 8, 20, 7)
