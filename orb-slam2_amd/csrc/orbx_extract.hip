@@ -685,7 +685,13 @@ static size_t tree_lds_bytes(const Geom &G, int lds_pts_cap)
     const size_t cap = G.max_node_cap;
     return cap * (4 + 4 + 8 + 8 + 16 + 4 * 5) + (size_t)((G.max_cells_level + 4) & ~3) * 4 + (size_t)lds_pts_cap * 6 + 64;
 }
-static const int kLdsPtsCap = 12288;
+// LDS point capacity of k_tree: enough for a level's typical candidate count (P_0/96), bounded so that
+// several (level, image) workgroups fit one CU; levels with more candidates use the HBM scratch.
+static int lds_pts_cap(const Geom &G)
+{
+    int c = (G.lv[0].w * G.lv[0].h / 96 + 1023) & ~1023;
+    return c < 4096 ? 4096 : c > 12288 ? 12288 : c;
+}
 
 int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
 {
@@ -779,7 +785,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         }
         L.resize_lds = ok ? 1 : 0;
     }
-    if (tree_lds_bytes(G, kLdsPtsCap) > 160 * 1024) { orbx_set_error("nfeatures too large for the quadtree kernel's LDS"); return ORBX_E_INVALID; }
+    if (tree_lds_bytes(G, lds_pts_cap(G)) > 160 * 1024) { orbx_set_error("nfeatures too large for the quadtree kernel's LDS"); return ORBX_E_INVALID; }
     ORBX_HIP(hipSetDevice(e->device));
     ORBX_HIP(hipStreamSynchronize(e->stream));
     const size_t B = e->max_batch;
@@ -803,7 +809,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
     ORBX_HIP(hipMemcpy(e->d_tabs, tabs.data(), tabs.size() * 2, hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(e->d_geom, &G, sizeof G, hipMemcpyHostToDevice));
     ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)tree_lds_bytes(G, kLdsPtsCap)));
+                                 (int)tree_lds_bytes(G, lds_pts_cap(G))));
     e->geom = G;
     return ORBX_OK;
 }
@@ -962,8 +968,8 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
     orbx_prof_end(e, s);
     int *err_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;
     orbx_prof_begin(e, ORBX_STAGE_TREE, s);
-    hipLaunchKernelGGL(k_tree, dim3(G.nlevels, batch), dim3(256), tree_lds_bytes(G, kLdsPtsCap), s, e->d_geom,
-                       e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, kLdsPtsCap, err_flag);
+    hipLaunchKernelGGL(k_tree, dim3(G.nlevels, batch), dim3(256), tree_lds_bytes(G, lds_pts_cap(G)), s, e->d_geom,
+                       e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, lds_pts_cap(G), err_flag);
     orbx_prof_end(e, s);
     orbx_prof_begin(e, ORBX_STAGE_DESC, s);
     hipLaunchKernelGGL(k_desc, dim3(G.kp_total, batch), dim3(64), 0, s, e->d_geom, pr, e->d_lvl_cnt, e->d_lvl_kp,
