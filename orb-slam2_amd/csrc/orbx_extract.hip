@@ -236,44 +236,40 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, PyrRef 
     const int npx = dw * dh;
     const FastDiv fdw(dw);
     const uint8_t *t0 = tile + 3 * P + xo + 3;
+    // ---- pretest over all pixels (row-major), ordered compaction of the survivors
     int nlist = 0;
     for (int p0 = 0; p0 < npx; p0 += 64) {
-        const int p = p0 + lane;
-        bool pass = false;
-        if (p < npx) {
-            const int py = fdw.div(p), px = p - py * dw;
-            const uint8_t *t = t0 + py * P + px;
-            const int v = t[0];
-            const int d0 = v - t[3 * P], d8 = v - t[-3 * P], d4 = v - t[3], d12 = v - t[-3];
-            pass = ((d0 > min_th || d8 > min_th) && (d4 > min_th || d12 > min_th)) ||
-                   ((d0 < -min_th || d8 < -min_th) && (d4 < -min_th || d12 < -min_th));
-        }
+        const int p = p0 + lane, pc = min(p, npx - 1);
+        const int py = fdw.div(pc), px = pc - py * dw;
+        const uint8_t *t = t0 + py * P + px;
+        const int v = t[0];
+        const int d0 = v - t[3 * P], d8 = v - t[-3 * P], d4 = v - t[3], d12 = v - t[-3];
+        // dark: min(max(d0,d8), max(d4,d12)) > th ; bright: max(min(d0,d8), min(d4,d12)) < -th
+        const int dk = min(max(d0, d8), max(d4, d12)), br = max(min(d0, d8), min(d4, d12));
+        const bool pass = (max(dk, -br) > min_th) & (p < npx);
         const unsigned long long m = __ballot(pass);
-        if (pass) list[nlist + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (uint16_t)p;
+        if (pass) list[nlist + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (uint16_t)((py << 6) | px);
         nlist += __popcll(m);
     }
     __syncthreads();
+    // ---- full score on the compacted pixels (dense lanes); list entries are (py<<6 | px), ascending
     for (int i = lane; i < nlist; i += 64) {
-        const int p = list[i];
-        const int py = fdw.div(p), px = p - py * dw;
+        const int e = list[i], py = e >> 6, px = e & 63;
         sc[(py + 1) * SP + px + 1] = (uint8_t)fast_score_full(t0 + py * P + px, min_th);
     }
     __syncthreads();
-    // NMS: one ballot per 64 consecutive (row-major) pixels; masks stay in LDS for the emission pass
-    const int nchunk = (npx + 63) >> 6;
+    // ---- NMS on the same list (only listed pixels can score > 0); one ballot per 64 entries
+    const int nchunk = (nlist + 63) >> 6;
     unsigned long long any_ini = 0;
     for (int ch = 0; ch < nchunk; ch++) {
-        const int q = ch * 64 + lane;
-        bool is_max = false, is_ini = false;
-        if (q < npx) {
-            const int py = fdw.div(q), px = q - py * dw;
-            const uint8_t *c = sc + (py + 1) * SP + px + 1;
-            const int s = c[0];
-            is_max = s > 0 && s > c[-1] && s > c[1] && s > c[-SP - 1] && s > c[-SP] && s > c[-SP + 1] &&
-                     s > c[SP - 1] && s > c[SP] && s > c[SP + 1];
-            is_ini = is_max && s >= ini_th;
-        }
-        const unsigned long long mm = __ballot(is_max), mi = __ballot(is_ini);
+        const int i = ch * 64 + lane;
+        const int e = list[min(i, nlist - 1)], py = e >> 6, px = e & 63;
+        const uint8_t *c = sc + (py + 1) * SP + px + 1;
+        const int s = c[0];
+        const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)c[-SP - 1], (int)c[-SP])),
+                           max(max((int)c[-SP + 1], (int)c[SP - 1]), max((int)c[SP], (int)c[SP + 1])));
+        const bool is_max = (i < nlist) & (s > nb); // strict 3x3 maximum; s > nb >= 0 implies s > 0
+        const unsigned long long mm = __ballot(is_max), mi = __ballot(is_max & (s >= ini_th));
         if (lane == 0) { masks[2 * ch] = mm; masks[2 * ch + 1] = mi; }
         any_ini |= mi;
     }
@@ -285,8 +281,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, PyrRef 
         const unsigned long long sel = masks[2 * ch + pick];
         if (sel == 0) continue;
         if ((sel >> lane) & 1ull) {
-            const int q = ch * 64 + lane;
-            const int py = fdw.div(q), px = q - py * dw;
+            const int e = list[ch * 64 + lane], py = e >> 6, px = e & 63;
             const int s = sc[(py + 1) * SP + px + 1];
             const int X = ini_x + 3 + px - ORBX_MIN_BORDER, Y = ini_y + 3 + py - ORBX_MIN_BORDER;
             const int o = off + __builtin_amdgcn_mbcnt_hi((unsigned)(sel >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sel, 0));
