@@ -881,7 +881,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *e)
     if (e->stream) hipStreamSynchronize(e->stream);
     for (auto &ev : e->prof_ev) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     void *ptrs[] = { e->d_geom, e->d_tabs, e->d_pyr, e->d_stage_in, e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid,
-                     e->d_lvl_cnt, e->d_lvl_kp, e->d_out_kps, e->d_out_desc, e->d_out_n, e->d_out_ur, e->d_out_depth, e->d_st_dist };
+                     e->d_lvl_cnt, e->d_lvl_kp, e->d_out_kps, e->d_out_desc, e->d_out_n, e->d_out_ur, e->d_out_depth, e->d_st_dist, e->d_st_entries };
     for (void *p : ptrs) if (p) hipFree(p);
     for (void *p : e->scratch) if (p) hipFree(p);
     if (e->stream) hipStreamDestroy(e->stream);

@@ -1,9 +1,10 @@
 // orbx_stereo.hip — Frame::ComputeStereoMatches (reference src/Frame.cc:577-751) for gfx950.
 //
-// K5 k_stereo: one wave per left keypoint.  Coarse stage: all right keypoints are tested 64 at a
-// time against the row band / octave / disparity-range predicates of :594-604,:644-649 (no row
-// table is built; the predicate is evaluated directly), 256-bit Hamming with v_bcnt, wave min of
-// (dist<<16 | iR) reproduces "first minimum in ascending iR" (:654-658).  Fine stage: 11x11
+// K5a k_stereo_prep: the row table vRowIndices of :584-604 as a CSR in HBM, one workgroup per pair.
+// K5 k_stereo: one wave per left keypoint.  Coarse stage: the right keypoints listed for the left
+// keypoint's row are tested 64 at a time against the octave / disparity-range predicates of
+// :644-649, 256-bit Hamming with v_bcnt, wave min of (dist<<16 | iR) reproduces "first minimum in
+// ascending iR" (:654-658).  Fine stage: 11x11
 // centre-subtracted L1 SAD over 11 shifts on the unblurred pyramids (:666-703), parabola (:709-716),
 // disparity / depth (:719-733) by the same wave.
 // K6 k_stereo_cut: per pair, radix-select the median SAD and drop matches >= 1.5*1.4*median (:737-750).
@@ -17,16 +18,55 @@ __device__ __forceinline__ int lvl_px(const uint8_t *img, int pitch, int w, int 
     return img[(long long)reflect101(y, h) * pitch + reflect101(x, w)];
 }
 
+// Row table of src/Frame.cc:584-604 (vRowIndices), built per stereo pair by one workgroup: right
+// keypoint iR is listed in every image row of its band [floor(y-r), ceil(y+r)], r = 2*scale[octave].
+// CSR in HBM: row_off[rows+1] + entries (order inside a row is irrelevant: the coarse stage reduces
+// with min(dist<<16 | iR), which is "first minimum in ascending iR").
+extern __shared__ __align__(16) int prep_smem[];
+
+__global__ __launch_bounds__(256) void k_stereo_prep(const Geom *__restrict__ g, const orbx_keypoint *__restrict__ kR,
+                                                     const int *__restrict__ nR, int cap, StereoTabs tabs,
+                                                     int *__restrict__ row_off, uint16_t *__restrict__ entries, int ent_cap)
+{
+    __shared__ int s_w[4];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int rows = g->lv[0].h, n_r = nR[p];
+    int *cnt = prep_smem, *cur = prep_smem + ((rows + 4) & ~3);
+    const orbx_keypoint *kr = kR + (long long)p * cap;
+    for (int i = tid; i < rows; i += 256) { cnt[i] = 0; cur[i] = 0; }
+    __syncthreads();
+    for (int ir = tid; ir < n_r; ir += 256) {
+        const float y = kr[ir].y, r = 2.0f * tabs.sf[kr[ir].octave];
+        const int maxr = min((int)ceilf(y + r), rows - 1), minr = max((int)floorf(y - r), 0);
+        for (int yi = minr; yi <= maxr; yi++) atomicAdd(&cnt[yi], 1);
+    }
+    __syncthreads();
+    const int total = lds_excl_scan(cnt, rows, s_w);
+    int *ro = row_off + (long long)p * (rows + 1);
+    for (int i = tid; i < rows; i += 256) ro[i] = min(cnt[i], ent_cap);
+    if (tid == 0) ro[rows] = min(total, ent_cap);
+    uint16_t *en = entries + (long long)p * ent_cap;
+    for (int ir = tid; ir < n_r; ir += 256) {
+        const float y = kr[ir].y, r = 2.0f * tabs.sf[kr[ir].octave];
+        const int maxr = min((int)ceilf(y + r), rows - 1), minr = max((int)floorf(y - r), 0);
+        for (int yi = minr; yi <= maxr; yi++) {
+            const int pos = cnt[yi] + atomicAdd(&cur[yi], 1);
+            if (pos < ent_cap) en[pos] = (uint16_t)ir;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrRef prL, PyrRef prR, int img_l0, int img_r0,
                                                 const orbx_keypoint *__restrict__ kL, const uint32_t *__restrict__ dL,
                                                 const int *__restrict__ nL, const orbx_keypoint *__restrict__ kR,
                                                 const uint32_t *__restrict__ dR, const int *__restrict__ nR, int cap,
                                                 float bf, float max_d, StereoTabs tabs, float *__restrict__ u_right,
-                                                float *__restrict__ depth, int *__restrict__ st_dist)
+                                                float *__restrict__ depth, int *__restrict__ st_dist,
+                                                const int *__restrict__ row_off, const uint16_t *__restrict__ entries, int ent_cap)
 {
     const int p = blockIdx.y, lane = threadIdx.x & 63;
     const int il = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n_l = nL[p], n_r = nR[p];
+    const int n_l = nL[p];
     if (il >= n_l) return; // wave-uniform
     const long long ol = (long long)p * cap + il;
     const orbx_keypoint *kr = kR + (long long)p * cap;
@@ -44,14 +84,14 @@ __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrR
         uint32_t a[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) a[i] = dL[ol * 8 + i];
-        for (int base = 0; base < n_r; base += 64) {
-            const int ir = base + lane;
-            if (ir < n_r) {
+        const int *ro = row_off + (long long)p * (n_rows + 1);
+        const uint16_t *en = entries + (long long)p * ent_cap;
+        const int e1 = ro[row + 1];
+        for (int base = ro[row]; base < e1; base += 64) { // right keypoints whose row band holds this row (:622)
+            if (base + lane < e1) {
+                const int ir = en[base + lane];
                 const orbx_keypoint q = kr[ir];
-                const float r = 2.0f * tabs.sf[q.octave];
-                const int maxr = (int)ceilf(q.y + r), minr = (int)floorf(q.y - r);
-                if (row >= minr && row <= maxr && q.octave >= level_l - 1 && q.octave <= level_l + 1 &&
-                    q.x >= min_u && q.x <= max_u) {
+                if (q.octave >= level_l - 1 && q.octave <= level_l + 1 && q.x >= min_u && q.x <= max_u) {
                     uint32_t bq[8];
                     const uint4 *src = reinterpret_cast<const uint4 *>(dr + (long long)ir * 8);
                     const uint4 v0 = src[0], v1 = src[1];
@@ -204,19 +244,38 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
         ORBX_HIP(hipMalloc((void **)&L->d_st_dist, need));
         L->st_cap = need;
     }
+    StereoTabs tabs;
+    for (int i = 0; i < ORBX_MAX_LEVELS; i++) { tabs.sf[i] = L->sf[i]; tabs.isf[i] = L->isf[i]; }
+    // row table: a right keypoint spans at most 2*r+3 rows, r = 2*scale[top level]
+    const int rows = L->geom.lv[0].h;
+    const int ent_cap = cap * ((int)(4.0f * L->sf[L->nlevels - 1]) + 4);
+    void *d_row_off, *d_entries;
+    {
+        int rc;
+        if ((rc = orbx_scratch(L, 7, (size_t)batch * (rows + 1) * sizeof(int), &d_row_off))) return rc;
+        const size_t need_e = (size_t)batch * ent_cap * sizeof(uint16_t);
+        if (need_e > L->st_ent_cap || !L->d_st_entries) {
+            ORBX_HIP(hipStreamSynchronize(s));
+            if (L->d_st_entries) ORBX_HIP(hipFree(L->d_st_entries));
+            L->d_st_entries = nullptr;
+            ORBX_HIP(hipMalloc((void **)&L->d_st_entries, need_e));
+            L->st_ent_cap = need_e;
+        }
+        d_entries = L->d_st_entries;
+    }
     PyrRef pl, pr;
     pl.img0 = L->last_img0; pl.img0_stride = (long long)L->last_img_stride; pl.img0_pitch = (int)L->last_pitch;
     pl.pyr = L->d_pyr; pl.pyr_stride = L->geom.pyr_bytes;
     pr.img0 = R->last_img0; pr.img0_stride = (long long)R->last_img_stride; pr.img0_pitch = (int)R->last_pitch;
     pr.pyr = R->d_pyr; pr.pyr_stride = R->geom.pyr_bytes;
-    StereoTabs tabs;
-    for (int i = 0; i < ORBX_MAX_LEVELS; i++) { tabs.sf[i] = L->sf[i]; tabs.isf[i] = L->isf[i]; }
     const float max_d = bf / min_z; // src/Frame.cc:609
     orbx_prof_begin(L, ORBX_STAGE_STEREO, s);
+    hipLaunchKernelGGL(k_stereo_prep, dim3(batch), dim3(256), (size_t)2 * ((rows + 4) & ~3) * sizeof(int), s, L->d_geom,
+                       (const orbx_keypoint *)d_kR, (const int *)d_nR, cap, tabs, (int *)d_row_off, (uint16_t *)d_entries, ent_cap);
     hipLaunchKernelGGL(k_stereo, dim3((cap + 3) / 4, batch), dim3(256), 0, s, L->d_geom, pl, pr, img_l0, img_r0,
                        (const orbx_keypoint *)d_kL, (const uint32_t *)d_dL, (const int *)d_nL,
                        (const orbx_keypoint *)d_kR, (const uint32_t *)d_dR, (const int *)d_nR, cap, bf, max_d, tabs,
-                       (float *)d_u_right, (float *)d_depth, L->d_st_dist);
+                       (float *)d_u_right, (float *)d_depth, L->d_st_dist, (const int *)d_row_off, (const uint16_t *)d_entries, ent_cap);
     orbx_prof_end(L, s);
     orbx_prof_begin(L, ORBX_STAGE_STEREO_CUT, s);
     hipLaunchKernelGGL(k_stereo_cut, dim3(batch), dim3(256), 0, s, (const int *)d_nL, cap, (float *)d_u_right,
