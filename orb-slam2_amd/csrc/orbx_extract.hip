@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_resize_direct(const Geom *__restrict__ 
 // A pixel is a FAST-9 corner at threshold t iff max(A,B) > t and its OpenCV score is then
 // max(A,B)-1 independent of t, so one score map at minThFAST serves both passes of
 // src/ORBextractor.cc:988-995.  The sliding 9-window max/min over the circular ring is a doubling
-// network (2,4,8,+1) evaluated on packed u16 pairs (v_pk_max_u16 / v_pk_min_u16).
+// 3x3 composition of three-input min/max (v_min3_i32 / v_max3_i32).
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ u16x2 pk(unsigned lo, unsigned hi)
@@ -150,29 +150,32 @@ __device__ __forceinline__ int fast_score_full(const uint8_t *t, int th)
 {
     constexpr int P = ORBX_TILE_PITCH;
     const int v = t[0];
-    unsigned x[16];
+    int x[16];
     x[0] = t[3 * P];      x[1] = t[3 * P + 1];  x[2] = t[2 * P + 2];   x[3] = t[P + 3];
     x[4] = t[3];          x[5] = t[-P + 3];     x[6] = t[-2 * P + 2];  x[7] = t[-3 * P + 1];
     x[8] = t[-3 * P];     x[9] = t[-3 * P - 1]; x[10] = t[-2 * P - 2]; x[11] = t[-P - 3];
     x[12] = t[-3];        x[13] = t[P - 3];     x[14] = t[2 * P - 2];  x[15] = t[3 * P - 1];
-    u16x2 E[8], O[8], hi[8], lo[8], h2[8], l2[8];
+    // window 9 = 3 x 3 with three-input min/max (v_min3_i32 / v_max3_i32)
+    int lo3[16], hi3[16];
 #pragma unroll
-    for (int i = 0; i < 8; i++) { E[i] = pk(x[2 * i], x[2 * i + 1]); O[i] = pk(x[2 * i + 1], x[(2 * i + 2) & 15]); }
+    for (int k = 0; k < 16; k++) {
+        lo3[k] = min(min(x[k], x[(k + 1) & 15]), x[(k + 2) & 15]);
+        hi3[k] = max(max(x[k], x[(k + 1) & 15]), x[(k + 2) & 15]);
+    }
+    int lo9[16], hi9[16];
 #pragma unroll
-    for (int i = 0; i < 8; i++) { hi[i] = __builtin_elementwise_max(E[i], O[i]); lo[i] = __builtin_elementwise_min(E[i], O[i]); }
+    for (int k = 0; k < 16; k++) {
+        lo9[k] = min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]);
+        hi9[k] = max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]);
+    }
+    int a[6], bq[6];
 #pragma unroll
-    for (int i = 0; i < 8; i++) { h2[i] = __builtin_elementwise_max(hi[i], hi[(i + 1) & 7]); l2[i] = __builtin_elementwise_min(lo[i], lo[(i + 1) & 7]); }
-#pragma unroll
-    for (int i = 0; i < 8; i++) { hi[i] = __builtin_elementwise_max(h2[i], h2[(i + 2) & 7]); lo[i] = __builtin_elementwise_min(l2[i], l2[(i + 2) & 7]); }
-#pragma unroll
-    for (int i = 0; i < 8; i++) { h2[i] = __builtin_elementwise_max(hi[i], E[(i + 4) & 7]); l2[i] = __builtin_elementwise_min(lo[i], E[(i + 4) & 7]); }
-    // h2 = max over each 9-arc, l2 = min over each 9-arc (two arcs per register)
-#pragma unroll
-    for (int i = 0; i < 4; i++) { h2[i] = __builtin_elementwise_min(h2[i], h2[i + 4]); l2[i] = __builtin_elementwise_max(l2[i], l2[i + 4]); }
-#pragma unroll
-    for (int i = 0; i < 2; i++) { h2[i] = __builtin_elementwise_min(h2[i], h2[i + 2]); l2[i] = __builtin_elementwise_max(l2[i], l2[i + 2]); }
-    const u16x2 hm = __builtin_elementwise_min(h2[0], h2[1]), lm = __builtin_elementwise_max(l2[0], l2[1]);
-    const int min_of_max = min((int)hm.x, (int)hm.y), max_of_min = max((int)lm.x, (int)lm.y);
+    for (int k = 0; k < 5; k++) {
+        a[k] = max(max(lo9[3 * k], lo9[3 * k + 1]), lo9[3 * k + 2]);
+        bq[k] = min(min(hi9[3 * k], hi9[3 * k + 1]), hi9[3 * k + 2]);
+    }
+    const int max_of_min = max(max(max(a[0], a[1]), a[2]), max(max(a[3], a[4]), lo9[15]));
+    const int min_of_max = min(min(min(bq[0], bq[1]), bq[2]), min(min(bq[3], bq[4]), hi9[15]));
     const int s = max(v - min_of_max, max_of_min - v);
     return s > th ? s - 1 : 0;
 }
