@@ -188,8 +188,8 @@ __device__ __forceinline__ int fast_score_full(const uint8_t *t, int th)
 // emission into the cell's candidate slots.  Candidate = x | y<<12 | score<<24, (x,y) relative to (16,16).
 extern __shared__ __align__(16) unsigned char fast_smem[];
 
-__global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, PyrRef pr, int *__restrict__ cell_cnt,
-                                             uint32_t *__restrict__ cand, int ini_th, int min_th)
+__global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const CellRec *__restrict__ cells, PyrRef pr,
+                                             int *__restrict__ cell_cnt, uint32_t *__restrict__ cand, int ini_th, int min_th)
 {
     constexpr int P = ORBX_TILE_PITCH, SP = ORBX_SCORE_PITCH;
     uint8_t *tile = fast_smem;
@@ -197,32 +197,29 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, PyrRef 
     uint16_t *list = reinterpret_cast<uint16_t *>(fast_smem + g->fast_lds_list);
     unsigned long long *masks = reinterpret_cast<unsigned long long *>(fast_smem + g->fast_lds_mask);
     const int b = blockIdx.y, cell = blockIdx.x, lane = threadIdx.x;
-    int l = 0;
-    while (l + 1 < g->nlevels && cell >= g->lv[l + 1].cell_base) l++;
-    const LevelGeom &L = g->lv[l];
-    const int ci = cell - L.cell_base;
-    const int ci_row = ci / L.n_cols, ci_col = ci - ci_row * L.n_cols;
-    const int max_bx = L.w - ORBX_MIN_BORDER, max_by = L.h - ORBX_MIN_BORDER;
-    const int ini_y = ORBX_MIN_BORDER + ci_row * L.h_cell, ini_x = ORBX_MIN_BORDER + ci_col * L.w_cell;
-    const int max_y = min(ini_y + L.h_cell + 6, max_by), max_x = min(ini_x + L.w_cell + 6, max_bx);
+    const CellRec rec = cells[cell];
     int *my_cnt = cell_cnt + (long long)b * g->total_cells + cell;
-    const int tw = max_x - ini_x, th = max_y - ini_y, dw = tw - 6, dh = th - 6;
-    // src/ORBextractor.cc:961-976 skip rules (note the asymmetric 3 / 6)
-    if (ini_y >= max_by - 3 || ini_x >= max_bx - 6 || dw <= 0 || dh <= 0) {
+    if (rec.skip) { // src/ORBextractor.cc:961-976 skip rules, evaluated on the host
         if (lane == 0) *my_cnt = 0;
         return;
     }
-    int pitch;
-    const uint8_t *img = orbx_level_ptr(pr, L, l, b, &pitch);
+    const int ini_x = rec.ini_x, ini_y = rec.ini_y, tw = rec.tw, th = rec.th, dw = tw - 6, dh = th - 6;
+    const int pitch = rec.level == 0 ? pr.img0_pitch : rec.pitch;
+    const uint8_t *img = rec.level == 0 ? pr.img0 + (long long)b * pr.img0_stride
+                                        : pr.pyr + (long long)b * pr.pyr_stride + rec.pyr_off;
     int xo; // tile column of image column ini_x
     if ((((uintptr_t)img | (unsigned)pitch) & 3) == 0) {
         xo = ini_x & 3;
         const int ndw = (tw + xo + 3) >> 2; // <= 17 dwords per row
         const FastDiv fd(ndw);
         const uint8_t *src = img + (long long)ini_y * pitch + (ini_x - xo);
+        // (r, c) of element i = lane + 64k advances by (64 / ndw, 64 % ndw) with carry: no per-element division
+        int r = fd.div(lane), c = lane - r * ndw;
+        const int dr = fd.div(64), dc = 64 - dr * ndw;
         for (int i = lane; i < th * ndw; i += 64) {
-            const int r = fd.div(i), c = i - r * ndw;
-            reinterpret_cast<uint32_t *>(tile + r * P)[c] = *reinterpret_cast<const uint32_t *>(src + (long long)r * pitch + 4 * c);
+            reinterpret_cast<uint32_t *>(tile + r * P)[c] = *reinterpret_cast<const uint32_t *>(src + (unsigned)(r * pitch + 4 * c));
+            r += dr; c += dc;
+            if (c >= ndw) { c -= ndw; r++; }
         }
     } else {
         xo = 0;
@@ -232,8 +229,8 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, PyrRef 
         }
     }
     {
-        uint32_t *z = reinterpret_cast<uint32_t *>(sc);
-        for (int i = lane; i < (dh + 2) * (SP / 4); i += 64) z[i] = 0;
+        uint4 *z = reinterpret_cast<uint4 *>(sc);
+        for (int i = lane; i < (dh + 2) * (SP / 16); i += 64) z[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     const int npx = dw * dh;
@@ -278,7 +275,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, PyrRef 
     }
     __syncthreads();
     const int pick = any_ini ? 1 : 0; // the cell falls back to minThFAST only if iniThFAST kept nothing (:991-995)
-    uint32_t *slot = cand + (long long)b * g->cand_total + L.cand_off + (long long)ci * L.cand_cap;
+    uint32_t *slot = cand + (long long)b * g->cand_total + rec.cand_slot;
     int off = 0;
     for (int ch = 0; ch < nchunk; ch++) {
         const unsigned long long sel = masks[2 * ch + pick];
@@ -288,11 +285,11 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, PyrRef 
             const int s = sc[(py + 1) * SP + px + 1];
             const int X = ini_x + 3 + px - ORBX_MIN_BORDER, Y = ini_y + 3 + py - ORBX_MIN_BORDER;
             const int o = off + __builtin_amdgcn_mbcnt_hi((unsigned)(sel >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sel, 0));
-            if (o < L.cand_cap) slot[o] = (uint32_t)X | ((uint32_t)Y << 12) | ((uint32_t)s << 24);
+            if (o < rec.cand_cap) slot[o] = (uint32_t)X | ((uint32_t)Y << 12) | ((uint32_t)s << 24);
         }
         off += __popcll(sel);
     }
-    if (lane == 0) *my_cnt = min(off, L.cand_cap);
+    if (lane == 0) *my_cnt = min(off, rec.cand_cap);
 }
 
 // ================================================================ K3: quadtree cull (E4)
@@ -783,12 +780,31 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         }
         L.resize_lds = ok ? 1 : 0;
     }
+    std::vector<CellRec> cells(G.total_cells);
+    for (int l = 0; l < e->nlevels; l++) {
+        const LevelGeom &L = G.lv[l];
+        const int max_bx = L.w - ORBX_MIN_BORDER, max_by = L.h - ORBX_MIN_BORDER;
+        for (int ci = 0; ci < L.n_cells; ci++) {
+            CellRec &c = cells[L.cell_base + ci];
+            const int row = ci / L.n_cols, col = ci % L.n_cols;
+            const int ini_y = ORBX_MIN_BORDER + row * L.h_cell, ini_x = ORBX_MIN_BORDER + col * L.w_cell; // :957-971
+            const int max_y = ini_y + L.h_cell + 6 < max_by ? ini_y + L.h_cell + 6 : max_by;
+            const int max_x = ini_x + L.w_cell + 6 < max_bx ? ini_x + L.w_cell + 6 : max_bx;
+            c.level = (short)l;
+            c.ini_x = (short)ini_x; c.ini_y = (short)ini_y; c.tw = (short)(max_x - ini_x); c.th = (short)(max_y - ini_y);
+            // src/ORBextractor.cc:961-976 skip rules (note the asymmetric 3 / 6)
+            c.skip = (ini_y >= max_by - 3 || ini_x >= max_bx - 6 || c.tw - 6 <= 0 || c.th - 6 <= 0) ? 1 : 0;
+            c.pitch = L.pitch; c.cand_cap = L.cand_cap; c.pyr_off = L.pyr_off;
+            c.cand_slot = L.cand_off + (long long)ci * L.cand_cap;
+        }
+    }
     if (tree_lds_bytes(G, lds_pts_cap(G)) > 160 * 1024) { orbx_set_error("nfeatures too large for the quadtree kernel's LDS"); return ORBX_E_INVALID; }
     ORBX_HIP(hipSetDevice(e->device));
     ORBX_HIP(hipStreamSynchronize(e->stream));
     const size_t B = e->max_batch;
     int rc;
     if ((rc = ensure(&e->d_tabs, &e->tabs_cap, tabs.size() * 2))) return rc;
+    if ((rc = ensure(&e->d_cells, &e->cells_cap, cells.size() * sizeof(CellRec)))) return rc;
     if ((rc = ensure(&e->d_pyr, &e->pyr_cap, (size_t)G.pyr_bytes * B))) return rc;
     if ((rc = ensure(&e->d_cell_cnt, &e->cell_cnt_cap, (size_t)G.total_cells * B * 4))) return rc;
     if ((rc = ensure(&e->d_cand, &e->cand_cap, (size_t)G.cand_total * B * 4))) return rc;
@@ -805,6 +821,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
     }
     if ((rc = ensure(&e->d_lvl_kp, &e->lvl_kp_cap, (size_t)G.kp_total * B * 4))) return rc;
     ORBX_HIP(hipMemcpy(e->d_tabs, tabs.data(), tabs.size() * 2, hipMemcpyHostToDevice));
+    ORBX_HIP(hipMemcpy(e->d_cells, cells.data(), cells.size() * sizeof(CellRec), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(e->d_geom, &G, sizeof G, hipMemcpyHostToDevice));
     ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)tree_lds_bytes(G, lds_pts_cap(G))));
@@ -883,7 +900,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *e)
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
     for (auto &ev : e->prof_ev) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
-    void *ptrs[] = { e->d_geom, e->d_tabs, e->d_pyr, e->d_stage_in, e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid,
+    void *ptrs[] = { e->d_cells, e->d_geom, e->d_tabs, e->d_pyr, e->d_stage_in, e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid,
                      e->d_lvl_cnt, e->d_lvl_kp, e->d_out_kps, e->d_out_desc, e->d_out_n, e->d_out_ur, e->d_out_depth, e->d_st_dist, e->d_st_entries };
     for (void *p : ptrs) if (p) hipFree(p);
     for (void *p : e->scratch) if (p) hipFree(p);
@@ -961,7 +978,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
         orbx_prof_end(e, s);
     }
     orbx_prof_begin(e, ORBX_STAGE_FAST, s);
-    hipLaunchKernelGGL(k_fast, dim3(G.total_cells, batch), dim3(64), G.fast_lds_bytes, s, e->d_geom, pr, e->d_cell_cnt, e->d_cand,
+    hipLaunchKernelGGL(k_fast, dim3(G.total_cells, batch), dim3(64), G.fast_lds_bytes, s, e->d_geom, e->d_cells, pr, e->d_cell_cnt, e->d_cand,
                        e->ini_th, e->min_th);
     orbx_prof_end(e, s);
     int *err_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;

@@ -45,6 +45,18 @@ struct Geom {
     LevelGeom lv[ORBX_MAX_LEVELS];
 };
 
+// Per-cell record of k_fast (same for every image): one 32-byte scalar load replaces the level search
+// and the cell-grid arithmetic (a chain of dependent scalar loads per wave).
+struct CellRec {
+    short level, skip;
+    short ini_x, ini_y, tw, th;  // cell rectangle incl. 3-px halo, level coordinates
+    int pitch;                   // level pitch (levels >= 1; level 0 uses the caller's pitch)
+    int cand_cap;
+    long long pyr_off;           // byte offset of the level in one image's pyramid block
+    long long cand_slot;         // first candidate slot (u32 units) of this cell in one image's block
+};
+static_assert(sizeof(CellRec) == 40, "CellRec layout");
+
 struct ProfEvent { hipEvent_t a, b; int stage; };
 
 struct orbx_extractor {
@@ -61,6 +73,7 @@ struct orbx_extractor {
     Geom geom;           // host copy (geom.w == 0: none yet)
     Geom *d_geom;        // device copy
     int16_t *d_tabs; size_t tabs_cap;      // resize tables
+    CellRec *d_cells; size_t cells_cap;    // per-cell records of k_fast
     // workspace (sized for max_w x max_h x max_batch)
     uint8_t *d_pyr; size_t pyr_cap;        // levels >= 1, all images
     uint8_t *d_stage_in; size_t stage_in_cap; // host-API input staging (level 0)

@@ -4,7 +4,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liborbx.so")
+_SO = os.environ.get("ORBX_SO") or os.path.join(_HERE, "liborbx.so")  # ORBX_SO: diagnostic builds only
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])  # == cv::KeyPoint, 28 B
