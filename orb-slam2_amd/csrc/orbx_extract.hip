@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void k_resize_direct(const Geom *__restrict__ 
 // src/ORBextractor.cc:988-995.  The sliding 9-window max/min over the circular ring is a doubling
 // 3x3 composition of three-input min/max (v_min3_i32 / v_max3_i32).
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ u16x2 pk(unsigned lo, unsigned hi)
 {
@@ -236,20 +237,56 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
     const int npx = dw * dh;
     const FastDiv fdw(dw);
     const uint8_t *t0 = tile + 3 * P + xo + 3;
-    // ---- pretest over all pixels (row-major), ordered compaction of the survivors
+    // ---- pretest, 4 horizontally adjacent pixels per lane: five aligned dword LDS loads (centre, W, E,
+    // N, S), packed-i16 differences; dark  <=> min(max(dN,dS), max(dE,dW)) >  th,
+    //                                bright <=> max(min(dN,dS), min(dE,dW)) < -th.
+    // Survivors are appended in row-major order (ballot prefix over the per-lane counts).
     int nlist = 0;
-    for (int p0 = 0; p0 < npx; p0 += 64) {
-        const int p = p0 + lane, pc = min(p, npx - 1);
-        const int py = fdw.div(pc), px = pc - py * dw;
-        const uint8_t *t = t0 + py * P + px;
-        const int v = t[0];
-        const int d0 = v - t[3 * P], d8 = v - t[-3 * P], d4 = v - t[3], d12 = v - t[-3];
-        // dark: min(max(d0,d8), max(d4,d12)) > th ; bright: max(min(d0,d8), min(d4,d12)) < -th
-        const int dk = min(max(d0, d8), max(d4, d12)), br = max(min(d0, d8), min(d4, d12));
-        const bool pass = (max(dk, -br) > min_th) & (p < npx);
-        const unsigned long long m = __ballot(pass);
-        if (pass) list[nlist + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = (uint16_t)((py << 6) | px);
-        nlist += __popcll(m);
+    {
+        const int tc_lo = xo + 3, tc_hi = xo + 2 + dw;      // tile columns of the detectable pixels
+        const int g_lo = tc_lo >> 2, gpr = (tc_hi >> 2) - g_lo + 1;
+        const int nitems = dh * gpr;
+        const FastDiv fg(gpr);
+        const i16x2 thv = { (short)min_th, (short)min_th }, zero = { 0, 0 };
+        for (int i0 = 0; i0 < nitems; i0 += 64) {
+            const int i = i0 + lane, ic = min(i, nitems - 1);
+            const int py = fg.div(ic), gcol = g_lo + (ic - py * gpr);
+            const uint32_t *rc = reinterpret_cast<const uint32_t *>(tile + (py + 3) * P) + gcol;
+            const unsigned C = rc[0], Wd = rc[-1], Ed = rc[1], N = rc[3 * (P / 4)], S = rc[-3 * (P / 4)];
+            const unsigned Wv = __builtin_amdgcn_alignbyte(C, Wd, 1), Ev = __builtin_amdgcn_alignbyte(Ed, C, 3);
+            unsigned bits = 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const unsigned sel = h ? 0x0c030c02u : 0x0c010c00u; // bytes (2h, 2h+1) -> two u16
+                const i16x2 c = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, C, sel));
+                const i16x2 dn = c - __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, N, sel));
+                const i16x2 ds = c - __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, S, sel));
+                const i16x2 de = c - __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, Ev, sel));
+                const i16x2 dwv = c - __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, Wv, sel));
+                const i16x2 dk = __builtin_elementwise_min(__builtin_elementwise_max(dn, ds), __builtin_elementwise_max(de, dwv));
+                const i16x2 br = __builtin_elementwise_max(__builtin_elementwise_min(dn, ds), __builtin_elementwise_min(de, dwv));
+                const i16x2 r = __builtin_elementwise_max(dk, zero - br);
+                const unsigned t = __builtin_bit_cast(unsigned, thv - r); // negative halves <=> r > th
+                bits |= (((t >> 15) & 1u) | ((t >> 30) & 2u)) << (2 * h);
+            }
+            // keep only pixels inside the detectable columns of a real item
+            const int tc = 4 * gcol;
+            unsigned valid = 0xFu;
+            if (tc < tc_lo) valid &= 0xFu << (tc_lo - tc);
+            if (tc + 3 > tc_hi) valid &= 0xFu >> (tc + 3 - tc_hi);
+            bits &= (i < nitems) ? valid : 0u;
+            const int cnt = __popc(bits);
+            // exclusive prefix of cnt (0..4) over the wave from three ballots
+            const unsigned long long m0 = __ballot(cnt & 1), m1 = __ballot(cnt & 2), m2 = __ballot(cnt & 4);
+            int pos = nlist + __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0)) +
+                      2 * __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0)) +
+                      4 * __builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0));
+            const int e0 = (py << 6) + (tc - tc_lo); // tc - tc_lo may be negative for the first group
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (bits & (1u << j)) list[pos++] = (uint16_t)(e0 + j);
+            nlist += __popcll(m0) + 2 * __popcll(m1) + 4 * __popcll(m2);
+        }
     }
     __syncthreads();
     // ---- full score on the compacted pixels (dense lanes); list entries are (py<<6 | px), ascending
