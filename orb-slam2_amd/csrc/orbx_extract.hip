@@ -189,6 +189,14 @@ __device__ __forceinline__ int fast_score_full(const uint8_t *t, int th)
 // emission into the cell's candidate slots.  Candidate = x | y<<12 | score<<24, (x,y) relative to (16,16).
 extern __shared__ __align__(16) unsigned char fast_smem[];
 
+#ifdef ORBX_DIAG
+__device__ unsigned long long g_fast_stamp[4096 * 8]; // diagnostic build only: summed phase cycles of k_fast, 4096 slots
+#define STAMP(k) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+    if (threadIdx.x == 0) atomicAdd(&g_fast_stamp[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + (k)], _t - _t_prev); _t_prev = _t; } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const CellRec *__restrict__ cells, PyrRef pr,
                                              int *__restrict__ cell_cnt, uint32_t *__restrict__ cand, int ini_th, int min_th)
 {
@@ -198,6 +206,9 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
     uint16_t *list = reinterpret_cast<uint16_t *>(fast_smem + g->fast_lds_list);
     unsigned long long *masks = reinterpret_cast<unsigned long long *>(fast_smem + g->fast_lds_mask);
     const int b = blockIdx.y, cell = blockIdx.x, lane = threadIdx.x;
+#ifdef ORBX_DIAG
+    unsigned long long _t_prev = __builtin_amdgcn_s_memtime();
+#endif
     const CellRec rec = cells[cell];
     int *my_cnt = cell_cnt + (long long)b * g->total_cells + cell;
     if (rec.skip) { // src/ORBextractor.cc:961-976 skip rules, evaluated on the host
@@ -234,8 +245,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
         for (int i = lane; i < (dh + 2) * (SP / 16); i += 64) z[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    const int npx = dw * dh;
-    const FastDiv fdw(dw);
+    STAMP(0);
     const uint8_t *t0 = tile + 3 * P + xo + 3;
     // ---- pretest, 4 horizontally adjacent pixels per lane: five aligned dword LDS loads (centre, W, E,
     // N, S), packed-i16 differences; dark  <=> min(max(dN,dS), max(dE,dW)) >  th,
@@ -289,12 +299,14 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
         }
     }
     __syncthreads();
+    STAMP(1);
     // ---- full score on the compacted pixels (dense lanes); list entries are (py<<6 | px), ascending
     for (int i = lane; i < nlist; i += 64) {
         const int e = list[i], py = e >> 6, px = e & 63;
         sc[(py + 1) * SP + px + 1] = (uint8_t)fast_score_full(t0 + py * P + px, min_th);
     }
     __syncthreads();
+    STAMP(2);
     // ---- NMS on the same list (only listed pixels can score > 0); one ballot per 64 entries
     const int nchunk = (nlist + 63) >> 6;
     unsigned long long any_ini = 0;
@@ -311,6 +323,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
         any_ini |= mi;
     }
     __syncthreads();
+    STAMP(3);
     const int pick = any_ini ? 1 : 0; // the cell falls back to minThFAST only if iniThFAST kept nothing (:991-995)
     uint32_t *slot = cand + (long long)b * g->cand_total + rec.cand_slot;
     int off = 0;
@@ -327,7 +340,23 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
         off += __popcll(sel);
     }
     if (lane == 0) *my_cnt = min(off, rec.cand_cap);
+    STAMP(4);
+#ifdef ORBX_DIAG
+    if (lane == 0) atomicAdd(&g_fast_stamp[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + 7], 1ull);
+#endif
 }
+
+#ifdef ORBX_DIAG
+extern "C" int orbx_diag_fast_stamps(unsigned long long *out, int reset)
+{
+    ORBX_HIP(hipDeviceSynchronize());
+    static unsigned long long h[4096 * 8];
+    ORBX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fast_stamp), sizeof h));
+    for (int k = 0; k < 8; k++) { out[k] = 0; for (int i = 0; i < 4096; i++) out[k] += h[i * 8 + k]; }
+    if (reset) { memset(h, 0, sizeof h); ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fast_stamp), h, sizeof h)); }
+    return ORBX_OK;
+}
+#endif
 
 // ================================================================ K3: quadtree cull (E4)
 // ORBextractor::DistributeOctTree (src/ORBextractor.cc:617-915) as a label-propagation problem:

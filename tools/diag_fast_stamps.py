@@ -1,0 +1,28 @@
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["ORBX_SO"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diag", "liborbx_diag.so")  # built with -DORBX_DIAG
+import numpy as np, torch
+import __graft_entry__ as ge
+from tools import synth
+pkg = ge.load_pkg(); L = pkg.lib()
+W,H,B = 1241,376,64
+pairs=[synth.stereo_pair(1000+i,W,H)[:2] for i in range(4)]
+pitch=1280; host=np.zeros((2*B,H,pitch),np.uint8)
+for i in range(B): host[i,:,:W]=pairs[i%4][0]; host[B+i,:,:W]=pairs[i%4][1]
+imgs=torch.from_numpy(host).cuda()
+ex=pkg.ORBextractor(1000,1.2,8,20,7,device=0,max_size=(W,H),max_batch=2*B)
+cap=ex.max_keypoints(W,H)
+kps=torch.zeros((2*B,cap,7),device='cuda'); desc=torch.zeros((2*B,cap,32),dtype=torch.uint8,device='cuda'); n=torch.zeros(2*B,dtype=torch.int32,device='cuda')
+def step(): ex.extract_batch_device(imgs.data_ptr(),H*pitch,pitch,2*B,W,H,kps.data_ptr(),desc.data_ptr(),cap,n.data_ptr(),None)
+for _ in range(3): step()
+ex.sync()
+out=(C.c_ulonglong*8)()
+L.orbx_diag_fast_stamps(out,1)
+for _ in range(5): step()
+ex.sync()
+L.orbx_diag_fast_stamps(out,1)
+w=out[7]
+names=["load+zero","pretest","fullscore","nms","emit"]
+tot=sum(out[i] for i in range(5))
+print("waves",w, "avg cycles/wave", tot/w)
+for i,nm in enumerate(names): print(f"  {nm:10s} {out[i]/w:9.1f} cycles  {100*out[i]/tot:5.1f}%")
