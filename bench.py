@@ -27,7 +27,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H, NFEAT, NLEVELS = 1241, 376, 1000, 8
+W, H, NFEAT, NLEVELS = 1241, 376, 1000, 8   # headline workload; --workload may rebind W/H/NFEAT
+WORKLOADS = {
+    # name: (w, h, nfeatures, kind, default frames per step, metric string)
+    "stereo1000": (1241, 376, 1000, "stereo", 64, "frames/sec ORB extract+match, 1241x376 @1000 feats; bit-exact vs CPU"),
+    "stereo2000": (1241, 376, 2000, "stereo", 64, "frames/sec ORB extract + L/R stereo match, KITTI 1241x376 @2000 feats (BASELINE config 2)"),
+    "euroc_bow": (752, 480, 1000, "bow", 32, "frames/sec ORB extract + SearchByBoW vs 500-KF map, EuRoC 752x480 @1000 feats (BASELINE config 3)"),
+    "fhd4000": (1920, 1080, 4000, "mono", 16, "frames/sec ORB extract, 1920x1080 @4000 feats (BASELINE config 4)"),
+}
 BF, FX = 386.1448, 718.856          # reference Examples/Stereo/KITTI00-02.yaml:8,25
 MIN_Z = BF / FX                     # mb = mbf/fx (src/Frame.cc:118)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -84,10 +91,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="stereo frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (0 = the workload's default)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="stereo1000",
+                    help="stereo1000 is the BASELINE.json headline metric; the others are the remaining single-GPU configs")
     ap.add_argument("--cpu-frames", type=int, default=60, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs (tiled to the batch)")
     args = ap.parse_args()
+    global W, H, NFEAT
+    W, H, NFEAT, kind, def_batch, metric = WORKLOADS[args.workload]
+    if args.batch <= 0:
+        args.batch = def_batch
 
     import torch
     import torch.distributed as dist
@@ -106,30 +119,79 @@ def main():
 
     B = args.batch
     stream_id = st.owned_streams(rank, world)[0]      # one camera stream per GPU
-    pairs = [synth.stereo_pair(st.stream_seed(stream_id) + i, W, H)[:2] for i in range(args.distinct)]
+    seed0 = st.stream_seed(stream_id)
     pitch = (W + 63) // 64 * 64
-    host = np.zeros((2 * B, H, pitch), np.uint8)
-    for i in range(B):
-        host[i, :, :W] = pairs[i % len(pairs)][0]
-        host[B + i, :, :W] = pairs[i % len(pairs)][1]
+    stereo = kind == "stereo"
+    NI = 2 * B if stereo else B                        # images per step
+    host = np.zeros((NI, H, pitch), np.uint8)
+    if stereo:
+        pairs = [synth.stereo_pair(seed0 + i, W, H)[:2] for i in range(args.distinct)]
+        for i in range(B):
+            host[i, :, :W] = pairs[i % len(pairs)][0]
+            host[B + i, :, :W] = pairs[i % len(pairs)][1]
+    else:
+        pairs = None
+        monos = [synth.image(seed0 + i, W, H, nshapes=max(400, W * H // 311)) for i in range(args.distinct)]
+        for i in range(B):
+            host[i, :, :W] = monos[i % len(monos)]
     imgs = torch.from_numpy(host).to(dev)
 
-    ex = pkg.ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local, max_size=(W, H), max_batch=2 * B)
+    ex = pkg.ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local, max_size=(W, H), max_batch=NI)
     cap = ex.max_keypoints(W, H)
-    kps = torch.zeros((2 * B, cap, 7), dtype=torch.float32, device=dev)
-    desc = torch.zeros((2 * B, cap, 32), dtype=torch.uint8, device=dev)
-    nout = torch.zeros(2 * B, dtype=torch.int32, device=dev)
+    kps = torch.zeros((NI, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((NI, cap, 32), dtype=torch.uint8, device=dev)
+    nout = torch.zeros(NI, dtype=torch.int32, device=dev)
     ur = torch.zeros((B, cap), dtype=torch.float32, device=dev)
     dp = torch.zeros((B, cap), dtype=torch.float32, device=dev)
     stream = torch.cuda.Stream(device=dev)
     sp = stream.cuda_stream
     orbx = pkg.orbx
 
+    def extract():
+        ex.extract_batch_device(imgs.data_ptr(), H * pitch, pitch, NI, W, H, kps.data_ptr(), desc.data_ptr(), cap, nout.data_ptr(), sp)
+
+    bow = None
+    if kind == "bow":
+        # BASELINE config 3: 500-keyframe synthetic map: keyframe descriptors = frame descriptors
+        # with Bernoulli(0.08) bit flips, shuffled; hasGoodMP ~ Bernoulli(0.6); FeatureVector from a seeded
+        # two-level slice of a k=10 vocabulary (levelsup=4 of L=6; the real ORBvoc.txt is absent).
+        extract(); stream.synchronize()
+        n0 = nout.cpu().numpy()
+        rng = np.random.Generator(np.random.PCG64(seed0 + 7))
+        k_h = kps.cpu().numpy().view(np.uint8).reshape(NI, cap, 28)
+        d_h = desc.cpu().numpy()
+        frames_fs = []
+        voc = synth.Vocab2(seed0 + 9)
+        for i in range(min(B, args.distinct)):
+            kp = np.frombuffer(k_h[i, :n0[i]].tobytes(), dtype=pkg.KP_DTYPE)
+            dd = d_h[i, :n0[i]].copy()
+            if i == 0:
+                voc.seed_from(dd, rng)
+            ids, off, feat = voc.feature_vector(dd)
+            frames_fs.append(dict(desc=dd, node_id=ids, node_off=off, feat=feat, flag=np.zeros(len(dd), np.uint8), angle=kp["angle"].copy()))
+        kfs = []
+        base = frames_fs[0]
+        for _ in range(500):
+            perm = rng.permutation(len(base["desc"]))
+            dk = synth.flip_bits(rng, base["desc"], 0.08)[perm]
+            ids, off, feat = voc.feature_vector(dk)
+            kfs.append(dict(desc=dk, node_id=ids, node_off=off, feat=feat, flag=(rng.random(len(dk)) < 0.6).astype(np.uint8),
+                            angle=base["angle"][perm]))
+        bow = {"db": pkg.BowDatabase(kfs, device=local), "frames": frames_fs, "ms": 0.0, "queries": 0, "matches": 0}
+
     def step():
-        ex.extract_batch_device(imgs.data_ptr(), H * pitch, pitch, 2 * B, W, H, kps.data_ptr(), desc.data_ptr(), cap, nout.data_ptr(), sp)
-        orbx.stereo_match_batch_device(ex, 0, ex, B, B, kps.data_ptr(), desc.data_ptr(), nout.data_ptr(),
-                                       kps[B:].data_ptr(), desc[B:].data_ptr(), nout[B:].data_ptr(), cap,
-                                       BF, MIN_Z, ur.data_ptr(), dp.data_ptr(), sp)
+        extract()
+        if stereo:
+            orbx.stereo_match_batch_device(ex, 0, ex, B, B, kps.data_ptr(), desc.data_ptr(), nout.data_ptr(),
+                                           kps[B:].data_ptr(), desc[B:].data_ptr(), nout[B:].data_ptr(), cap,
+                                           BF, MIN_Z, ur.data_ptr(), dp.data_ptr(), sp)
+        elif bow is not None:
+            tq = time.perf_counter()
+            for i in range(B):                      # Tracking::Relocalization shape: one frame against every keyframe
+                m, n = bow["db"].search(bow["frames"][i % len(bow["frames"])], 0.75, True)
+                bow["matches"] += int(n.sum())
+            bow["ms"] += (time.perf_counter() - tq) * 1e3
+            bow["queries"] += B
 
     def local_sync():
         stream.synchronize()
@@ -138,6 +200,8 @@ def main():
     for _ in range(args.warmup):
         step()
     local_sync()
+    if bow is not None:
+        bow["ms"], bow["queries"], bow["matches"] = 0.0, 0, 0
     ex.profile_read(reset=True)
     ex.profile_enable(True)           # HIP events on the launch stream, around every kernel of the timed steps
     elapsed = st.timed_steps(step, args.steps, local_sync, world, device=dev)   # barrier + sync both sides, MAX over ranks
@@ -147,7 +211,7 @@ def main():
 
     n_h = nout.cpu().numpy()
     nkp_avg = float(n_h.mean())
-    matched = float((ur.cpu().numpy() >= 0).sum() / B)
+    matched = float((ur.cpu().numpy() >= 0).sum() / B) if stereo else 0.0
     value = st.aggregate_rate(B, args.steps, world, elapsed)
 
     # dominant kernel + roofline (per launch: total stage time / launches; resize = 7 launches per step)
@@ -156,24 +220,31 @@ def main():
     launches = max(prof[dom][1], 1)
     avg_ms = stage_ms[dom] / launches
     per_step_launches = launches / args.steps
-    bytes_per_launch = algorithmic_bytes(dom, 2 * B, B, nkp_avg) / per_step_launches
+    bytes_per_launch = algorithmic_bytes(dom, NI, B, nkp_avg) / per_step_launches
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in stage_ms.items()}}
 
-    out = {"metric": "frames/sec ORB extract+match, 1241x376 @1000 feats; bit-exact vs CPU", "value": round(value, 2),
+    desc_txt = {"stereo": f"KITTI-shape stereo {W}x{H}, nFeatures={NFEAT}/eye, 8 levels, FAST 20/7: "
+                          "extract(L)+extract(R)+ComputeStereoMatches; 1 frame = 1 stereo pair",
+                "mono": f"mono {W}x{H}, nFeatures={NFEAT}, 8 levels, FAST 20/7: extract only",
+                "bow": f"mono {W}x{H}, nFeatures={NFEAT}: extract + SearchByBoW(ratio 0.75, checkOri) of every frame against a "
+                       "device-resident 500-keyframe synthetic map (frame side passed as host CSR feature vectors)"}[kind]
+    out = {"metric": metric, "value": round(value, 2),
            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": {"workload": f"KITTI-shape stereo {W}x{H}, nFeatures={NFEAT}/eye, 8 levels, FAST 20/7: "
-                                  "extract(L)+extract(R)+ComputeStereoMatches; 1 frame = 1 stereo pair",
-                      "frames_per_step_per_gpu": B, "images_per_step_per_gpu": 2 * B,
+           "config": {"workload": desc_txt, "name": args.workload,
+                      "frames_per_step_per_gpu": B, "images_per_step_per_gpu": NI,
                       "keypoints_per_image": round(nkp_avg, 1), "stereo_matches_per_frame": round(matched, 1),
                       "parallelism": f"{world} independent camera-stream batches, one per GPU"},
            "roofline": roofline}
-    if rank == 0 and world == 1 and args.cpu_frames > 0:
+    if bow is not None and bow["queries"]:
+        out["config"]["bow_ms_per_query_frame_incl_host"] = round(bow["ms"] / bow["queries"], 4)
+        out["config"]["bow_matches_per_query_frame"] = round(bow["matches"] / bow["queries"], 1)
+    if rank == 0 and world == 1 and args.cpu_frames > 0 and stereo:
         out["cpu_baseline"] = cpu_baseline([pairs[i % len(pairs)] for i in range(args.cpu_frames)])
     elif rank == 0:
         out["cpu_baseline"] = None

@@ -144,6 +144,17 @@ int orbx_search_by_bow_kf_f(int device, const orbx_featset *kf, const orbx_feats
 int orbx_search_by_bow_kf_f_batch(int device, const orbx_featset *kfs, int nkf, const orbx_featset *f,
                                   float nnratio, int check_orientation, int32_t *match_f, int *nmatches);
 
+/* Device-resident keyframe set for the relocalisation / place-recognition loops
+ * (src/Tracking.cc:1661-1682 calls SearchByBoW once per candidate keyframe): the keyframes'
+ * descriptors, CSR feature vectors, flags and angles are uploaded once; each search uploads only
+ * the frame side.  match_f[nkf][f->n], nmatches[nkf] as in orbx_search_by_bow_kf_f_batch. */
+typedef struct orbx_bowdb orbx_bowdb;
+int orbx_bowdb_create(int device, const orbx_featset *kfs, int nkf, orbx_bowdb **out);
+int orbx_bowdb_search(orbx_bowdb *db, const orbx_featset *f, float nnratio, int check_orientation,
+                      int32_t *match_f, int *nmatches);
+int orbx_bowdb_size(const orbx_bowdb *db);
+void orbx_bowdb_destroy(orbx_bowdb *db);
+
 /* ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (src/ORBmatcher.cc:568-702).
  * flag != 0 <=> non-bad MapPoint (both sides).  match12[k1->n] = KF2 feature index or -1. */
 int orbx_search_by_bow_kf_kf(int device, const orbx_featset *k1, const orbx_featset *k2,

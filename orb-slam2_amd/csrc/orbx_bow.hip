@@ -10,6 +10,7 @@
 // per pair in LDS.
 #include "orbx_device.h"
 #include <string.h>
+#include <vector>
 
 struct DevFeat {
     int n, nnodes;
@@ -399,6 +400,105 @@ static int bow_run(int mode, int device, const orbx_featset *as, int na, const o
         memcpy(match + (size_t)i * stride, c->h_out + (size_t)i * stride, sizeof(int32_t) * cnt);
         nmatches[i] = c->h_out[(size_t)na * (stride > 0 ? stride : 1) + i];
     }
+    return ORBX_OK;
+}
+
+// ---- device-resident keyframe set
+struct orbx_bowdb {
+    int device, nkf, max_n;
+    uint8_t *d_blob;       // DevFeat[nkf] followed by the packed arrays
+    hipStream_t stream;
+    uint8_t *h_f; size_t h_f_cap;   // pinned staging of the frame side
+    uint8_t *d_f; size_t d_f_cap;
+    int32_t *d_out; int32_t *h_out; size_t out_cap;
+};
+
+extern "C" int orbx_bowdb_create(int device, const orbx_featset *kfs, int nkf, orbx_bowdb **out)
+{
+    if (!out || !kfs || nkf < 1) { orbx_set_error("orbx_bowdb_create: invalid argument"); return ORBX_E_INVALID; }
+    *out = nullptr;
+    size_t blob = a16(sizeof(DevFeat) * (size_t)nkf);
+    for (int i = 0; i < nkf; i++) {
+        if (!feat_validate(&kfs[i], 0)) { orbx_set_error("orbx_bowdb_create: malformed feature set %d", i); return ORBX_E_INVALID; }
+        blob += feat_bytes(&kfs[i], 0);
+    }
+    BowCtx *c;
+    int rc = bow_ctx(device, &c); // validates the device
+    if (rc) return rc;
+    orbx_bowdb *db = new orbx_bowdb();
+    memset(db, 0, sizeof *db);
+    db->device = device; db->nkf = nkf;
+    std::vector<uint8_t> h(blob);
+    hipError_t e1 = hipMalloc((void **)&db->d_blob, blob);
+    hipError_t e2 = hipStreamCreateWithFlags(&db->stream, hipStreamNonBlocking);
+    if (e1 != hipSuccess || e2 != hipSuccess) { orbx_set_error("orbx_bowdb_create: HIP allocation failed"); orbx_bowdb_destroy(db); return ORBX_E_HIP; }
+    DevFeat *hd = (DevFeat *)h.data();
+    size_t off = a16(sizeof(DevFeat) * (size_t)nkf);
+    for (int i = 0; i < nkf; i++) {
+        feat_pack(&kfs[i], 0, h.data(), db->d_blob, &off, &hd[i]);
+        if (kfs[i].n > db->max_n) db->max_n = kfs[i].n;
+    }
+    if (hipMemcpy(db->d_blob, h.data(), off, hipMemcpyHostToDevice) != hipSuccess) { orbx_set_error("upload failed"); orbx_bowdb_destroy(db); return ORBX_E_HIP; }
+    *out = db;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_bowdb_size(const orbx_bowdb *db) { return db ? db->nkf : ORBX_E_INVALID; }
+
+extern "C" void orbx_bowdb_destroy(orbx_bowdb *db)
+{
+    if (!db) return;
+    hipSetDevice(db->device);
+    if (db->stream) { hipStreamSynchronize(db->stream); hipStreamDestroy(db->stream); }
+    if (db->d_blob) hipFree(db->d_blob);
+    if (db->d_f) hipFree(db->d_f);
+    if (db->h_f) hipHostFree(db->h_f);
+    if (db->d_out) hipFree(db->d_out);
+    if (db->h_out) hipHostFree(db->h_out);
+    delete db;
+}
+
+extern "C" int orbx_bowdb_search(orbx_bowdb *db, const orbx_featset *f, float nnratio, int check_orientation,
+                                 int32_t *match_f, int *nmatches)
+{
+    if (!db || !f || !match_f || !nmatches) { orbx_set_error("orbx_bowdb_search: null argument"); return ORBX_E_INVALID; }
+    if (!feat_validate(f, 0)) { orbx_set_error("orbx_bowdb_search: malformed feature set"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipSetDevice(db->device));
+    const size_t fb = a16(sizeof(DevFeat)) + feat_bytes(f, 0);
+    if (fb > db->h_f_cap) {
+        if (db->h_f) ORBX_HIP(hipHostFree(db->h_f));
+        if (db->d_f) ORBX_HIP(hipFree(db->d_f));
+        db->h_f = nullptr; db->d_f = nullptr;
+        ORBX_HIP(hipHostMalloc((void **)&db->h_f, fb * 2, hipHostMallocDefault));
+        ORBX_HIP(hipMalloc((void **)&db->d_f, fb * 2));
+        db->h_f_cap = db->d_f_cap = fb * 2;
+    }
+    const int stride = f->n > 0 ? f->n : 1;
+    const size_t out_ints = (size_t)db->nkf * stride + db->nkf;
+    if (out_ints > db->out_cap) {
+        if (db->d_out) ORBX_HIP(hipFree(db->d_out));
+        if (db->h_out) ORBX_HIP(hipHostFree(db->h_out));
+        db->d_out = nullptr; db->h_out = nullptr;
+        ORBX_HIP(hipMalloc((void **)&db->d_out, out_ints * 2 * sizeof(int32_t)));
+        ORBX_HIP(hipHostMalloc((void **)&db->h_out, out_ints * 2 * sizeof(int32_t), hipHostMallocDefault));
+        db->out_cap = out_ints * 2;
+    }
+    DevFeat *hd = (DevFeat *)db->h_f;
+    size_t off = a16(sizeof(DevFeat));
+    feat_pack(f, 0, db->h_f, db->d_f, &off, hd);
+    ORBX_HIP(hipMemcpyAsync(db->d_f, db->h_f, off, hipMemcpyHostToDevice, db->stream));
+    const size_t lds = (size_t)((f->n + 15) & ~15) * 2 + 16;
+    if (lds > 150 * 1024) { orbx_set_error("feature set too large for LDS"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int32_t *d_match = db->d_out;
+    int *d_n = db->d_out + (size_t)db->nkf * stride;
+    hipLaunchKernelGGL(k_bow<0>, dim3(db->nkf), dim3(256), lds, db->stream, (const DevFeat *)db->d_blob, (const DevFeat *)db->d_f, 1,
+                       nnratio, check_orientation, d_match, f->n, d_n);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(db->h_out, db->d_out, out_ints * sizeof(int32_t), hipMemcpyDeviceToHost, db->stream));
+    ORBX_HIP(hipStreamSynchronize(db->stream));
+    if (f->n) memcpy(match_f, db->h_out, sizeof(int32_t) * (size_t)db->nkf * f->n);
+    memcpy(nmatches, db->h_out + (size_t)db->nkf * stride, sizeof(int) * db->nkf);
     return ORBX_OK;
 }
 

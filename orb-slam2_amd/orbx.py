@@ -66,6 +66,11 @@ def lib():
     L.orbx_search_by_bow_kf_f_batch.argtypes = [i, FS, i, FS, f, i, vp, vp]
     L.orbx_search_by_bow_kf_kf.argtypes = [i, FS, FS, f, i, vp, ip]
     L.orbx_search_for_triangulation.argtypes = [i, FS, FS, vp, f, f, vp, vp, i, i, i, vp, i, ip]
+    L.orbx_bowdb_create.argtypes = [i, FS, i, C.POINTER(vp)]
+    L.orbx_bowdb_search.argtypes = [vp, FS, f, i, vp, vp]
+    L.orbx_bowdb_size.argtypes = [vp]
+    L.orbx_bowdb_destroy.argtypes = [vp]
+    L.orbx_bowdb_destroy.restype = None
     L.orbx_profile_enable.argtypes = [vp, i]
     L.orbx_profile_read.argtypes = [vp, vp, vp, i]
     L.orbx_debug_candidates.argtypes = [vp, i, i, vp, vp, vp, i, ip]
@@ -232,6 +237,30 @@ def ComputeStereoMatches(extractorLeft, extractorRight, mvKeys, mDescriptors, mv
 def stereo_match_batch_device(L, imgL0, R, imgR0, batch, d_kL, d_dL, d_nL, d_kR, d_dR, d_nR, cap, bf, min_z, d_ur, d_depth, stream=None):
     _check(lib().orbx_stereo_match_batch_device(L._h, imgL0, R._h, imgR0, batch, d_kL, d_dL, d_nL, d_kR, d_dR, d_nR, cap,
                                                 bf, min_z, d_ur, d_depth, stream))
+
+
+class BowDatabase:
+    """Device-resident keyframe set (include/orbx.h: orbx_bowdb_*): upload once, search many frames."""
+
+    def __init__(self, keyframes, device=0):
+        self._L = lib()
+        sets = [make_featset(k) for k in keyframes]
+        arr = (FeatSet * len(sets))(*[s_[0] for s_ in sets])
+        self._h = C.c_void_p()
+        _check(self._L.orbx_bowdb_create(device, arr, len(sets), C.byref(self._h)))
+        self.nkf = len(sets)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.orbx_bowdb_destroy(h)
+            self._h = None
+
+    def search(self, F, nnratio=0.75, checkOri=True):
+        b, kb = make_featset(F)
+        out = np.full((self.nkf, b.n), -1, np.int32); n = np.zeros(self.nkf, np.int32)
+        _check(self._L.orbx_bowdb_search(self._h, C.byref(b), nnratio, int(checkOri), _p(out), _p(n)))
+        return out, n
 
 
 class ORBmatcher:

@@ -245,6 +245,17 @@ def test_search_by_bow_kf_f(pkg, oracle, ratio, ori):
         assert n[i] == en and (got[i] == exp).all()
 
 
+def test_bow_database(pkg, oracle):
+    """device-resident keyframe set: same answers as one call per keyframe, for several query frames"""
+    frame, kfs, _ = _bow_sets(pkg, oracle, 85, n_kf=7)
+    db = pkg.BowDatabase(kfs)
+    for q, ratio in ((frame, 0.75), (kfs[3], 0.7)):
+        got, n = db.search(q, ratio, True)
+        for i, kf in enumerate(kfs):
+            exp, en = oracle.search_by_bow_kf_f(kf, q, ratio, True)
+            assert n[i] == en and (got[i] == exp).all(), i
+
+
 def test_search_by_bow_kf_kf(pkg, oracle):
     frame, kfs, _ = _bow_sets(pkg, oracle, 82)
     m = pkg.ORBmatcher(0.75, True)
