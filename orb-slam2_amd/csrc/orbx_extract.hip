@@ -382,8 +382,9 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
     int *cnt_n = cnt + cap;
     uint2 *box = reinterpret_cast<uint2 *>(cnt_n + cap);
     uint2 *box_n = box + cap;
-    int *cc = reinterpret_cast<int *>(box_n + cap); // [4*cap] child counts, then child positions
-    int *a1 = cc + 4 * cap;                         // processing rank of split nodes
+    int *cc = reinterpret_cast<int *>(box_n + cap); // [4*cap] child counts, then child positions (16-byte aligned)
+    int *cc_n = cc + 4 * cap;                       // the next table's child counts
+    int *a1 = cc_n + 4 * cap;                       // processing rank of split nodes
     int *a2 = a1 + cap;                             // children per processed node -> S offsets
     int *a3 = a2 + cap;                             // unsplit flags -> ranks
     int *a4 = a3 + cap;                             // phase-2 gains
@@ -411,13 +412,12 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
         pts = g_pts + (long long)b * g->cand_total + L.cand_off;
         nid = g_nid + (long long)b * g->cand_total + L.cand_off;
     }
-    {
+    {   // one thread per cell: the copies of different cells are independent loads in flight together
         const uint32_t *src = cand + (long long)b * g->cand_total + L.cand_off;
-        const int lane = tid & 63, wv = tid >> 6;
-        for (int c = wv; c < L.n_cells; c += 4) {
+        for (int c = tid; c < L.n_cells; c += 256) {
             const int beg = cellpref[c], end = c + 1 < L.n_cells ? cellpref[c + 1] : n;
             const uint32_t *s = src + (long long)c * L.cand_cap;
-            for (int e = lane; e < end - beg; e += 64) pts[beg + e] = s[e];
+            for (int e = 0; e < end - beg; e++) pts[beg + e] = s[e];
         }
     }
     // ---- roots (src/ORBextractor.cc:627-705)
@@ -444,41 +444,49 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
     for (int i = tid; i < n; i += 256) nid[i] = (uint16_t)a1[nid[i]];
     __syncthreads();
 
-    // ---- sweeps
+    // ---- sweeps.  Invariant at the top of the loop: cc[0..4m) holds the child counts of the current
+    // table (cnt/box) and every point label is (node id | child << NB).
+    auto classify = [&](int id, uint32_t p, const int *cn, const uint2 *bx_tab, int *cct) -> int {
+        int c = 0;
+        if (cn[id] > 1) {
+            const uint2 bx = bx_tab[id];
+            const int x0 = bx.x & 0xFFFF, x1 = bx.x >> 16, y0 = bx.y & 0xFFFF, y1 = bx.y >> 16;
+            const int x = p & 0xFFF, y = (p >> 12) & 0xFFF;
+            const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1; // ceil(d/2), DivideNode :553-554
+            c = (x >= x0 + hx ? 1 : 0) + (y >= y0 + hy ? 2 : 0);
+            atomicAdd(&cct[id * 4 + c], 1);
+        }
+        return c;
+    };
+    for (int k = tid; k < 4 * m; k += 256) cc[k] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int id = nid[i];
+        nid[i] = (uint16_t)(id | (classify(id, pts[i], cnt, box, cc) << NB));
+    }
     bool phase2 = false;
     for (;;) {
         const int prev = m;
-        for (int k = tid; k < 4 * m; k += 256) cc[k] = 0;
-        if (tid == 0) s_acc = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += 256) { // classify the points of every splittable node
-            const int id = nid[i] & NMASK;
-            int c = 0;
-            if (cnt[id] > 1) {
-                const uint2 bx = box[id];
-                const int x0 = bx.x & 0xFFFF, x1 = bx.x >> 16, y0 = bx.y & 0xFFFF, y1 = bx.y >> 16;
-                const uint32_t p = pts[i];
-                const int x = p & 0xFFF, y = (p >> 12) & 0xFFF;
-                const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1; // ceil(d/2), DivideNode :553-554
-                c = (x >= x0 + hx ? 1 : 0) + (y >= y0 + hy ? 2 : 0);
-                atomicAdd(&cc[id * 4 + c], 1);
-            }
-            nid[i] = (uint16_t)(id | (c << NB));
-        }
-        __syncthreads();
-        int nsplit;
+        int nsplit = 0, S, U;
         if (!phase2) {
+            // processing order == list order: one packed scan gives both the children offset of every split
+            // node (low 16 bits) and the rank of every unsplit node (high 16 bits)
             for (int k = tid; k < m; k += 256) {
-                const int s = cnt[k] > 1;
-                ncarr[k] = s ? (cc[4 * k] > 0) + (cc[4 * k + 1] > 0) + (cc[4 * k + 2] > 0) + (cc[4 * k + 3] > 0) : 0;
-                a1[k] = s;
-                a3[k] = !s;
+                const int sp = cnt[k] > 1;
+                const int ncv = sp ? (cc[4 * k] > 0) + (cc[4 * k + 1] > 0) + (cc[4 * k + 2] > 0) + (cc[4 * k + 3] > 0) : 0;
+                ncarr[k] = ncv;
+                a2[k] = sp ? ncv : (1 << 16);
             }
+            if (tid == 0) s_acc = 0;
             __syncthreads();
-            nsplit = lds_excl_scan(a1, m, s_w);
+            const int tot = lds_excl_scan(a2, m, s_w);
+            S = tot & 0xFFFF; U = tot >> 16;
         } else {
             // processing order: count desc, list position asc (src/ORBextractor.cc:832-834 with the
             // address tie-break defined as "created later first" == nearer the list front)
+            if (tid == 0) s_acc = 0;
+            __syncthreads();
             int ncand_local = 0;
             for (int k = tid; k < m; k += 256) {
                 const int ck = cnt[k];
@@ -510,29 +518,30 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
             nsplit = min(ncand, s_acc + 1);
             __syncthreads();
             for (int k = tid; k < m; k += 256) {
-                const bool s = a1[k] >= 0 && a1[k] < nsplit;
-                if (!s) ncarr[k] = 0;
-                a3[k] = !s;
+                const bool sp = a1[k] >= 0 && a1[k] < nsplit;
+                if (!sp) ncarr[k] = 0;
+                a3[k] = !sp;
             }
             if (tid == 0) s_acc = 0;
             __syncthreads();
+            for (int k = tid; k < m; k += 256)
+                if (ncarr[k] > 0) a2[a1[k]] = ncarr[k];
+            __syncthreads();
+            S = lds_excl_scan(a2, nsplit, s_w);
+            U = lds_excl_scan(a3, m, s_w);
         }
-        for (int k = tid; k < m; k += 256)
-            if (ncarr[k] > 0) a2[a1[k]] = ncarr[k];
-        __syncthreads();
-        const int S = lds_excl_scan(a2, nsplit, s_w);
-        const int U = lds_excl_scan(a3, m, s_w);
         if (S + U > cap) { // cannot happen (SURVEY.md A.4 bound); never write out of bounds
             if (tid == 0) { atomicExch(err_flag, 1); *out_cnt = 0; }
             return;
         }
+        // ---- apply: build the next table, turn cc into child positions, zero the next table's counters
         int expand_local = 0;
         for (int k = tid; k < m; k += 256) {
             if (ncarr[k] > 0) {
                 const uint2 bx = box[k];
                 const int x0 = bx.x & 0xFFFF, x1 = bx.x >> 16, y0 = bx.y & 0xFFFF, y1 = bx.y >> 16;
                 const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
-                int pos = S - 1 - a2[a1[k]];
+                int pos = S - 1 - (phase2 ? a2[a1[k]] : (a2[k] & 0xFFFF));
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const int q = cc[4 * k + c];
@@ -541,31 +550,43 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
                         const unsigned cy0 = (c & 2) ? y0 + hy : y0, cy1 = (c & 2) ? y1 : y0 + hy;
                         box_n[pos] = make_uint2(cx0 | (cx1 << 16), cy0 | (cy1 << 16));
                         cnt_n[pos] = q;
+                        reinterpret_cast<int4 *>(cc_n)[pos] = make_int4(0, 0, 0, 0);
                         expand_local += q > 1;
                         cc[4 * k + c] = pos;
                         pos--;
                     }
                 }
             } else {
-                const int pos = S + a3[k];
+                const int pos = S + (phase2 ? a3[k] : (a2[k] >> 16));
                 box_n[pos] = box[k];
                 cnt_n[pos] = cnt[k];
+                reinterpret_cast<int4 *>(cc_n)[pos] = make_int4(0, 0, 0, 0);
                 cc[4 * k] = cc[4 * k + 1] = cc[4 * k + 2] = cc[4 * k + 3] = pos;
             }
         }
         if (expand_local) atomicAdd(&s_acc, expand_local);
         __syncthreads();
+        m = S + U;
+        const int n_to_expand = s_acc;
+        const bool done = m >= N || m == prev;                     // :803-806, :883-884
+        if (!phase2 && !done && m + 3 * n_to_expand > N) phase2 = true; // :814
+        if (done) {
+            for (int i = tid; i < n; i += 256) {
+                const int v = nid[i];
+                nid[i] = (uint16_t)cc[(v & NMASK) * 4 + (v >> NB)];
+            }
+            __syncthreads();
+            break;
+        }
+        // ---- relabel fused with the next sweep's classification (one pass over the points)
         for (int i = tid; i < n; i += 256) {
             const int v = nid[i];
-            nid[i] = (uint16_t)cc[(v & NMASK) * 4 + (v >> NB)];
+            const int id = cc[(v & NMASK) * 4 + (v >> NB)];
+            nid[i] = (uint16_t)(id | (classify(id, pts[i], cnt_n, box_n, cc_n) << NB));
         }
-        m = S + U;
         { int *t = cnt; cnt = cnt_n; cnt_n = t; }
         { uint2 *t = box; box = box_n; box_n = t; }
-        const int n_to_expand = s_acc;
-        __syncthreads();
-        if (m >= N || m == prev) break;                          // :803-806, :883-884
-        if (!phase2 && m + 3 * n_to_expand > N) phase2 = true;   // :814
+        { int *t = cc; cc = cc_n; cc_n = t; }
     }
 
     // ---- one keypoint per leaf: max response, first in list order wins ties (:895-912)
@@ -744,7 +765,7 @@ static int ensure(T **p, size_t *cap, size_t need)
 static size_t tree_lds_bytes(const Geom &G, int lds_pts_cap)
 {
     const size_t cap = G.max_node_cap;
-    return cap * (4 + 4 + 8 + 8 + 16 + 4 * 5) + (size_t)((G.max_cells_level + 4) & ~3) * 4 + (size_t)lds_pts_cap * 6 + 64;
+    return cap * (4 + 4 + 8 + 8 + 16 + 16 + 4 * 5) + (size_t)((G.max_cells_level + 4) & ~3) * 4 + (size_t)lds_pts_cap * 6 + 64;
 }
 // LDS point capacity of k_tree: enough for a level's typical candidate count (P_0/96), bounded so that
 // several (level, image) workgroups fit one CU; levels with more candidates use the HBM scratch.
