@@ -127,18 +127,35 @@ __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrR
             const int dy1 = e1 / 11 - 5, dx1 = e1 % 11 - 5;
             const int il0 = lvl_px(imL, pl, LV.w, LV.h, cxl + dx0, cy + dy0) - lc;
             const int il1 = e1 < 121 ? lvl_px(imL, pl, LV.w, LV.h, cxl + dx1, cy + dy1) - lc : 0;
-            int best_sad = 0x7FFFFFFF, best_inc = 0;
-            int dists[11];
+            // all right-image loads first (independent, in flight together): the 11 shifts of window pixel
+            // (dx,dy) are the 11 consecutive columns sur0+dx-5 .. sur0+dx+5 of row cy+dy
+            const int cx0 = (int)sur0;
+            int r0[11], r1[11];
 #pragma unroll
-            for (int inc = -5; inc <= 5; inc++) {
-                const int cxr = (int)(sur0 + (float)inc);
-                const int rc = lvl_px(imR, prr, LV.w, LV.h, cxr, cy);
-                int s = abs(il0 - (lvl_px(imR, prr, LV.w, LV.h, cxr + dx0, cy + dy0) - rc));
-                if (e1 < 121) s += abs(il1 - (lvl_px(imR, prr, LV.w, LV.h, cxr + dx1, cy + dy1) - rc));
-                s = wave_sum(s);
-                dists[inc + 5] = s;
-                if (s < best_sad) { best_sad = s; best_inc = inc; }
+            for (int k = 0; k < 11; k++) {
+                r0[k] = lvl_px(imR, prr, LV.w, LV.h, cx0 + dx0 + k - 5, cy + dy0);
+                r1[k] = e1 < 121 ? lvl_px(imR, prr, LV.w, LV.h, cx0 + dx1 + k - 5, cy + dy1) : 0;
             }
+            int dists[11];
+            // lane 60 is the window centre (dy = 0, dx = 0): its r0[k] is the centre pixel of shift k
+#pragma unroll
+            for (int k = 0; k < 11; k += 2) {
+                const int c_a = __shfl(r0[k], 60, WAVE);
+                int sa = abs(il0 - (r0[k] - c_a)) + (e1 < 121 ? abs(il1 - (r1[k] - c_a)) : 0);
+                if (k + 1 < 11) { // two shifts per reduction: each total is <= 121*510 < 2^16
+                    const int c_b = __shfl(r0[k + 1], 60, WAVE);
+                    const int sb = abs(il0 - (r0[k + 1] - c_b)) + (e1 < 121 ? abs(il1 - (r1[k + 1] - c_b)) : 0);
+                    const unsigned tot = (unsigned)wave_sum(sa | (sb << 16));
+                    dists[k] = (int)(tot & 0xFFFFu);
+                    dists[k + 1] = (int)(tot >> 16);
+                } else {
+                    dists[k] = wave_sum(sa);
+                }
+            }
+            int best_sad = 0x7FFFFFFF, best_inc = 0;
+#pragma unroll
+            for (int k = 0; k < 11; k++)
+                if (dists[k] < best_sad) { best_sad = dists[k]; best_inc = k - 5; }
             if (!(best_inc == -5 || best_inc == 5)) {
                 float d1 = 0, d2 = 0, d3 = 0;
 #pragma unroll
