@@ -36,28 +36,53 @@ extern "C" int orbx_hamming(const uint8_t *a, const uint8_t *b)
     return d;
 }
 
-// ---- per-launch HIP-event timing on the launch stream (bench.py's roofline leg)
+// ---- per-launch HIP-event timing on the launch stream (bench.py's roofline leg).
+// Event records are not free (each is a barrier packet on the queue), so back-to-back launches on one
+// stream share the boundary event: the end event of launch i is the begin event of launch i+1.  A
+// launch's time therefore runs from the completion of its predecessor to its own completion.
+
+static hipEvent_t prof_new_event(orbx_extractor *e)
+{
+    hipEvent_t ev = nullptr;
+    if (!e->prof_pool.empty()) { ev = e->prof_pool.back(); e->prof_pool.pop_back(); return ev; }
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return ev;
+}
 
 void orbx_prof_begin(orbx_extractor *e, int stage, hipStream_t s)
 {
     if (!e->prof) return;
     ProfEvent ev;
     ev.stage = stage;
-    if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
-    hipEventRecord(ev.a, s);
+    ev.b = nullptr;
+    if (!e->prof_ev.empty() && e->prof_ev.back().b && e->prof_last_stream == s && e->prof_chain) {
+        ev.a = e->prof_ev.back().b; // shared boundary
+        ev.owns_a = false;
+    } else {
+        ev.a = prof_new_event(e);
+        if (!ev.a) return;
+        ev.owns_a = true;
+        hipEventRecord(ev.a, s);
+    }
     e->prof_ev.push_back(ev);
 }
 
 void orbx_prof_end(orbx_extractor *e, hipStream_t s)
 {
-    if (!e->prof || e->prof_ev.empty()) return;
-    hipEventRecord(e->prof_ev.back().b, s);
+    if (!e->prof || e->prof_ev.empty() || e->prof_ev.back().b) return;
+    hipEvent_t b = prof_new_event(e);
+    if (!b) return;
+    hipEventRecord(b, s);
+    e->prof_ev.back().b = b;
+    e->prof_last_stream = s;
+    e->prof_chain = true;
 }
 
 extern "C" int orbx_profile_enable(orbx_extractor *e, int enable)
 {
     if (!e) { orbx_set_error("null extractor"); return ORBX_E_INVALID; }
     e->prof = enable != 0;
+    e->prof_chain = false;
     return ORBX_OK;
 }
 
@@ -68,11 +93,14 @@ extern "C" int orbx_profile_read(orbx_extractor *e, float *ms, int *launches, in
     ORBX_HIP(hipDeviceSynchronize());
     for (auto &ev : e->prof_ev) {
         float t = 0;
-        if (hipEventElapsedTime(&t, ev.a, ev.b) == hipSuccess) { e->prof_ms[ev.stage] += t; e->prof_n[ev.stage]++; }
-        hipEventDestroy(ev.a);
-        hipEventDestroy(ev.b);
+        if (ev.a && ev.b && hipEventElapsedTime(&t, ev.a, ev.b) == hipSuccess) { e->prof_ms[ev.stage] += t; e->prof_n[ev.stage]++; }
+    }
+    for (auto &ev : e->prof_ev) { // events go back to the pool (a shared boundary is owned by the earlier launch as its b)
+        if (ev.owns_a && ev.a) e->prof_pool.push_back(ev.a);
+        if (ev.b) e->prof_pool.push_back(ev.b);
     }
     e->prof_ev.clear();
+    e->prof_chain = false;
     for (int i = 0; i < ORBX_STAGE_COUNT; i++) {
         if (ms) ms[i] = e->prof_ms[i];
         if (launches) launches[i] = e->prof_n[i];

@@ -986,7 +986,8 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *e)
     if (!e) return;
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
-    for (auto &ev : e->prof_ev) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+    for (auto &ev : e->prof_ev) { if (ev.owns_a && ev.a) hipEventDestroy(ev.a); if (ev.b) hipEventDestroy(ev.b); }
+    for (auto ev : e->prof_pool) hipEventDestroy(ev);
     void *ptrs[] = { e->d_cells, e->d_geom, e->d_tabs, e->d_pyr, e->d_stage_in, e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid,
                      e->d_lvl_cnt, e->d_lvl_kp, e->d_out_kps, e->d_out_desc, e->d_out_n, e->d_out_ur, e->d_out_depth, e->d_st_dist, e->d_st_entries };
     for (void *p : ptrs) if (p) hipFree(p);
@@ -1128,6 +1129,7 @@ extern "C" int orbx_extract_batch(orbx_extractor *e, const uint8_t *const *imgs,
         if (!imgs[i]) { orbx_set_error("imgs[%d] is NULL", i); return ORBX_E_INVALID; }
         ORBX_HIP(hipMemcpy2DAsync(e->d_stage_in + img_bytes * i, pitch, imgs[i], stride, w, h, hipMemcpyHostToDevice, e->stream));
     }
+    e->prof_chain = false; // the copies above are not part of the first launch
     rc = orbx_extract_batch_device(e, e->d_stage_in, img_bytes, pitch, batch, w, h, e->d_out_kps, e->d_out_desc, need, e->d_out_n, nullptr);
     if (rc) return rc;
     ORBX_HIP(hipMemcpyAsync(n_out, e->d_out_n, sizeof(int) * batch, hipMemcpyDeviceToHost, e->stream));

@@ -57,7 +57,7 @@ struct CellRec {
 };
 static_assert(sizeof(CellRec) == 40, "CellRec layout");
 
-struct ProfEvent { hipEvent_t a, b; int stage; };
+struct ProfEvent { hipEvent_t a, b; int stage; bool owns_a; };
 
 struct orbx_extractor {
     int device;
@@ -92,7 +92,8 @@ struct orbx_extractor {
     // state of the most recent extract
     const uint8_t *last_img0; size_t last_img_stride, last_pitch; int last_batch;
     // profiling
-    bool prof; std::vector<ProfEvent> prof_ev; float prof_ms[ORBX_STAGE_COUNT]; int prof_n[ORBX_STAGE_COUNT];
+    bool prof, prof_chain; hipStream_t prof_last_stream; std::vector<ProfEvent> prof_ev; std::vector<hipEvent_t> prof_pool;
+    float prof_ms[ORBX_STAGE_COUNT]; int prof_n[ORBX_STAGE_COUNT];
 };
 
 void orbx_set_error(const char *fmt, ...);

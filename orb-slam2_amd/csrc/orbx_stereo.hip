@@ -332,9 +332,8 @@ extern "C" int orbx_stereo_match(orbx_extractor *L, orbx_extractor *R,
         ORBX_HIP(hipMemcpyAsync(bdR, dR, 32 * (size_t)nR, hipMemcpyHostToDevice, s));
     }
     ORBX_HIP(hipMemcpyAsync(bn, counts, sizeof counts, hipMemcpyHostToDevice, s));
-    const int save_l = L->last_batch, save_r = R->last_batch;
+    L->prof_chain = false;
     rc = orbx_stereo_match_batch_device(L, 0, R, 0, 1, bkL, bdL, bn, bkR, bdR, (int *)bn + 1, cap, bf, min_z, bu, bz, s);
-    (void)save_l; (void)save_r;
     if (rc) return rc;
     ORBX_HIP(hipMemcpyAsync(u_right, bu, 4 * (size_t)nL, hipMemcpyDeviceToHost, s));
     ORBX_HIP(hipMemcpyAsync(depth, bz, 4 * (size_t)nL, hipMemcpyDeviceToHost, s));
