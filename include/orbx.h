@@ -171,6 +171,33 @@ int orbx_search_for_triangulation(int device, const orbx_featset *k1, const orbx
                                   const float *scale_factors2, const float *level_sigma2_2, int nlevels2,
                                   int only_stereo, int check_orientation, int32_t *pairs, int cap, int *npairs);
 
+/* ---- Frame::ComputeBoW (src/Frame.cc:459-466) --------------------------- */
+
+/* DBoW2 vocabulary tree resident in HBM.  Arrays describe nodes 1..N in id order exactly as
+ * TemplatedVocabulary::loadFromTextFile builds them (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:
+ * 1358-1445): parent id (0 = root), leaf flag, 32-byte descriptor, weight; children are attached
+ * to their parent in id order and word ids are given to leaves in id order.  k <= 20, L <= 10 as
+ * in the reference loader.  Only TF_IDF weighting with L1_NORM scoring (ORBvoc.txt) is supported. */
+typedef struct orbx_vocab orbx_vocab;
+int orbx_vocab_create(int device, int k, int L, int nnodes_minus_root, const int32_t *parent, const uint8_t *is_leaf,
+                      const uint8_t *desc, const double *weight, orbx_vocab **out);
+/* reads the ORBvoc.txt text format: header "k L scoring weighting", then one line per node
+ * "parent isLeaf d0 .. d31 weight" */
+int orbx_vocab_load_text(int device, const char *path, orbx_vocab **out);
+int orbx_vocab_info(const orbx_vocab *v, int *k, int *L, int *nnodes, int *nwords);
+void orbx_vocab_destroy(orbx_vocab *v);
+
+/* TemplatedVocabulary::transform(features, BowVector, FeatureVector, levelsup) (:1127-1194, :1218-1259).
+ * desc[n][32] (n <= 8192).  Per-feature outputs (may be NULL): word id, word weight (0 = stopped word:
+ * the feature is in neither vector), node id at tree level L - levelsup.  BowVector: bow_id/bow_val[*nbow],
+ * ascending word ids, values L1-normalised, bit-exact doubles (weights added in feature order, norm in
+ * word order as std::map iteration gives).  FeatureVector as CSR ready for orbx_featset:
+ * fv_node_id[*fv_nnodes], fv_node_off[*fv_nnodes + 1], fv_feat[].  Capacities: n (n + 1 for fv_node_off). */
+int orbx_bow_transform(orbx_vocab *v, const uint8_t *desc, int n, int levelsup,
+                       uint32_t *word_id, double *word_weight, uint32_t *node_id,
+                       uint32_t *bow_id, double *bow_val, int *nbow,
+                       uint32_t *fv_node_id, int32_t *fv_node_off, uint32_t *fv_feat, int *fv_nnodes);
+
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------- */
 
 enum { ORBX_STAGE_RESIZE = 0, ORBX_STAGE_FAST = 1, ORBX_STAGE_TREE = 2, ORBX_STAGE_DESC = 3,

@@ -70,6 +70,14 @@ def lib():
         L.oracle_search_by_bow_kf_kf.argtypes = [C.POINTER(FeatSet), C.POINTER(FeatSet), C.c_float, C.c_int, C.c_void_p]
         L.oracle_search_for_triangulation.argtypes = [C.POINTER(FeatSet), C.POINTER(FeatSet), C.c_void_p, C.c_float, C.c_float,
                                                       C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_vocab_create.restype = C.c_void_p
+        L.oracle_vocab_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_vocab_load_text.restype = C.c_void_p
+        L.oracle_vocab_load_text.argtypes = [C.c_char_p]
+        L.oracle_vocab_destroy.argtypes = [C.c_void_p]
+        L.oracle_vocab_nodes.argtypes = [C.c_void_p]
+        L.oracle_vocab_words.argtypes = [C.c_void_p]
+        L.oracle_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.POINTER(C.c_int)] + [C.c_void_p] * 3 + [C.POINTER(C.c_int)]
         L.oracle_three_maxima.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _lib = L
     return _lib
@@ -190,3 +198,36 @@ def search_for_triangulation(k1, k2, F12, ex, ey, sf2, sig2, nnratio, check_ori,
     n = lib().oracle_search_for_triangulation(C.byref(a), C.byref(b), _p(F), ex, ey, _p(sf2), _p(sig2),
                                               nnratio, int(check_ori), int(only_stereo), _p(pairs), a.n)
     return pairs[:n].copy()
+
+
+class Vocabulary:
+    """DBoW2 vocabulary tree of the CPU oracle (TF_IDF weights, L1 norm)"""
+
+    def __init__(self, k=None, L=None, parent=None, is_leaf=None, desc=None, weight=None, path=None):
+        self.lib = lib()
+        if path is not None:
+            self.h = self.lib.oracle_vocab_load_text(path.encode())
+        else:
+            parent = np.ascontiguousarray(parent, np.int32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+            desc = np.ascontiguousarray(desc, np.uint8); weight = np.ascontiguousarray(weight, np.float64)
+            self.h = self.lib.oracle_vocab_create(k, L, len(parent), _p(parent), _p(is_leaf), _p(desc), _p(weight))
+        if not self.h:
+            raise ValueError("vocabulary rejected")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.oracle_vocab_destroy(self.h); self.h = None
+
+    def nodes(self): return self.lib.oracle_vocab_nodes(self.h)
+    def words(self): return self.lib.oracle_vocab_words(self.h)
+
+    def transform(self, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, np.uint8); n = len(desc)
+        wid = np.zeros(n, np.uint32); ww = np.zeros(n, np.float64); nid = np.zeros(n, np.uint32)
+        bid = np.zeros(n, np.uint32); bval = np.zeros(n, np.float64); nb = C.c_int()
+        fid = np.zeros(n, np.uint32); foff = np.zeros(n + 1, np.int32); ffeat = np.zeros(n, np.uint32); fn = C.c_int()
+        rc = self.lib.oracle_bow_transform(self.h, _p(desc), n, levelsup, _p(wid), _p(ww), _p(nid), _p(bid), _p(bval), C.byref(nb),
+                                           _p(fid), _p(foff), _p(ffeat), C.byref(fn))
+        assert rc == 0
+        return dict(word_id=wid, word_weight=ww, node_id=nid, bow_id=bid[:nb.value].copy(), bow_val=bval[:nb.value].copy(),
+                    fv_node_id=fid[:fn.value].copy(), fv_node_off=foff[:fn.value + 1].copy(), fv_feat=ffeat[:foff[fn.value]].copy())

@@ -14,6 +14,7 @@
 #include <float.h>
 #include <limits.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -996,4 +997,158 @@ int oracle_search_for_triangulation(const oracle_featset *k1, const oracle_feats
     }
     free(m12);
     return np;
+}
+
+/* ------------------------------------------------------------------ DBoW2 vocabulary + transform (f2) */
+
+struct oracle_vocab {
+    int k, L, nnodes, nwords;  /* nnodes includes the root */
+    int *parent, *child_off, *child_ids, *word_id;
+    uint8_t *desc;             /* [nnodes][32]; root's is zero */
+    double *weight;
+};
+
+static oracle_vocab *vocab_finish(oracle_vocab *v, const uint8_t *is_leaf)
+{
+    /* children lists in id order (loadFromTextFile pushes nid onto m_nodes[pid].children as it reads) */
+    int n = v->nnodes;
+    v->child_off = calloc(n + 1, sizeof(int));
+    v->child_ids = malloc(sizeof(int) * (n > 1 ? n - 1 : 1));
+    v->word_id = malloc(sizeof(int) * n);
+    for (int i = 1; i < n; i++) {
+        if (v->parent[i] < 0 || v->parent[i] >= i) { oracle_vocab_destroy(v); return NULL; } /* parents precede children */
+        v->child_off[v->parent[i] + 1]++;
+    }
+    for (int i = 0; i < n; i++) v->child_off[i + 1] += v->child_off[i];
+    int *cur = malloc(sizeof(int) * n);
+    memcpy(cur, v->child_off, sizeof(int) * n);
+    for (int i = 1; i < n; i++) v->child_ids[cur[v->parent[i]]++] = i;
+    free(cur);
+    v->nwords = 0;
+    v->word_id[0] = -1;
+    for (int i = 1; i < n; i++) v->word_id[i] = is_leaf[i - 1] ? v->nwords++ : -1; /* :1425-1432 */
+    return v;
+}
+
+oracle_vocab *oracle_vocab_create(int k, int L, int nm1, const int32_t *parent, const uint8_t *is_leaf,
+                                  const uint8_t *desc, const double *weight)
+{
+    if (k < 0 || k > 20 || L < 1 || L > 10 || nm1 < 1) return NULL; /* loader limits :1379 */
+    oracle_vocab *v = calloc(1, sizeof *v);
+    v->k = k; v->L = L; v->nnodes = nm1 + 1;
+    v->parent = malloc(sizeof(int) * v->nnodes);
+    v->desc = calloc((size_t)v->nnodes, 32);
+    v->weight = calloc(v->nnodes, sizeof(double));
+    v->parent[0] = -1;
+    for (int i = 0; i < nm1; i++) { v->parent[i + 1] = parent[i]; v->weight[i + 1] = weight[i]; }
+    memcpy(v->desc + 32, desc, (size_t)nm1 * 32);
+    return vocab_finish(v, is_leaf);
+}
+
+/* text format of loadFromTextFile: header "k L scoring weighting", then per node "parent isLeaf d0 .. d31 weight" */
+oracle_vocab *oracle_vocab_load_text(const char *path)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return NULL;
+    int k, L, n1, n2;
+    if (fscanf(f, "%d %d %d %d", &k, &L, &n1, &n2) != 4 || k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) { fclose(f); return NULL; }
+    int cap = 1024, n = 0;
+    int32_t *parent = malloc(sizeof(int32_t) * cap);
+    uint8_t *leaf = malloc(cap), *desc = malloc((size_t)cap * 32);
+    double *w = malloc(sizeof(double) * cap);
+    for (;;) {
+        int pid, isl;
+        if (fscanf(f, "%d %d", &pid, &isl) != 2) break;
+        if (n == cap) { cap *= 2; parent = realloc(parent, sizeof(int32_t) * cap); leaf = realloc(leaf, cap); desc = realloc(desc, (size_t)cap * 32); w = realloc(w, sizeof(double) * cap); }
+        int ok = 1;
+        for (int i = 0; i < 32; i++) { int b; if (fscanf(f, "%d", &b) != 1) { ok = 0; break; } desc[(size_t)n * 32 + i] = (uint8_t)b; }
+        if (!ok || fscanf(f, "%lf", &w[n]) != 1) break;
+        parent[n] = pid; leaf[n] = isl > 0;
+        n++;
+    }
+    fclose(f);
+    oracle_vocab *v = n ? oracle_vocab_create(k, L, n, parent, leaf, desc, w) : NULL;
+    free(parent); free(leaf); free(desc); free(w);
+    return v;
+}
+
+void oracle_vocab_destroy(oracle_vocab *v)
+{
+    if (!v) return;
+    free(v->parent); free(v->child_off); free(v->child_ids); free(v->word_id); free(v->desc); free(v->weight);
+    free(v);
+}
+int oracle_vocab_nodes(const oracle_vocab *v) { return v->nnodes; }
+int oracle_vocab_words(const oracle_vocab *v) { return v->nwords; }
+
+typedef struct { uint32_t key; int feat; } kf_pair;
+static int kf_cmp(const void *a, const void *b)
+{
+    const kf_pair *p = a, *q = b;
+    if (p->key != q->key) return p->key < q->key ? -1 : 1;
+    return p->feat < q->feat ? -1 : p->feat > q->feat ? 1 : 0;
+}
+
+int oracle_bow_transform(const oracle_vocab *v, const uint8_t *desc, int n, int levelsup,
+                         uint32_t *word_id, double *word_weight, uint32_t *node_id,
+                         uint32_t *bow_id, double *bow_val, int *nbow,
+                         uint32_t *fv_node_id, int32_t *fv_node_off, uint32_t *fv_feat, int *fv_nnodes)
+{
+    kf_pair *words = malloc(sizeof(kf_pair) * (n ? n : 1)), *nodes = malloc(sizeof(kf_pair) * (n ? n : 1));
+    double *wts = malloc(sizeof(double) * (n ? n : 1));
+    int m = 0;
+    const int nid_level = v->L - levelsup;
+    for (int i = 0; i < n; i++) {
+        /* transform(feature, word_id, weight, nid, levelsup), :1218-1259 */
+        const uint8_t *f = desc + (size_t)i * 32;
+        int nid = 0, final_id = 0, level = 0;
+        do {
+            ++level;
+            const int c0 = v->child_off[final_id], c1 = v->child_off[final_id + 1];
+            final_id = v->child_ids[c0];
+            double best_d = oracle_hamming(f, v->desc + (size_t)final_id * 32);
+            for (int c = c0 + 1; c < c1; c++) {
+                const int id = v->child_ids[c];
+                const double d = oracle_hamming(f, v->desc + (size_t)id * 32);
+                if (d < best_d) { best_d = d; final_id = id; }
+            }
+            if (level == nid_level) nid = final_id;
+        } while (v->child_off[final_id + 1] > v->child_off[final_id]);
+        const int wid = v->word_id[final_id];
+        const double w = v->weight[final_id];
+        if (word_id) word_id[i] = (uint32_t)wid;
+        if (word_weight) word_weight[i] = w;
+        if (node_id) node_id[i] = (uint32_t)nid;
+        if (w > 0) { /* not stopped, :1157 */
+            words[m].key = (uint32_t)wid; words[m].feat = i; wts[i] = w;
+            nodes[m].key = (uint32_t)nid; nodes[m].feat = i;
+            m++;
+        }
+    }
+    /* BowVector: std::map<WordId, WordValue> with addWeight in feature order (BowVector.cpp:33-45) */
+    qsort(words, m, sizeof(kf_pair), kf_cmp);
+    int nb = 0;
+    for (int i = 0; i < m;) {
+        int j = i;
+        double acc = wts[words[i].feat];
+        for (j = i + 1; j < m && words[j].key == words[i].key; j++) acc += wts[words[j].feat];
+        bow_id[nb] = words[i].key; bow_val[nb] = acc; nb++;
+        i = j;
+    }
+    /* L1 normalisation (TF_IDF with L1_NORM: mustNormalize), BowVector.cpp:58-77 */
+    double norm = 0.0;
+    for (int i = 0; i < nb; i++) norm += fabs(bow_val[i]);
+    if (norm > 0.0) for (int i = 0; i < nb; i++) bow_val[i] /= norm;
+    *nbow = nb;
+    /* FeatureVector: std::map<NodeId, vector<unsigned>> with addFeature in feature order */
+    qsort(nodes, m, sizeof(kf_pair), kf_cmp);
+    int nn = 0;
+    for (int i = 0; i < m; i++) {
+        if (i == 0 || nodes[i].key != nodes[i - 1].key) { fv_node_id[nn] = nodes[i].key; fv_node_off[nn] = i; nn++; }
+        fv_feat[i] = (uint32_t)nodes[i].feat;
+    }
+    fv_node_off[nn] = m;
+    *fv_nnodes = nn;
+    free(words); free(nodes); free(wts);
+    return 0;
 }

@@ -111,6 +111,27 @@ int oracle_search_for_triangulation(const oracle_featset *k1, const oracle_feats
                                     float nnratio, int check_ori, int only_stereo,
                                     int32_t *pairs, int cap);
 
+/* ---- DBoW2 vocabulary tree + transform (Frame::ComputeBoW, src/Frame.cc:459-466) */
+typedef struct oracle_vocab oracle_vocab;
+/* nodes in id order as TemplatedVocabulary::loadFromTextFile builds them
+ * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1358-1445): node 0 is the root and is NOT in the arrays;
+ * entry j describes node j+1: parent id, leaf flag, 32-byte descriptor, weight.  Children are appended to
+ * their parent in id order; word ids are assigned to leaves in id order. */
+oracle_vocab *oracle_vocab_create(int k, int L, int nnodes_minus_root, const int32_t *parent, const uint8_t *is_leaf,
+                                  const uint8_t *desc, const double *weight);
+oracle_vocab *oracle_vocab_load_text(const char *path);
+void oracle_vocab_destroy(oracle_vocab *v);
+int oracle_vocab_nodes(const oracle_vocab *v);
+int oracle_vocab_words(const oracle_vocab *v);
+/* TemplatedVocabulary::transform(features, BowVector, FeatureVector, levelsup), TF_IDF weighting + L1 norm
+ * (:1127-1194, :1218-1259; BowVector.cpp:33-77).  Per-feature outputs may be NULL.  BowVector: ascending word
+ * ids with L1-normalised values; FeatureVector: CSR.  Capacities: n entries each (fv_node_off: n+1).
+ * Returns 0. */
+int oracle_bow_transform(const oracle_vocab *v, const uint8_t *desc, int n, int levelsup,
+                         uint32_t *word_id, double *word_weight, uint32_t *node_id,
+                         uint32_t *bow_id, double *bow_val, int *nbow,
+                         uint32_t *fv_node_id, int32_t *fv_node_off, uint32_t *fv_feat, int *fv_nnodes);
+
 /* ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1687-1728 */
 void oracle_three_maxima(const int *count, int L, int *ind1, int *ind2, int *ind3);
 

@@ -1,0 +1,319 @@
+// orbx_vocab.hip — DBoW2 vocabulary tree on device and Frame::ComputeBoW
+// (reference src/Frame.cc:459-466 -> TemplatedVocabulary::transform(features, BowVector, FeatureVector, 4),
+//  Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1194 and :1218-1259; BowVector.cpp:33-77).
+// the step between the extractor and the SearchByBoW kernels.
+//
+// k_vocab_descend: one thread per feature walks the tree (k Hamming distances per level, first
+// minimum wins, strict <), yielding word id, word weight and the node id at level L - levelsup.
+// k_bow_build: one workgroup sorts (node, feature) and (word, feature) keys with an LDS bitonic
+// network and emits the FeatureVector as CSR and the BowVector; weights of one word are added in
+// feature order and the L1 norm is accumulated in ascending word order, i.e. in the order
+// std::map / addWeight / normalize produce (doubles, so the order is part of the result).
+#include "orbx_device.h"
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+struct orbx_vocab {
+    int device, k, L, nnodes, nwords;
+    int *d_child_off, *d_child_ids, *d_word_id;
+    uint32_t *d_desc;
+    double *d_weight;
+    hipStream_t stream;
+    // per-call scratch (grown on demand)
+    uint8_t *d_in; size_t in_cap;
+    uint8_t *d_out; size_t out_cap;
+    uint8_t *h_out; size_t h_out_cap;
+};
+
+__global__ __launch_bounds__(256) void k_vocab_descend(const int *__restrict__ child_off, const int *__restrict__ child_ids,
+                                                       const int *__restrict__ word_of, const uint32_t *__restrict__ ndesc,
+                                                       const double *__restrict__ nweight, const uint32_t *__restrict__ feat,
+                                                       int n, int nid_level, uint32_t *__restrict__ word_id,
+                                                       double *__restrict__ word_w, uint32_t *__restrict__ node_id)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t f[8];
+    {
+        const uint4 *s = reinterpret_cast<const uint4 *>(feat + (long long)i * 8);
+        const uint4 v0 = s[0], v1 = s[1];
+        f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+    }
+    int nid = 0, node = 0, level = 0; // nid stays 0 (root) when nid_level <= 0 (:1228)
+    for (;;) {
+        ++level;
+        const int c0 = child_off[node], c1 = child_off[node + 1];
+        int best = child_ids[c0], best_d = 0x7FFFFFFF;
+        for (int c = c0; c < c1; c++) {
+            const int id = child_ids[c];
+            const uint4 *s = reinterpret_cast<const uint4 *>(ndesc + (long long)id * 8);
+            const uint4 v0 = s[0], v1 = s[1];
+            const int d = __popc(f[0] ^ v0.x) + __popc(f[1] ^ v0.y) + __popc(f[2] ^ v0.z) + __popc(f[3] ^ v0.w) +
+                          __popc(f[4] ^ v1.x) + __popc(f[5] ^ v1.y) + __popc(f[6] ^ v1.z) + __popc(f[7] ^ v1.w);
+            if (d < best_d) { best_d = d; best = id; } // first minimum wins (:1238-1249)
+        }
+        node = best;
+        if (level == nid_level) nid = node;
+        if (child_off[node + 1] <= child_off[node]) break; // isLeaf(): no children
+    }
+    word_id[i] = (uint32_t)word_of[node];
+    word_w[i] = nweight[node];
+    node_id[i] = (uint32_t)nid;
+}
+
+extern __shared__ __align__(16) unsigned char vocab_smem[];
+
+// in-LDS bitonic sort of npad (power of two) u64 keys by 256 threads, ascending
+__device__ void bitonic_sort_u64(unsigned long long *keys, int npad)
+{
+    for (int size = 2; size <= npad; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (npad >> 1); t += 256) {
+                const int lo = 2 * t - (t & (stride - 1)); // index with bit `stride` clear
+                const int hi = lo + stride;
+                const bool asc = (lo & size) == 0;
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a > b) == asc) { keys[lo] = b; keys[hi] = a; }
+            }
+        }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_bow_build(int n, int npad, const uint32_t *__restrict__ word_id,
+                                                   const double *__restrict__ word_w, const uint32_t *__restrict__ node_id,
+                                                   uint32_t *__restrict__ bow_id, double *__restrict__ bow_val, int *__restrict__ counts,
+                                                   uint32_t *__restrict__ fv_node_id, int32_t *__restrict__ fv_node_off,
+                                                   uint32_t *__restrict__ fv_feat)
+{
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(vocab_smem);
+    int *flags = reinterpret_cast<int *>(keys + npad);
+    __shared__ int s_w[4];
+    __shared__ double s_norm;
+    const int tid = threadIdx.x;
+    // ---- FeatureVector: (node id, feature) ascending; stopped words (weight 0) are in no node (:1157)
+    for (int i = tid; i < npad; i += 256)
+        keys[i] = (i < n && word_w[i] > 0) ? (((unsigned long long)node_id[i] << 32) | (unsigned)i) : ~0ull;
+    bitonic_sort_u64(keys, npad);
+    for (int i = tid; i < npad; i += 256) {
+        const bool valid = keys[i] != ~0ull;
+        flags[i] = valid && (i == 0 || (keys[i] >> 32) != (keys[i - 1] >> 32));
+        if (valid) fv_feat[i] = (uint32_t)(keys[i] & 0xFFFFFFFFu);
+    }
+    __syncthreads();
+    int m_local = 0;
+    for (int i = tid; i < npad; i += 256) m_local += keys[i] != ~0ull;
+    const int nn = lds_excl_scan(flags, npad, s_w);
+    for (int i = tid; i < npad; i += 256) {
+        const bool head = keys[i] != ~0ull && (i == 0 || (keys[i] >> 32) != (keys[i - 1] >> 32));
+        if (head) { fv_node_id[flags[i]] = (uint32_t)(keys[i] >> 32); fv_node_off[flags[i]] = i; }
+    }
+    int m;
+    block_excl_scan256(m_local, &m, s_w);
+    if (tid == 0) { fv_node_off[nn] = m; counts[1] = nn; }
+    __syncthreads();
+    // ---- BowVector: (word id, feature) ascending; per word the weights are added in feature order
+    for (int i = tid; i < npad; i += 256)
+        keys[i] = (i < n && word_w[i] > 0) ? (((unsigned long long)word_id[i] << 32) | (unsigned)i) : ~0ull;
+    bitonic_sort_u64(keys, npad);
+    for (int i = tid; i < npad; i += 256)
+        flags[i] = keys[i] != ~0ull && (i == 0 || (keys[i] >> 32) != (keys[i - 1] >> 32));
+    __syncthreads();
+    const int nb = lds_excl_scan(flags, npad, s_w);
+    for (int i = tid; i < npad; i += 256) {
+        const unsigned long long key = keys[i];
+        const bool head = key != ~0ull && (i == 0 || (key >> 32) != (keys[i - 1] >> 32));
+        if (head) {
+            double acc = word_w[key & 0xFFFFFFFFu]; // addWeight: first insert, then += in feature order (BowVector.cpp:33-45)
+            for (int j = i + 1; j < npad && (keys[j] >> 32) == (key >> 32) && keys[j] != ~0ull; j++) acc += word_w[keys[j] & 0xFFFFFFFFu];
+            bow_id[flags[i]] = (uint32_t)(key >> 32);
+            bow_val[flags[i]] = acc;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) { // normalize(L1): ascending word order, sequential doubles (BowVector.cpp:58-77)
+        double norm = 0.0;
+        for (int i = 0; i < nb; i++) norm += fabs(bow_val[i]);
+        s_norm = norm;
+        counts[0] = nb;
+    }
+    __syncthreads();
+    const double norm = s_norm;
+    if (norm > 0.0)
+        for (int i = tid; i < nb; i += 256) bow_val[i] = bow_val[i] / norm;
+}
+
+// ---------------------------------------------------------------- host side
+
+static int vocab_build(int device, int k, int L, int nm1, const int32_t *parent, const uint8_t *is_leaf,
+                       const uint8_t *desc, const double *weight, orbx_vocab **out)
+{
+    if (!out || !parent || !is_leaf || !desc || !weight || nm1 < 1 || k < 0 || k > 20 || L < 1 || L > 10) { // loader limits :1379
+        orbx_set_error("orbx_vocab_create: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        orbx_set_error("no usable HIP device %d (liborbx has no CPU fallback)", device);
+        return ORBX_E_NO_DEVICE;
+    }
+    const int n = nm1 + 1;
+    std::vector<int> off(n + 1, 0), ids(n > 1 ? n - 1 : 1), word(n, -1);
+    for (int i = 1; i < n; i++) {
+        const int p = parent[i - 1];
+        if (p < 0 || p >= i) { orbx_set_error("vocabulary node %d has parent %d (parents must precede children)", i, p); return ORBX_E_INVALID; }
+        off[p + 1]++;
+    }
+    for (int i = 0; i < n; i++) off[i + 1] += off[i];
+    {
+        std::vector<int> cur(off.begin(), off.end() - 1);
+        for (int i = 1; i < n; i++) ids[cur[parent[i - 1]]++] = i; // children in id order (:1409)
+    }
+    if (off[1] == 0) { orbx_set_error("vocabulary root has no children"); return ORBX_E_INVALID; }
+    int nwords = 0;
+    for (int i = 1; i < n; i++) if (is_leaf[i - 1]) word[i] = nwords++; // :1425-1432
+    std::vector<double> w(n, 0.0);
+    std::vector<uint8_t> d((size_t)n * 32, 0);
+    for (int i = 1; i < n; i++) w[i] = weight[i - 1];
+    memcpy(d.data() + 32, desc, (size_t)nm1 * 32);
+    ORBX_HIP(hipSetDevice(device));
+    orbx_vocab *v = new orbx_vocab();
+    memset(v, 0, sizeof *v);
+    v->device = device; v->k = k; v->L = L; v->nnodes = n; v->nwords = nwords;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc((void **)&v->d_child_off, sizeof(int) * (n + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&v->d_child_ids, sizeof(int) * ids.size());
+    if (e == hipSuccess) e = hipMalloc((void **)&v->d_word_id, sizeof(int) * n);
+    if (e == hipSuccess) e = hipMalloc((void **)&v->d_desc, (size_t)n * 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&v->d_weight, sizeof(double) * n);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpy(v->d_child_off, off.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_child_ids, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_word_id, word.data(), sizeof(int) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_desc, d.data(), (size_t)n * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_weight, w.data(), sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { orbx_set_error("vocabulary upload failed: %s", hipGetErrorString(e)); orbx_vocab_destroy(v); return ORBX_E_HIP; }
+    *out = v;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_vocab_create(int device, int k, int L, int nnodes_minus_root, const int32_t *parent, const uint8_t *is_leaf,
+                                 const uint8_t *desc, const double *weight, orbx_vocab **out)
+{
+    return vocab_build(device, k, L, nnodes_minus_root, parent, is_leaf, desc, weight, out);
+}
+
+// the ORBvoc.txt format of TemplatedVocabulary::loadFromTextFile (:1358-1445)
+extern "C" int orbx_vocab_load_text(int device, const char *path, orbx_vocab **out)
+{
+    if (!path || !out) { orbx_set_error("orbx_vocab_load_text: null argument"); return ORBX_E_INVALID; }
+    FILE *f = fopen(path, "r");
+    if (!f) { orbx_set_error("cannot open vocabulary file %s", path); return ORBX_E_INVALID; }
+    int k, L, n1, n2;
+    if (fscanf(f, "%d %d %d %d", &k, &L, &n1, &n2) != 4 || k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) {
+        fclose(f);
+        orbx_set_error("Vocabulary loading failure: This is not a correct text file!"); // message of the reference loader (:1381)
+        return ORBX_E_INVALID;
+    }
+    if (n1 != 0 || n2 != 0) { // ORB-SLAM2's vocabulary is L1_NORM (0) + TF_IDF (0); other scorings are not implemented
+        fclose(f);
+        orbx_set_error("only scoring L1_NORM and weighting TF_IDF are supported (file has %d %d)", n1, n2);
+        return ORBX_E_INVALID;
+    }
+    std::vector<int32_t> parent; std::vector<uint8_t> leaf, desc; std::vector<double> w;
+    for (;;) {
+        int pid, isl;
+        if (fscanf(f, "%d %d", &pid, &isl) != 2) break;
+        uint8_t d[32];
+        bool ok = true;
+        for (int i = 0; i < 32 && ok; i++) { int b; if (fscanf(f, "%d", &b) != 1) ok = false; else d[i] = (uint8_t)b; }
+        double wt;
+        if (!ok || fscanf(f, "%lf", &wt) != 1) break;
+        parent.push_back(pid); leaf.push_back(isl > 0); desc.insert(desc.end(), d, d + 32); w.push_back(wt);
+    }
+    fclose(f);
+    if (parent.empty()) { orbx_set_error("vocabulary file %s holds no nodes", path); return ORBX_E_INVALID; }
+    return vocab_build(device, k, L, (int)parent.size(), parent.data(), leaf.data(), desc.data(), w.data(), out);
+}
+
+extern "C" void orbx_vocab_destroy(orbx_vocab *v)
+{
+    if (!v) return;
+    hipSetDevice(v->device);
+    if (v->stream) { hipStreamSynchronize(v->stream); hipStreamDestroy(v->stream); }
+    void *ptrs[] = { v->d_child_off, v->d_child_ids, v->d_word_id, v->d_desc, v->d_weight, v->d_in, v->d_out };
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (v->h_out) hipHostFree(v->h_out);
+    delete v;
+}
+
+extern "C" int orbx_vocab_info(const orbx_vocab *v, int *k, int *L, int *nnodes, int *nwords)
+{
+    if (!v) { orbx_set_error("null vocabulary"); return ORBX_E_INVALID; }
+    if (k) *k = v->k;
+    if (L) *L = v->L;
+    if (nnodes) *nnodes = v->nnodes;
+    if (nwords) *nwords = v->nwords;
+    return ORBX_OK;
+}
+
+static size_t a16v(size_t x) { return (x + 15) & ~(size_t)15; }
+
+extern "C" int orbx_bow_transform(orbx_vocab *v, const uint8_t *desc, int n, int levelsup,
+                                  uint32_t *word_id, double *word_weight, uint32_t *node_id,
+                                  uint32_t *bow_id, double *bow_val, int *nbow,
+                                  uint32_t *fv_node_id, int32_t *fv_node_off, uint32_t *fv_feat, int *fv_nnodes)
+{
+    if (!v || n < 0 || (n && !desc) || !nbow || !fv_nnodes || (n && (!bow_id || !bow_val || !fv_node_id || !fv_node_off || !fv_feat))) {
+        orbx_set_error("orbx_bow_transform: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    if (n > 8192) { orbx_set_error("orbx_bow_transform: at most 8192 features per call"); return ORBX_E_INVALID; }
+    *nbow = 0; *fv_nnodes = 0;
+    if (n == 0) { if (fv_node_off) fv_node_off[0] = 0; return ORBX_OK; }
+    ORBX_HIP(hipSetDevice(v->device));
+    int npad = 64;
+    while (npad < n) npad <<= 1;
+    // device scratch: [desc | word u32 | weight f64 | nid u32 | bow_id | bow_val | counts | fv_node_id | fv_node_off | fv_feat]
+    const size_t o_word = a16v((size_t)n * 32), o_w = o_word + a16v(4 * (size_t)n), o_nid = o_w + a16v(8 * (size_t)n);
+    const size_t o_bid = o_nid + a16v(4 * (size_t)n), o_bval = o_bid + a16v(4 * (size_t)n), o_cnt = o_bval + a16v(8 * (size_t)n);
+    const size_t o_fid = o_cnt + 16, o_foff = o_fid + a16v(4 * (size_t)n), o_ffeat = o_foff + a16v(4 * ((size_t)n + 1));
+    const size_t total = o_ffeat + a16v(4 * (size_t)npad);
+    if (total > v->in_cap) {
+        if (v->d_in) ORBX_HIP(hipFree(v->d_in));
+        if (v->h_out) ORBX_HIP(hipHostFree(v->h_out));
+        v->d_in = nullptr; v->h_out = nullptr;
+        ORBX_HIP(hipMalloc((void **)&v->d_in, total * 2));
+        ORBX_HIP(hipHostMalloc((void **)&v->h_out, total * 2, hipHostMallocDefault));
+        v->in_cap = total * 2;
+    }
+    uint8_t *d = v->d_in;
+    ORBX_HIP(hipMemcpyAsync(d, desc, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
+    hipLaunchKernelGGL(k_vocab_descend, dim3((n + 255) / 256), dim3(256), 0, v->stream, v->d_child_off, v->d_child_ids, v->d_word_id,
+                       v->d_desc, v->d_weight, (const uint32_t *)d, n, v->L - levelsup, (uint32_t *)(d + o_word), (double *)(d + o_w),
+                       (uint32_t *)(d + o_nid));
+    const size_t lds = (size_t)npad * 12 + 64;
+    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_bow_build, dim3(1), dim3(256), lds, v->stream, n, npad, (const uint32_t *)(d + o_word), (const double *)(d + o_w),
+                       (const uint32_t *)(d + o_nid), (uint32_t *)(d + o_bid), (double *)(d + o_bval), (int *)(d + o_cnt),
+                       (uint32_t *)(d + o_fid), (int32_t *)(d + o_foff), (uint32_t *)(d + o_ffeat));
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(v->h_out + o_word, d + o_word, total - o_word, hipMemcpyDeviceToHost, v->stream));
+    ORBX_HIP(hipStreamSynchronize(v->stream));
+    const uint8_t *h = v->h_out;
+    const int *cnt = (const int *)(h + o_cnt);
+    const int nb = cnt[0], nn = cnt[1];
+    if (word_id) memcpy(word_id, h + o_word, 4 * (size_t)n);
+    if (word_weight) memcpy(word_weight, h + o_w, 8 * (size_t)n);
+    if (node_id) memcpy(node_id, h + o_nid, 4 * (size_t)n);
+    memcpy(bow_id, h + o_bid, 4 * (size_t)nb);
+    memcpy(bow_val, h + o_bval, 8 * (size_t)nb);
+    memcpy(fv_node_id, h + o_fid, 4 * (size_t)nn);
+    memcpy(fv_node_off, h + o_foff, 4 * ((size_t)nn + 1));
+    memcpy(fv_feat, h + o_ffeat, 4 * (size_t)fv_node_off[nn]);
+    *nbow = nb; *fv_nnodes = nn;
+    return ORBX_OK;
+}

@@ -71,6 +71,12 @@ def lib():
     L.orbx_bowdb_size.argtypes = [vp]
     L.orbx_bowdb_destroy.argtypes = [vp]
     L.orbx_bowdb_destroy.restype = None
+    L.orbx_vocab_create.argtypes = [i, i, i, i, vp, vp, vp, vp, C.POINTER(vp)]
+    L.orbx_vocab_load_text.argtypes = [i, C.c_char_p, C.POINTER(vp)]
+    L.orbx_vocab_info.argtypes = [vp, ip, ip, ip, ip]
+    L.orbx_vocab_destroy.argtypes = [vp]
+    L.orbx_vocab_destroy.restype = None
+    L.orbx_bow_transform.argtypes = [vp, vp, i, i, vp, vp, vp, vp, vp, ip, vp, vp, vp, ip]
     L.orbx_profile_enable.argtypes = [vp, i]
     L.orbx_profile_read.argtypes = [vp, vp, vp, i]
     L.orbx_debug_candidates.argtypes = [vp, i, i, vp, vp, vp, i, ip]
@@ -237,6 +243,47 @@ def ComputeStereoMatches(extractorLeft, extractorRight, mvKeys, mDescriptors, mv
 def stereo_match_batch_device(L, imgL0, R, imgR0, batch, d_kL, d_dL, d_nL, d_kR, d_dR, d_nR, cap, bf, min_z, d_ur, d_depth, stream=None):
     _check(lib().orbx_stereo_match_batch_device(L._h, imgL0, R._h, imgR0, batch, d_kL, d_dL, d_nL, d_kR, d_dR, d_nR, cap,
                                                 bf, min_z, d_ur, d_depth, stream))
+
+
+class ORBVocabulary:
+    """Mirror of ORB_SLAM2::ORBVocabulary (= DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>, reference
+    include/ORBVocabulary.h) for the part on the hot path: loadFromTextFile and transform()."""
+
+    def __init__(self, k=None, L=None, parent=None, is_leaf=None, desc=None, weight=None, device=0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        if k is not None:
+            parent = np.ascontiguousarray(parent, np.int32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+            desc = np.ascontiguousarray(desc, np.uint8); weight = np.ascontiguousarray(weight, np.float64)
+            _check(self._L.orbx_vocab_create(device, k, L, len(parent), _p(parent), _p(is_leaf), _p(desc), _p(weight), C.byref(self._h)))
+
+    @classmethod
+    def loadFromTextFile(cls, filename, device=0):
+        v = cls(device=device)
+        _check(v._L.orbx_vocab_load_text(device, str(filename).encode(), C.byref(v._h)))
+        return v
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.orbx_vocab_destroy(h)
+            self._h = None
+
+    def info(self):
+        k, L_, n, w = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _check(self._L.orbx_vocab_info(self._h, C.byref(k), C.byref(L_), C.byref(n), C.byref(w)))
+        return dict(k=k.value, L=L_.value, nodes=n.value, words=w.value)
+
+    def transform(self, features, levelsup=4):
+        """-> dict(word_id, word_weight, node_id, bow_id, bow_val, fv_node_id, fv_node_off, fv_feat)"""
+        desc = np.ascontiguousarray(features, np.uint8).reshape(-1, 32); n = len(desc)
+        wid = np.zeros(n, np.uint32); ww = np.zeros(n, np.float64); nid = np.zeros(n, np.uint32)
+        bid = np.zeros(n, np.uint32); bval = np.zeros(n, np.float64); nb = C.c_int()
+        fid = np.zeros(n, np.uint32); foff = np.zeros(n + 1, np.int32); ffeat = np.zeros(n, np.uint32); fn = C.c_int()
+        _check(self._L.orbx_bow_transform(self._h, _p(desc), n, levelsup, _p(wid), _p(ww), _p(nid), _p(bid), _p(bval), C.byref(nb),
+                                          _p(fid), _p(foff), _p(ffeat), C.byref(fn)))
+        return dict(word_id=wid, word_weight=ww, node_id=nid, bow_id=bid[:nb.value].copy(), bow_val=bval[:nb.value].copy(),
+                    fv_node_id=fid[:fn.value].copy(), fv_node_off=foff[:fn.value + 1].copy(), fv_feat=ffeat[:foff[fn.value]].copy())
 
 
 class BowDatabase:

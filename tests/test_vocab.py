@@ -1,0 +1,149 @@
+"""DBoW2 vocabulary + transform (Frame::ComputeBoW).  CPU: the oracle against an
+independent plain-Python restatement with dict/list standing in for std::map/std::vector.  GPU: the HIP
+path against the oracle, bit-exact doubles included."""
+import os
+
+import numpy as np
+import pytest
+
+from tools import synth
+
+POP = np.array([bin(i).count("1") for i in range(256)])
+
+
+def _python_transform(k, L, parent, is_leaf, ndesc, weight, feats, levelsup):
+    n = len(parent) + 1
+    children = [[] for _ in range(n)]
+    for i, p in enumerate(parent):
+        children[p].append(i + 1)
+    word = {}
+    for i in range(1, n):
+        if is_leaf[i - 1]:
+            word[i] = len(word)
+    bow, fv = {}, {}
+    for fi, f in enumerate(feats):
+        node, level, nid = 0, 0, 0
+        while True:
+            level += 1
+            ch = children[node]
+            ds = [int(POP[f ^ ndesc[c - 1]].sum()) for c in ch]
+            node = ch[int(np.argmin(ds))]          # first minimum
+            if level == L - levelsup:
+                nid = node
+            if not children[node]:
+                break
+        w = weight[node - 1]
+        if w > 0:
+            bow[word[node]] = bow.get(word[node], 0.0) + w if word[node] in bow else w
+            fv.setdefault(nid, []).append(fi)
+    ids = sorted(bow)
+    vals = [bow[i] for i in ids]
+    norm = 0.0
+    for v in vals:
+        norm += abs(v)
+    if norm > 0:
+        vals = [v / norm for v in vals]
+    return ids, vals, {k_: fv[k_] for k_ in sorted(fv)}
+
+
+def _data(seed, n=600):
+    rng = np.random.default_rng(seed)
+    centers = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    return synth.flip_bits(np.random.Generator(np.random.PCG64(seed)), centers[rng.integers(0, 40, n)], 0.08)
+
+
+@pytest.mark.parametrize("k,L,levelsup", [(10, 3, 1), (4, 5, 2), (7, 2, 4), (10, 3, 0)])
+def test_oracle_transform_vs_python(oracle, k, L, levelsup):
+    data = _data(1)
+    par, leaf, nd, w = synth.vocab_tree(2, k, L, stop_frac=0.05, data=data)
+    v = oracle.Vocabulary(k, L, par, leaf, nd, w)
+    assert v.nodes() == len(par) + 1 and v.words() == int(leaf.sum())
+    t = v.transform(data, levelsup)
+    ids, vals, fv = _python_transform(k, L, par, leaf, nd, w, data, levelsup)
+    assert t["bow_id"].tolist() == ids
+    assert t["bow_val"].tolist() == vals                      # identical doubles
+    assert abs(t["bow_val"].sum() - 1.0) < 1e-12
+    assert t["fv_node_id"].tolist() == list(fv)
+    for j, nid in enumerate(fv):
+        assert t["fv_feat"][t["fv_node_off"][j]:t["fv_node_off"][j + 1]].tolist() == fv[nid]
+    if L - levelsup <= 0:
+        assert t["fv_node_id"].tolist() == [0]                # everything hangs off the root (:1228)
+
+
+def test_oracle_text_loader_roundtrip(oracle, tmp_path):
+    data = _data(3)
+    par, leaf, nd, w = synth.vocab_tree(4, 6, 3, data=data)
+    path = os.path.join(tmp_path, "voc.txt")
+    synth.write_vocab_text(path, 6, 3, par, leaf, nd, w)
+    a = oracle.Vocabulary(6, 3, par, leaf, nd, w).transform(data, 1)
+    b = oracle.Vocabulary(path=path).transform(data, 1)
+    assert all((a[k_] == b[k_]).all() for k_ in a)
+    with pytest.raises(ValueError):
+        oracle.Vocabulary(path=os.path.join(tmp_path, "missing.txt"))
+
+
+# ------------------------------------------------------------------------------------------ GPU
+
+def _cmp(a, b):
+    for k_ in a:
+        assert a[k_].dtype == b[k_].dtype and a[k_].shape == b[k_].shape, k_
+        assert a[k_].tobytes() == b[k_].tobytes(), k_
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,L,levelsup,n", [(10, 3, 1, 1000), (10, 4, 2, 2003), (4, 5, 4, 300), (10, 3, 0, 64), (3, 2, 5, 17)])
+def test_hip_transform_parity(pkg, oracle, k, L, levelsup, n):
+    data = _data(5, n)
+    par, leaf, nd, w = synth.vocab_tree(6, k, L, stop_frac=0.05, data=data)
+    got = pkg.ORBVocabulary(k, L, par, leaf, nd, w).transform(data, levelsup)
+    exp = oracle.Vocabulary(k, L, par, leaf, nd, w).transform(data, levelsup)
+    _cmp(got, exp)
+
+
+@pytest.mark.gpu
+def test_hip_transform_on_extracted_descriptors_and_search(pkg, oracle, tmp_path):
+    """extract -> ComputeBoW -> SearchByBoW entirely through liborbx, against the oracle chain"""
+    img = synth.image(7, 752, 480)
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7, device=0, max_size=(752, 480))
+    kp, d = ex(img)
+    par, leaf, nd, w = synth.vocab_tree(8, 10, 3, data=d)
+    path = os.path.join(tmp_path, "voc.txt")
+    synth.write_vocab_text(path, 10, 3, par, leaf, nd, w)
+    voc = pkg.ORBVocabulary.loadFromTextFile(path)
+    assert voc.info() == dict(k=10, L=3, nodes=1111, words=1000)
+    ovoc = oracle.Vocabulary(path=path)
+    rng = np.random.Generator(np.random.PCG64(9))
+    perm = rng.permutation(len(d)); d2 = synth.flip_bits(rng, d, 0.05)[perm]
+    sides = []
+    for desc_, kp_ in ((d2, kp[perm]), (d, kp)):
+        g = voc.transform(desc_, 1); o = ovoc.transform(desc_, 1)
+        _cmp(g, o)
+        sides.append(dict(desc=desc_, node_id=g["fv_node_id"], node_off=g["fv_node_off"], feat=g["fv_feat"],
+                          flag=np.ones(len(desc_), np.uint8), angle=kp_["angle"]))
+    got, n = pkg.ORBmatcher(0.75, True).SearchByBoW(sides[0], sides[1])
+    exp, en = oracle.search_by_bow_kf_f(sides[0], sides[1], 0.75, True)
+    assert n == en and (got == exp).all() and n > 100
+
+
+@pytest.mark.gpu
+def test_hip_vocab_edge_cases(pkg, oracle):
+    data = _data(11, 50)
+    par, leaf, nd, w = synth.vocab_tree(12, 5, 2, data=data)
+    voc = pkg.ORBVocabulary(5, 2, par, leaf, nd, w)
+    t = voc.transform(np.zeros((0, 32), np.uint8))
+    assert len(t["bow_id"]) == 0 and t["fv_node_off"].tolist() == [0]
+    # all words stopped: empty vectors
+    vz = pkg.ORBVocabulary(5, 2, par, leaf, nd, np.zeros_like(w))
+    t = vz.transform(data, 1)
+    assert len(t["bow_id"]) == 0 and len(t["fv_node_id"]) == 0 and (t["word_weight"] == 0).all()
+    _cmp(t, oracle.Vocabulary(5, 2, par, leaf, nd, np.zeros_like(w)).transform(data, 1))
+    # identical features: one word, weight added n times in sequence, then normalised to exactly 1.0
+    same = np.repeat(data[:1], 33, axis=0)
+    _cmp(voc.transform(same, 1), oracle.Vocabulary(5, 2, par, leaf, nd, w).transform(same, 1))
+    with pytest.raises(pkg.OrbxError):            # child before its parent
+        bad = par.copy(); bad[0] = 3
+        pkg.ORBVocabulary(5, 2, bad, leaf, nd, w)
+    with pytest.raises(pkg.OrbxError):
+        pkg.ORBVocabulary(25, 2, par, leaf, nd, w)  # k > 20 (reference loader limit)
+    with pytest.raises(pkg.OrbxError):
+        pkg.ORBVocabulary.loadFromTextFile("/nonexistent/ORBvoc.txt")

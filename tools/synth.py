@@ -127,3 +127,37 @@ def flip_bits(rng, desc, p):
     bits = np.unpackbits(desc, axis=1)
     bits ^= (rng.random(bits.shape) < p).astype(np.uint8)
     return np.packbits(bits, axis=1)
+
+
+def vocab_tree(seed, k=10, L=3, stop_frac=0.02, data=None):
+    """Seeded full k-ary vocabulary tree in DBoW2 id order (node ids assigned breadth-first, as
+    saveToTextFile / loadFromTextFile keep them): returns parent[], is_leaf[], desc[], weight[] for
+    nodes 1..N (the root is implicit).  Leaf weights are positive idf-like values, a fraction is 0
+    ("stopped" words, TemplatedVocabulary.h:1157).  Node descriptors are random, or sampled from
+    `data` descriptors (+ bit noise) so that real features spread over the tree."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    parent, leaf = [], []
+    level_nodes = [0]
+    next_id = 1
+    for lvl in range(1, L + 1):
+        new = []
+        for p in level_nodes:
+            for _ in range(k):
+                parent.append(p); leaf.append(1 if lvl == L else 0); new.append(next_id); next_id += 1
+        level_nodes = new
+    n = len(parent)
+    if data is not None:
+        desc = flip_bits(rng, data[rng.integers(0, len(data), n)], 0.1)
+    else:
+        desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    weight = np.where(np.array(leaf) == 1, rng.uniform(0.5, 9.0, n), 0.0)
+    weight[(np.array(leaf) == 1) & (rng.random(n) < stop_frac)] = 0.0
+    return np.array(parent, np.int32), np.array(leaf, np.uint8), desc, weight
+
+
+def write_vocab_text(path, k, L, parent, is_leaf, desc, weight, scoring=0, weighting=0):
+    """the ORBvoc.txt text format read by TemplatedVocabulary::loadFromTextFile (:1358-1445)"""
+    with open(path, "w") as f:
+        f.write(f"{k} {L} {scoring} {weighting}\n")
+        for i in range(len(parent)):
+            f.write(f"{parent[i]} {is_leaf[i]} " + " ".join(str(int(b)) for b in desc[i]) + f" {float(weight[i])!r}\n")
