@@ -198,6 +198,14 @@ int orbx_bow_transform(orbx_vocab *v, const uint8_t *desc, int n, int levelsup,
                        uint32_t *bow_id, double *bow_val, int *nbow,
                        uint32_t *fv_node_id, int32_t *fv_node_off, uint32_t *fv_feat, int *fv_nnodes);
 
+/* ---- MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:266-340) -- */
+
+/* Batched over map points: point p owns descriptors desc[off[p] .. off[p+1]) (its non-bad observations in the
+ * reference's std::map iteration order, at most 256 each).  best_idx[p] = index (relative to off[p]) of the
+ * descriptor with the smallest median Hamming distance to the others (first wins ties), or -1 for an empty
+ * point.  Host pointers. */
+int orbx_distinctive_descriptors(int device, const uint8_t *desc, const int32_t *off, int npoints, int32_t *best_idx);
+
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------- */
 
 enum { ORBX_STAGE_RESIZE = 0, ORBX_STAGE_FAST = 1, ORBX_STAGE_TREE = 2, ORBX_STAGE_DESC = 3,

@@ -78,6 +78,7 @@ def lib():
         L.oracle_vocab_nodes.argtypes = [C.c_void_p]
         L.oracle_vocab_words.argtypes = [C.c_void_p]
         L.oracle_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.POINTER(C.c_int)] + [C.c_void_p] * 3 + [C.POINTER(C.c_int)]
+        L.oracle_distinctive_descriptor.argtypes = [C.c_void_p, C.c_int]
         L.oracle_three_maxima.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _lib = L
     return _lib
@@ -231,3 +232,8 @@ class Vocabulary:
         assert rc == 0
         return dict(word_id=wid, word_weight=ww, node_id=nid, bow_id=bid[:nb.value].copy(), bow_val=bval[:nb.value].copy(),
                     fv_node_id=fid[:fn.value].copy(), fv_node_off=foff[:fn.value + 1].copy(), fv_feat=ffeat[:foff[fn.value]].copy())
+
+
+def distinctive_descriptor(desc):
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    return lib().oracle_distinctive_descriptor(_p(desc), len(desc))

@@ -1152,3 +1152,32 @@ int oracle_bow_transform(const oracle_vocab *v, const uint8_t *desc, int n, int 
     free(words); free(nodes); free(wts);
     return 0;
 }
+
+/* ------------------------------------------------------------------ MapPoint::ComputeDistinctiveDescriptors (f3) */
+
+static int int_cmp(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+
+/* src/MapPoint.cc:266-340 */
+int oracle_distinctive_descriptor(const uint8_t *desc, int n)
+{
+    if (n <= 0) return -1;
+    float *dist = malloc(sizeof(float) * (size_t)n * n);
+    for (int i = 0; i < n; i++) {
+        dist[(size_t)i * n + i] = 0;
+        for (int j = i + 1; j < n; j++) {
+            const int d = oracle_hamming(desc + (size_t)i * 32, desc + (size_t)j * 32);
+            dist[(size_t)i * n + j] = (float)d;
+            dist[(size_t)j * n + i] = (float)d;
+        }
+    }
+    int best_median = INT_MAX, best_idx = 0;
+    int *row = malloc(sizeof(int) * n);
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) row[j] = (int)dist[(size_t)i * n + j]; /* vector<int> vDists(float*, float*) */
+        qsort(row, n, sizeof(int), int_cmp);
+        const int median = row[(int)(0.5 * (n - 1))];
+        if (median < best_median) { best_median = median; best_idx = i; }
+    }
+    free(row); free(dist);
+    return best_idx;
+}

@@ -132,6 +132,10 @@ int oracle_bow_transform(const oracle_vocab *v, const uint8_t *desc, int n, int 
                          uint32_t *bow_id, double *bow_val, int *nbow,
                          uint32_t *fv_node_id, int32_t *fv_node_off, uint32_t *fv_feat, int *fv_nnodes);
 
+/* MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:266-340, for one map point: desc[n][32] are the
+ * descriptors of its (non-bad) observations in std::map iteration order; returns BestIdx (-1 if n == 0). */
+int oracle_distinctive_descriptor(const uint8_t *desc, int n);
+
 /* ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1687-1728 */
 void oracle_three_maxima(const int *count, int L, int *ind1, int *ind2, int *ind3);
 

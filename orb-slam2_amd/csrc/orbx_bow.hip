@@ -564,3 +564,75 @@ extern "C" int orbx_search_for_triangulation(int device, const orbx_featset *k1,
     if (np > cap) { orbx_set_error("pair capacity %d < %d matches", cap, np); return ORBX_E_CAPACITY; }
     return ORBX_OK;
 }
+
+// ---------------------------------------------------------------- MapPoint::ComputeDistinctiveDescriptors (f3)
+// One wave per map point (src/MapPoint.cc:266-340): the N x N Hamming matrix goes to LDS (u16), every
+// lane then takes rows and finds the row median vDists[int(0.5*(N-1))] by bisection on the value (the k-th
+// smallest of a row is the smallest v with #(d <= v) > k), and a wave min of (median<<16 | row) gives the
+// first row with the smallest median.
+__global__ __launch_bounds__(64) void k_distinctive(const uint32_t *__restrict__ desc, const int32_t *__restrict__ off,
+                                                    int32_t *__restrict__ best_idx)
+{
+    extern __shared__ __align__(16) unsigned char dd_smem[];
+    uint16_t *dm = reinterpret_cast<uint16_t *>(dd_smem);
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int o = off[p], n = off[p + 1] - o;
+    if (n <= 0) { if (lane == 0) best_idx[p] = -1; return; }
+    for (int i = lane; i < n; i += 64) {
+        uint32_t a[8];
+        load_desc(desc, o + i, a);
+        for (int j = 0; j < n; j++) {
+            uint32_t b[8];
+            load_desc(desc, o + j, b);
+            dm[i * n + j] = (uint16_t)hamming256(a, b);
+        }
+    }
+    __syncthreads();
+    const int k = (int)(0.5 * (n - 1));
+    unsigned best = 0xFFFFFFFFu;
+    for (int i = lane; i < n; i += 64) {
+        int lo = 0, hi = 256; // smallest v with count(d <= v) > k
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int c = 0;
+            for (int j = 0; j < n; j++) c += dm[i * n + j] <= mid;
+            if (c > k) hi = mid; else lo = mid + 1;
+        }
+        const unsigned key = ((unsigned)lo << 16) | (unsigned)i;
+        best = key < best ? key : best;
+    }
+    best = wave_min_u32(best);
+    if (lane == 0) best_idx[p] = (int)(best & 0xFFFF);
+}
+
+extern "C" int orbx_distinctive_descriptors(int device, const uint8_t *desc, const int32_t *off, int npoints, int32_t *best_idx)
+{
+    if (!off || !best_idx || npoints < 0 || (npoints && off[npoints] > 0 && !desc)) { orbx_set_error("orbx_distinctive_descriptors: invalid argument"); return ORBX_E_INVALID; }
+    if (npoints == 0) return ORBX_OK;
+    int max_n = 0;
+    if (off[0] != 0) { orbx_set_error("off[0] must be 0"); return ORBX_E_INVALID; }
+    for (int p = 0; p < npoints; p++) {
+        const int n = off[p + 1] - off[p];
+        if (n < 0) { orbx_set_error("offsets must be non-decreasing"); return ORBX_E_INVALID; }
+        if (n > 256) { orbx_set_error("map point %d has %d observations (limit 256)", p, n); return ORBX_E_INVALID; }
+        if (n > max_n) max_n = n;
+    }
+    BowCtx *c;
+    int rc = bow_ctx(device, &c);
+    if (rc) return rc;
+    const size_t total = (size_t)off[npoints];
+    const size_t b_desc = a16(total * 32), b_off = a16(sizeof(int32_t) * ((size_t)npoints + 1));
+    if ((rc = bow_reserve(c, b_desc + b_off, (size_t)npoints + 4))) return rc;
+    if (total) memcpy(c->h_blob, desc, total * 32);
+    memcpy(c->h_blob + b_desc, off, sizeof(int32_t) * ((size_t)npoints + 1));
+    ORBX_HIP(hipMemcpyAsync(c->d_blob, c->h_blob, b_desc + b_off, hipMemcpyHostToDevice, c->stream));
+    const size_t lds = (size_t)max_n * max_n * 2 + 16;
+    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_distinctive), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_distinctive, dim3(npoints), dim3(64), lds, c->stream, (const uint32_t *)c->d_blob,
+                       (const int32_t *)(c->d_blob + b_desc), c->d_out);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(c->h_out, c->d_out, sizeof(int32_t) * (size_t)npoints, hipMemcpyDeviceToHost, c->stream));
+    ORBX_HIP(hipStreamSynchronize(c->stream));
+    memcpy(best_idx, c->h_out, sizeof(int32_t) * (size_t)npoints);
+    return ORBX_OK;
+}

@@ -77,6 +77,7 @@ def lib():
     L.orbx_vocab_destroy.argtypes = [vp]
     L.orbx_vocab_destroy.restype = None
     L.orbx_bow_transform.argtypes = [vp, vp, i, i, vp, vp, vp, vp, vp, ip, vp, vp, vp, ip]
+    L.orbx_distinctive_descriptors.argtypes = [i, vp, vp, i, vp]
     L.orbx_profile_enable.argtypes = [vp, i]
     L.orbx_profile_read.argtypes = [vp, vp, vp, i]
     L.orbx_debug_candidates.argtypes = [vp, i, i, vp, vp, vp, i, ip]
@@ -354,3 +355,15 @@ class ORBmatcher:
         _check(lib().orbx_search_for_triangulation(self.device, C.byref(a), C.byref(b), _p(F), ex, ey, _p(sf), _p(sg), len(sf),
                                                    int(bOnlyStereo), int(self.mbCheckOrientation), _p(pairs), cap, C.byref(n)))
         return pairs[:n.value].copy()
+
+
+def ComputeDistinctiveDescriptors(descriptor_sets, device=0):
+    """Batched MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:266-340): one [n_i,32] uint8
+    array per map point -> BestIdx per map point (-1 for an empty one)."""
+    sets = [np.ascontiguousarray(d, np.uint8).reshape(-1, 32) for d in descriptor_sets]
+    off = np.zeros(len(sets) + 1, np.int32)
+    off[1:] = np.cumsum([len(d) for d in sets])
+    flat = np.concatenate(sets) if len(sets) and off[-1] else np.zeros((0, 32), np.uint8)
+    out = np.zeros(len(sets), np.int32)
+    _check(lib().orbx_distinctive_descriptors(device, _p(flat), _p(off), len(sets), _p(out)))
+    return out
