@@ -147,9 +147,9 @@ __device__ __forceinline__ u16x2 pk(unsigned lo, unsigned hi)
     return __builtin_bit_cast(u16x2, v);
 }
 
+template <int P>
 __device__ __forceinline__ int fast_score_full(const uint8_t *t, int th)
 {
-    constexpr int P = ORBX_TILE_PITCH;
     const int v = t[0];
     int x[16];
     x[0] = t[3 * P];      x[1] = t[3 * P + 1];  x[2] = t[2 * P + 2];   x[3] = t[P + 3];
@@ -197,10 +197,12 @@ __device__ unsigned long long g_fast_stamp[4096 * 8]; // diagnostic build only: 
 #define STAMP(k) do { } while (0)
 #endif
 
+// P / SP = LDS pitches of the pixel tile and the score tile: (48, 40) when every cell of the pyramid fits
+// (cells up to 38 px wide), else (72, 64); smaller tiles = more resident waves per CU.
+template <int P, int SP>
 __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const CellRec *__restrict__ cells, PyrRef pr,
                                              int *__restrict__ cell_cnt, uint32_t *__restrict__ cand, int ini_th, int min_th)
 {
-    constexpr int P = ORBX_TILE_PITCH, SP = ORBX_SCORE_PITCH;
     uint8_t *tile = fast_smem;
     uint8_t *sc = fast_smem + g->fast_lds_sc;
     uint16_t *list = reinterpret_cast<uint16_t *>(fast_smem + g->fast_lds_list);
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
     }
     {
         uint4 *z = reinterpret_cast<uint4 *>(sc);
-        for (int i = lane; i < (dh + 2) * (SP / 16); i += 64) z[i] = make_uint4(0, 0, 0, 0);
+        for (int i = lane; i < ((dh + 2) * SP + 15) / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     STAMP(0);
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
     // ---- full score on the compacted pixels (dense lanes); list entries are (py<<6 | px), ascending
     for (int i = lane; i < nlist; i += 64) {
         const int e = list[i], py = e >> 6, px = e & 63;
-        sc[(py + 1) * SP + px + 1] = (uint8_t)fast_score_full(t0 + py * P + px, min_th);
+        sc[(py + 1) * SP + px + 1] = (uint8_t)fast_score_full<P>(t0 + py * P + px, min_th);
     }
     __syncthreads();
     STAMP(2);
@@ -837,8 +839,13 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
             if (L.h_cell > max_dh) max_dh = L.h_cell;
             if (L.w_cell * L.h_cell > max_npx) max_npx = L.w_cell * L.h_cell;
         }
-        G.fast_lds_sc = (int)align_up((size_t)max_th * ORBX_TILE_PITCH + 8, 16);
-        G.fast_lds_list = G.fast_lds_sc + (int)align_up((size_t)(max_dh + 2) * ORBX_SCORE_PITCH, 16);
+        int max_w_cell = 0;
+        for (int l = 0; l < e->nlevels; l++) if (G.lv[l].w_cell > max_w_cell) max_w_cell = G.lv[l].w_cell;
+        // tile row = w_cell + 6 (+3 alignment slack, +4 for the E neighbour dword) <= 48 ; score row = w_cell + 2 <= 40
+        G.fast_small = (max_w_cell + 6 + 3 + 4 <= 48 && max_w_cell + 2 <= 40) ? 1 : 0;
+        const int tp = G.fast_small ? 48 : ORBX_TILE_PITCH, sp = G.fast_small ? 40 : ORBX_SCORE_PITCH;
+        G.fast_lds_sc = (int)align_up((size_t)max_th * tp + 8, 16);
+        G.fast_lds_list = G.fast_lds_sc + (int)align_up((size_t)(max_dh + 2) * sp, 16);
         G.fast_lds_mask = G.fast_lds_list + (int)align_up((size_t)max_npx * 2 + 16, 16);
         G.fast_lds_bytes = G.fast_lds_mask + 16 * ((max_npx + 63) / 64) + 16;
     }
@@ -1066,8 +1073,12 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
         orbx_prof_end(e, s);
     }
     orbx_prof_begin(e, ORBX_STAGE_FAST, s);
-    hipLaunchKernelGGL(k_fast, dim3(G.total_cells, batch), dim3(64), G.fast_lds_bytes, s, e->d_geom, e->d_cells, pr, e->d_cell_cnt, e->d_cand,
-                       e->ini_th, e->min_th);
+    if (G.fast_small)
+        hipLaunchKernelGGL((k_fast<48, 40>), dim3(G.total_cells, batch), dim3(64), G.fast_lds_bytes, s, e->d_geom, e->d_cells, pr,
+                           e->d_cell_cnt, e->d_cand, e->ini_th, e->min_th);
+    else
+        hipLaunchKernelGGL((k_fast<ORBX_TILE_PITCH, ORBX_SCORE_PITCH>), dim3(G.total_cells, batch), dim3(64), G.fast_lds_bytes, s,
+                           e->d_geom, e->d_cells, pr, e->d_cell_cnt, e->d_cand, e->ini_th, e->min_th);
     orbx_prof_end(e, s);
     int *err_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;
     orbx_prof_begin(e, ORBX_STAGE_TREE, s);
