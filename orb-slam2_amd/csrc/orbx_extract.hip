@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     constexpr int RP = 48, HP = 40, BP = 40; // LDS pitches: raw bytes, row-pass u16, blurred bytes
     __shared__ __align__(16) uint8_t raw[43 * RP + 16];
     __shared__ __align__(16) uint16_t hb[43 * HP];
-    __shared__ __align__(16) uint8_t bl[37 * BP];
+    uint8_t *bl = raw; // the blurred patch overwrites the raw one (dead after the row pass): 5.5 KB per wave, 29 waves/CU
     const int slot = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     int l = 0;
     while (l + 1 < g->nlevels && slot >= g->lv[l + 1].kp_off) l++;
