@@ -36,7 +36,7 @@ __device__ __forceinline__ int rot_bin(float a1, float a2)
     if (rot < 0.0f) rot += 360.0f;
     int bin = (int)roundf(rot * factor);
     if (bin == BOW_HISTO) bin = 0;
-    return bin;
+    return (unsigned)bin < BOW_HISTO ? bin : 0; // the reference asserts the range; NaN / huge angles must not index out of the histogram
 }
 
 __device__ __forceinline__ int find_node(const uint32_t *ids, int n, uint32_t key)

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_stereo_prep(const Geom *__restrict__ g,
     for (int i = tid; i < rows; i += 256) { cnt[i] = 0; cur[i] = 0; }
     __syncthreads();
     for (int ir = tid; ir < n_r; ir += 256) {
-        const float y = kr[ir].y, r = 2.0f * tabs.sf[kr[ir].octave];
+        const float y = kr[ir].y, r = 2.0f * tabs.sf[kr[ir].octave & (ORBX_MAX_LEVELS - 1)];
         const int maxr = min((int)ceilf(y + r), rows - 1), minr = max((int)floorf(y - r), 0);
         for (int yi = minr; yi <= maxr; yi++) atomicAdd(&cnt[yi], 1);
     }
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_stereo_prep(const Geom *__restrict__ g,
     if (tid == 0) ro[rows] = min(total, ent_cap);
     uint16_t *en = entries + (long long)p * ent_cap;
     for (int ir = tid; ir < n_r; ir += 256) {
-        const float y = kr[ir].y, r = 2.0f * tabs.sf[kr[ir].octave];
+        const float y = kr[ir].y, r = 2.0f * tabs.sf[kr[ir].octave & (ORBX_MAX_LEVELS - 1)];
         const int maxr = min((int)ceilf(y + r), rows - 1), minr = max((int)floorf(y - r), 0);
         for (int yi = minr; yi <= maxr; yi++) {
             const int pos = cnt[yi] + atomicAdd(&cur[yi], 1);
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrR
     const orbx_keypoint *kr = kR + (long long)p * cap;
     const uint32_t *dr = dR + (long long)p * cap * 8;
     const orbx_keypoint kp = kL[ol];
-    const int level_l = kp.octave;
+    const int level_l = min(max(kp.octave, 0), g->nlevels - 1); // never index the level tables out of range
     const float vl = kp.y, ul = kp.x;
     const int n_rows = g->lv[0].h;
     const int row = (int)vl;
@@ -312,6 +312,10 @@ extern "C" int orbx_stereo_match(orbx_extractor *L, orbx_extractor *R,
         return ORBX_E_INVALID;
     }
     if (nL == 0) return ORBX_OK;
+    for (int i = 0; i < nL; i++)
+        if (kL[i].octave < 0 || kL[i].octave >= L->nlevels) { orbx_set_error("left keypoint %d: octave %d out of range", i, kL[i].octave); return ORBX_E_INVALID; }
+    for (int i = 0; i < nR; i++)
+        if (kR[i].octave < 0 || kR[i].octave >= L->nlevels) { orbx_set_error("right keypoint %d: octave %d out of range", i, kR[i].octave); return ORBX_E_INVALID; }
     if (!L->last_img0 || !R->last_img0) { orbx_set_error("run orbx_extract on both eyes first"); return ORBX_E_INVALID; }
     ORBX_HIP(hipSetDevice(L->device));
     ORBX_HIP(hipStreamSynchronize(R->stream)); // the right pyramid was produced on R's stream

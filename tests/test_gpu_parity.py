@@ -191,6 +191,19 @@ def test_stereo_parity(pkg, oracle, seed, w, h, nf):
     assert (np.abs((kL["x"] - ur)[ok] - d_true[ok]) < 2.0).mean() > 0.8
 
 
+def test_stereo_rejects_bad_octave(pkg):
+    w, h = 640, 480
+    exL, exR = _extractor(pkg, 300, w, h), _extractor(pkg, 300, w, h)
+    img = synth.image(72, w, h)
+    kL, dL = exL(img); kR, dR = exR(img)
+    bad = kR.copy(); bad["octave"][0] = 99
+    with pytest.raises(pkg.OrbxError):
+        pkg.ComputeStereoMatches(exL, exR, kL, dL, bad, dR, 386.1448, 0.5372)
+    # identical eyes: every SAD is 0, so the median cut (thDist = 1.5*1.4*0) drops every match, as in the reference
+    ur, dp = pkg.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, 386.1448, 0.5372)
+    assert (ur == -1).all() and (dp == -1).all()
+
+
 def test_stereo_no_matches(pkg, oracle):
     """right eye unrelated to the left: (almost) nothing survives; empty accepted set must not fault"""
     w, h = 640, 480
