@@ -231,8 +231,15 @@ def main():
     per_step_launches = launches / args.steps
     bytes_per_launch = algorithmic_bytes(dom, NI, B, nkp_avg) / per_step_launches
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None   # HBM bytes per launch from the rocprofv3 PMC passes (tools/collect_pmc.py), same workload only
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if args.workload == "stereo1000" and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        kern = tj.get("kernels", {}).get("k_" + dom)
+        if kern and tj.get("images_per_launch"):
+            traffic = int(kern["hbm_bytes_per_launch"] * NI / tj["images_per_launch"])
     roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in stage_ms.items()}}
 

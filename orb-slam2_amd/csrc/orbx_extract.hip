@@ -188,6 +188,9 @@ __device__ __forceinline__ int fast_score_full(const uint8_t *t, int th)
 // ballot per 64 pixels (kept in LDS), iniThFAST/minThFAST selection and ordered (row-major)
 // emission into the cell's candidate slots.  Candidate = x | y<<12 | score<<24, (x,y) relative to (16,16).
 extern __shared__ __align__(16) unsigned char fast_smem[];
+#ifndef FAST_XG
+#define FAST_XG 4
+#endif
 
 #ifdef ORBX_DIAG
 __device__ unsigned long long g_fast_stamp[4096 * 8]; // diagnostic build only: summed phase cycles of k_fast, 4096 slots
@@ -207,7 +210,16 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
     uint8_t *sc = fast_smem + g->fast_lds_sc;
     uint16_t *list = reinterpret_cast<uint16_t *>(fast_smem + g->fast_lds_list);
     unsigned long long *masks = reinterpret_cast<unsigned long long *>(fast_smem + g->fast_lds_mask);
-    const int b = blockIdx.y, cell = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.y, lane = threadIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8, speed only): remap so that FAST_XG
+    // horizontally adjacent cells land on the same XCD (their halos share cache lines in that XCD's L2) while each
+    // XCD's work stays spread over the whole image (contiguous runs per XCD were measured slower).
+    int cell;
+    {
+        const int bx = blockIdx.x, grp = bx / (8 * FAST_XG), r = bx - grp * (8 * FAST_XG);
+        cell = grp * (8 * FAST_XG) + (r & 7) * FAST_XG + (r >> 3);
+        if (cell >= g->total_cells) return;
+    }
 #ifdef ORBX_DIAG
     unsigned long long _t_prev = __builtin_amdgcn_s_memtime();
 #endif
@@ -1074,10 +1086,10 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
     }
     orbx_prof_begin(e, ORBX_STAGE_FAST, s);
     if (G.fast_small)
-        hipLaunchKernelGGL((k_fast<48, 40>), dim3(G.total_cells, batch), dim3(64), G.fast_lds_bytes, s, e->d_geom, e->d_cells, pr,
+        hipLaunchKernelGGL((k_fast<48, 40>), dim3((G.total_cells + 8 * FAST_XG - 1) / (8 * FAST_XG) * (8 * FAST_XG), batch), dim3(64), G.fast_lds_bytes, s, e->d_geom, e->d_cells, pr,
                            e->d_cell_cnt, e->d_cand, e->ini_th, e->min_th);
     else
-        hipLaunchKernelGGL((k_fast<ORBX_TILE_PITCH, ORBX_SCORE_PITCH>), dim3(G.total_cells, batch), dim3(64), G.fast_lds_bytes, s,
+        hipLaunchKernelGGL((k_fast<ORBX_TILE_PITCH, ORBX_SCORE_PITCH>), dim3((G.total_cells + 8 * FAST_XG - 1) / (8 * FAST_XG) * (8 * FAST_XG), batch), dim3(64), G.fast_lds_bytes, s,
                            e->d_geom, e->d_cells, pr, e->d_cell_cnt, e->d_cand, e->ini_th, e->min_th);
     orbx_prof_end(e, s);
     int *err_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Collect HBM-side traffic of every kernel with rocprofv3 PMC passes and write profiles/<tag>_traffic.json.
+
+Run ON THE GPU BOX (e.g. `gpurun -- python3 tools/collect_pmc.py r01`).  FETCH_SIZE and WRITE_SIZE are
+collected in SEPARATE passes (they do not fit one pass on gfx950: MI355X_MICROARCH.md, rocprofv3 PMC slots),
+each with --kernel-trace only.  rocprofv3 is given `python3 bench.py ...` directly after `--` (no shell,
+env or launcher hop).  Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB per dispatch.
+gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE halves the bytes of 16-B-per-lane streaming reads;
+the kernels here read 4 B per lane (dword tile loads), for which `k_resize` calibrates the counter at ~1.0x
+(170 MB counted for 180 MB algorithmic per step), so no factor is applied; both raw counters are stored.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+out_dir = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}")
+res = collections.defaultdict(dict)
+env = dict(os.environ, TMPDIR="/tmp")
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    d = os.path.join(out_dir, counter)
+    subprocess.check_call(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                           "python3", os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--cpu-frames", "0",
+                           "--batch", str(batch)], cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()   # "void k_fast<48, 40>(...)" -> k_fast
+        acc[name].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        if k.startswith("k_"):
+            res[k][counter + "_KiB_per_launch"] = sum(v) / len(v)
+            res[k]["launches_sampled"] = len(v)
+for k in res:
+    res[k]["hbm_bytes_per_launch"] = int(1024 * (res[k].get("FETCH_SIZE_KiB_per_launch", 0) + res[k].get("WRITE_SIZE_KiB_per_launch", 0)))
+doc = {"tag": tag, "workload": "stereo1000", "frames_per_step": batch, "images_per_launch": 2 * batch,
+       "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace; mean over dispatches; "
+                 "no gfx950 x2 correction (4 B per lane loads calibrate at ~1.0x on k_resize)",
+       "kernels": res}
+path = os.path.join(ROOT, "gpurun_out", f"{tag}_traffic.json")
+json.dump(doc, open(path, "w"), indent=1)
+print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in res.items()}))
