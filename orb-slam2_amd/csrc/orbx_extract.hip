@@ -781,12 +781,17 @@ static size_t tree_lds_bytes(const Geom &G, int lds_pts_cap)
     const size_t cap = G.max_node_cap;
     return cap * (4 + 4 + 8 + 8 + 16 + 16 + 4 * 5) + (size_t)((G.max_cells_level + 4) & ~3) * 4 + (size_t)lds_pts_cap * 6 + 64;
 }
+static const size_t kTreeLdsLimit = 150 * 1024;
 // LDS point capacity of k_tree: enough for a level's typical candidate count (P_0/96), bounded so that
-// several (level, image) workgroups fit one CU; levels with more candidates use the HBM scratch.
+// several (level, image) workgroups fit one CU and so that the node tables (76 B per leaf) still fit;
+// levels with more candidates keep their points in the HBM scratch.  < 0: the node tables alone do not fit.
 static int lds_pts_cap(const Geom &G)
 {
     int c = (G.lv[0].w * G.lv[0].h / 96 + 1023) & ~1023;
-    return c < 4096 ? 4096 : c > 12288 ? 12288 : c;
+    c = c < 4096 ? 4096 : c > 12288 ? 12288 : c;
+    while (c > 0 && tree_lds_bytes(G, c) > kTreeLdsLimit) c -= 1024;
+    if (tree_lds_bytes(G, c) > kTreeLdsLimit) return -1;
+    return c;
 }
 
 int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
@@ -904,7 +909,10 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
             c.cand_slot = L.cand_off + (long long)ci * L.cand_cap;
         }
     }
-    if (tree_lds_bytes(G, lds_pts_cap(G)) > 160 * 1024) { orbx_set_error("nfeatures too large for the quadtree kernel's LDS"); return ORBX_E_INVALID; }
+    if (lds_pts_cap(G) < 0) {
+        orbx_set_error("per-level feature quota %d too large for the quadtree kernel's LDS node tables (limit about 2000 per level)", G.max_node_cap);
+        return ORBX_E_INVALID;
+    }
     ORBX_HIP(hipSetDevice(e->device));
     ORBX_HIP(hipStreamSynchronize(e->stream));
     const size_t B = e->max_batch;

@@ -79,6 +79,61 @@ def test_other_scale_factors(pkg, oracle, sf, nlevels):
     _check_stages(ex, orc, img, f"sf={sf}")
 
 
+def test_random_geometry_sweep(pkg, oracle):
+    """seeded sweep over image sizes / feature counts / level counts / scale factors: every combination changes the
+    cell grid, the resize tables, the quadtree roots and the LDS carve; all stages must stay bit-exact"""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    done = 0
+    for trial in range(60):
+        w = int(rng.integers(120, 1400)); h = int(rng.integers(100, 900))
+        nlevels = int(rng.integers(1, 9)); sf = float(rng.choice([1.1, 1.2, 1.2, 1.2, 1.25, 1.4, 1.7]))
+        nf = int(rng.integers(50, 3000))
+        try:
+            orc = oracle.Oracle(nf, sf, nlevels, 20, 7)
+            img = synth.image(3000 + trial, w, h, nshapes=int(w * h / 400) + 50)
+            okps, odesc = orc.extract(img)
+        except RuntimeError:
+            # the oracle rejects what the reference cannot process (top level smaller than a cell, zero roots)
+            ex = pkg.ORBextractor(nf, sf, nlevels, 20, 7, device=0, max_size=(w, h))
+            with pytest.raises(pkg.OrbxError):
+                ex(np.zeros((h, w), np.uint8))
+            continue
+        ex = pkg.ORBextractor(nf, sf, nlevels, 20, 7, device=0, max_size=(w, h))
+        tag = f"trial {trial}: {w}x{h} nf={nf} levels={nlevels} sf={sf}"
+        if orc.features_per_level().max() > 1900:
+            # documented limit (DESIGN.md, Limits): the quadtree's node tables live in LDS (76 B per leaf, ~2000 leaves)
+            if orc.features_per_level().max() > 2050:
+                with pytest.raises(pkg.OrbxError, match="too large for the quadtree"):
+                    ex(img)
+            continue
+        kps, desc = ex(img)
+        assert len(kps) == len(okps), tag
+        assert kps.tobytes() == okps.tobytes(), tag
+        assert desc.tobytes() == odesc.tobytes(), tag
+        done += 1
+    assert done >= 40
+
+
+def test_two_handles_two_threads(pkg, oracle):
+    """distinct handles may be used concurrently from different host threads"""
+    import threading
+    imgs = [synth.image(90 + i, 640, 480) for i in range(2)]
+    exp = [oracle.Oracle(1000, 1.2, 8, 20, 7).extract(im) for im in imgs]
+    exs = [_extractor(pkg, 1000, 640, 480) for _ in range(2)]
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(20):
+                k, d = exs[i](imgs[i])
+                assert k.tobytes() == exp[i][0].tobytes() and d.tobytes() == exp[i][1].tobytes()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+
+
 def test_tables_match_oracle(pkg, oracle):
     ex = _extractor(pkg, 2000, 640, 480)
     orc = oracle.Oracle(2000, 1.2, 8, 20, 7)
