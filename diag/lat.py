@@ -1,0 +1,19 @@
+import os, sys, time, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import __graft_entry__ as ge
+from tools import synth
+pkg = ge.load_pkg(); L = pkg.lib()
+W,H = 1241,376
+img = synth.image(5,W,H)
+ex = pkg.ORBextractor(1000,1.2,8,20,7,device=0,max_size=(W,H))
+cap = ex.max_keypoints(W,H)
+kps = np.zeros(cap, pkg.KP_DTYPE); desc = np.zeros((cap,32),np.uint8); n = C.c_int()
+def call():
+    rc = L.orbx_extract(ex._h, img.ctypes.data, W, H, img.strides[0], kps.ctypes.data, desc.ctypes.data, cap, C.byref(n)); assert rc == 0
+for _ in range(20): call()
+ts=[]
+for _ in range(300):
+    t=time.perf_counter(); call(); ts.append(time.perf_counter()-t)
+ts=np.array(ts)*1e6
+print("orbx_extract host API: median %.1f us  mean %.1f us  p95 %.1f us  n=%d" % (np.median(ts), ts.mean(), np.percentile(ts,95), n.value))

@@ -1001,7 +1001,9 @@ extern "C" int orbx_extractor_create(orbx_extractor **out, int nfeatures, float 
     int rc = upload_constants(e);
     if (rc == ORBX_OK && hipMalloc((void **)&e->d_geom, sizeof(Geom)) != hipSuccess) { orbx_set_error("hipMalloc failed"); rc = ORBX_E_HIP; }
     if (rc == ORBX_OK && hipMalloc((void **)&e->d_lvl_cnt, sizeof(int) * (size_t)max_batch * nlevels + 16) != hipSuccess) { orbx_set_error("hipMalloc failed"); rc = ORBX_E_HIP; }
+    if (rc == ORBX_OK && hipHostMalloc((void **)&e->h_flag, 64, hipHostMallocDefault) != hipSuccess) { orbx_set_error("hipHostMalloc failed"); rc = ORBX_E_HIP; }
     if (rc != ORBX_OK) { orbx_extractor_destroy(e); return rc; }
+    *e->h_flag = 0;
     // last int of d_lvl_cnt is the kernel error flag
     hipMemset(e->d_lvl_cnt, 0, sizeof(int) * (size_t)max_batch * nlevels + 16);
     *out = e;
@@ -1019,6 +1021,9 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *e)
                      e->d_lvl_cnt, e->d_lvl_kp, e->d_out_kps, e->d_out_desc, e->d_out_n, e->d_out_ur, e->d_out_depth, e->d_st_dist, e->d_st_entries };
     for (void *p : ptrs) if (p) hipFree(p);
     for (void *p : e->scratch) if (p) hipFree(p);
+    if (e->h_stage_in) hipHostFree(e->h_stage_in);
+    if (e->h_out) hipHostFree(e->h_out);
+    if (e->h_flag) hipHostFree(e->h_flag);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1117,9 +1122,11 @@ extern "C" int orbx_sync(orbx_extractor *e, void *stream)
 {
     if (!e) { orbx_set_error("null extractor"); return ORBX_E_INVALID; }
     ORBX_HIP(hipSetDevice(e->device));
-    ORBX_HIP(hipStreamSynchronize(stream ? (hipStream_t)stream : e->stream));
-    int flag = 0;
-    ORBX_HIP(hipMemcpy(&flag, e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels, sizeof(int), hipMemcpyDeviceToHost));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    // the kernel error flag rides the same stream into pinned memory: one synchronisation, no blocking pageable copy
+    ORBX_HIP(hipMemcpyAsync(e->h_flag, e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels, sizeof(int), hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    const int flag = *e->h_flag;
     if (flag) { orbx_set_error("quadtree kernel reported a node-table overflow"); return ORBX_E_CAPACITY; }
     return ORBX_OK;
 }
@@ -1139,6 +1146,15 @@ int orbx_ensure_out_staging(orbx_extractor *e, int batch, int cap)
     return ORBX_OK;
 }
 
+static int ensure_pinned(uint8_t **p, size_t *cap, size_t need)
+{
+    if (need <= *cap && *p) return ORBX_OK;
+    if (*p) { ORBX_HIP(hipHostFree(*p)); *p = nullptr; *cap = 0; }
+    ORBX_HIP(hipHostMalloc((void **)p, need ? need : 16, hipHostMallocDefault));
+    *cap = need;
+    return ORBX_OK;
+}
+
 extern "C" int orbx_extract_batch(orbx_extractor *e, const uint8_t *const *imgs, int batch, int w, int h, size_t stride,
                                   orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out)
 {
@@ -1155,24 +1171,35 @@ extern "C" int orbx_extract_batch(orbx_extractor *e, const uint8_t *const *imgs,
     if (cap < need) { orbx_set_error("keypoint capacity %d < orbx_max_keypoints() = %d", cap, need); return ORBX_E_CAPACITY; }
     const size_t pitch = align_up(w, 64), img_bytes = pitch * h;
     if ((rc = ensure(&e->d_stage_in, &e->stage_in_cap, img_bytes * e->max_batch))) return rc;
+    if ((rc = ensure_pinned(&e->h_stage_in, &e->h_stage_in_cap, img_bytes * e->max_batch))) return rc;
     if ((rc = orbx_ensure_out_staging(e, e->max_batch, need))) return rc;
+    // pinned output image: [n | keypoints | descriptors] per batch
+    const size_t o_kps = align_up(sizeof(int) * (size_t)e->max_batch, 64);
+    const size_t o_desc = o_kps + align_up(sizeof(orbx_keypoint) * (size_t)need * e->max_batch, 64);
+    const size_t out_bytes = o_desc + (size_t)32 * need * e->max_batch;
+    if ((rc = ensure_pinned(&e->h_out, &e->h_out_cap, out_bytes))) return rc;
+    // repitch into pinned memory on the host (a pageable 2-D copy is executed row by row by the runtime), one H2D copy
     for (int i = 0; i < batch; i++) {
         if (!imgs[i]) { orbx_set_error("imgs[%d] is NULL", i); return ORBX_E_INVALID; }
-        ORBX_HIP(hipMemcpy2DAsync(e->d_stage_in + img_bytes * i, pitch, imgs[i], stride, w, h, hipMemcpyHostToDevice, e->stream));
+        uint8_t *dst = e->h_stage_in + img_bytes * i;
+        for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * pitch, imgs[i] + (size_t)y * stride, (size_t)w);
     }
-    e->prof_chain = false; // the copies above are not part of the first launch
+    ORBX_HIP(hipMemcpyAsync(e->d_stage_in, e->h_stage_in, img_bytes * batch, hipMemcpyHostToDevice, e->stream));
+    e->prof_chain = false; // the copy above is not part of the first launch
     rc = orbx_extract_batch_device(e, e->d_stage_in, img_bytes, pitch, batch, w, h, e->d_out_kps, e->d_out_desc, need, e->d_out_n, nullptr);
     if (rc) return rc;
-    ORBX_HIP(hipMemcpyAsync(n_out, e->d_out_n, sizeof(int) * batch, hipMemcpyDeviceToHost, e->stream));
+    // whole capacity back in three copies, one synchronisation
+    ORBX_HIP(hipMemcpyAsync(e->h_out, e->d_out_n, sizeof(int) * batch, hipMemcpyDeviceToHost, e->stream));
+    ORBX_HIP(hipMemcpyAsync(e->h_out + o_kps, e->d_out_kps, sizeof(orbx_keypoint) * (size_t)need * batch, hipMemcpyDeviceToHost, e->stream));
+    ORBX_HIP(hipMemcpyAsync(e->h_out + o_desc, e->d_out_desc, (size_t)32 * need * batch, hipMemcpyDeviceToHost, e->stream));
     rc = orbx_sync(e, nullptr);
     if (rc) return rc;
+    const int *hn = reinterpret_cast<const int *>(e->h_out);
     for (int i = 0; i < batch; i++) {
-        ORBX_HIP(hipMemcpyAsync(kps + (size_t)i * cap, (orbx_keypoint *)e->d_out_kps + (size_t)i * need,
-                                sizeof(orbx_keypoint) * n_out[i], hipMemcpyDeviceToHost, e->stream));
-        ORBX_HIP(hipMemcpyAsync(desc + (size_t)i * cap * 32, (uint8_t *)e->d_out_desc + (size_t)i * need * 32,
-                                (size_t)32 * n_out[i], hipMemcpyDeviceToHost, e->stream));
+        n_out[i] = hn[i];
+        memcpy(kps + (size_t)i * cap, e->h_out + o_kps + sizeof(orbx_keypoint) * (size_t)need * i, sizeof(orbx_keypoint) * (size_t)hn[i]);
+        memcpy(desc + (size_t)i * cap * 32, e->h_out + o_desc + (size_t)32 * need * i, (size_t)32 * hn[i]);
     }
-    ORBX_HIP(hipStreamSynchronize(e->stream));
     return ORBX_OK;
 }
 

@@ -83,6 +83,10 @@ struct orbx_extractor {
     uint32_t *d_tree_pts; uint16_t *d_tree_nid; size_t tree_cap; // overflow scratch of the quadtree
     int *d_lvl_cnt;                        // [max_batch][nlevels]
     uint32_t *d_lvl_kp; size_t lvl_kp_cap; // [max_batch][kp_total]
+    // host-API pinned staging (pageable 2-D copies cost milliseconds)
+    uint8_t *h_stage_in; size_t h_stage_in_cap;
+    uint8_t *h_out; size_t h_out_cap;
+    int *h_flag;                           // pinned copy of the kernel error flag
     // host-API output staging
     void *d_out_kps, *d_out_desc, *d_out_n; int out_cap; int out_batch;
     float *d_out_ur, *d_out_depth;
