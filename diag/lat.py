@@ -17,3 +17,16 @@ for _ in range(300):
     t=time.perf_counter(); call(); ts.append(time.perf_counter()-t)
 ts=np.array(ts)*1e6
 print("orbx_extract host API: median %.1f us  mean %.1f us  p95 %.1f us  n=%d" % (np.median(ts), ts.mean(), np.percentile(ts,95), n.value))
+# stereo host path: extract L, extract R (sequential) + ComputeStereoMatches
+L_,R_,_ = synth.stereo_pair(9,W,H)
+exL = pkg.ORBextractor(1000,1.2,8,20,7,device=0,max_size=(W,H)); exR = pkg.ORBextractor(1000,1.2,8,20,7,device=0,max_size=(W,H))
+kL,dL = exL(L_); kR,dR = exR(R_)
+ur = np.zeros(len(kL),np.float32); dp = np.zeros(len(kL),np.float32)
+def st():
+    rc = L.orbx_stereo_match(exL._h, exR._h, kL.ctypes.data, dL.ctypes.data, len(kL), kR.ctypes.data, dR.ctypes.data, len(kR), C.c_float(386.1448), C.c_float(0.5372), ur.ctypes.data, dp.ctypes.data); assert rc==0
+for _ in range(10): st()
+ts=[]
+for _ in range(200):
+    t=time.perf_counter(); st(); ts.append(time.perf_counter()-t)
+ts=np.array(ts)*1e6
+print("orbx_stereo_match host API: median %.1f us  p95 %.1f us  matches %d" % (np.median(ts), np.percentile(ts,95), (ur>=0).sum()))
