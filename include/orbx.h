@@ -198,6 +198,45 @@ int orbx_bow_transform(orbx_vocab *v, const uint8_t *desc, int n, int levelsup,
                        uint32_t *bow_id, double *bow_val, int *nbow,
                        uint32_t *fv_node_id, int32_t *fv_node_off, uint32_t *fv_feat, int *fv_nnodes);
 
+/* ---- projection-guided tracking matchers -------------------------------- */
+
+/* the current Frame: undistorted keypoints, right coordinates, descriptors, image bounds (the 64x48 feature
+ * grid of Frame::AssignFeaturesToGrid / GetFeaturesInArea, src/Frame.cc:261-279,:386-457, is rebuilt on device) */
+typedef struct {
+    int n;
+    const float *x, *y;        /* mvKeysUn[i].pt */
+    const int32_t *octave;     /* mvKeysUn[i].octave */
+    const float *angle;        /* mvKeysUn[i].angle */
+    const float *u_right;      /* mvuRight */
+    const uint8_t *desc;       /* mDescriptors [n][32] */
+    const uint8_t *occupied;   /* 1: mvpMapPoints[i] is set and has Observations() > 0 before the call */
+    float min_x, min_y, max_x, max_y; /* mnMinX, mnMinY, mnMaxX, mnMaxY */
+} orbx_frame_feats;
+/* the projected map points in the reference's iteration order; the adaptor (which has the poses) projects */
+typedef struct {
+    int n;
+    const float *u, *v;        /* last-frame search: u, v of src/ORBmatcher.cc:1428-1429 ; map-point search: mTrackProjX/Y */
+    const float *aux;          /* last-frame search: invzc (:1425)                   ; map-point search: mTrackProjXR */
+    const int32_t *level;      /* last-frame search: LastFrame.mvKeys[i].octave      ; map-point search: mnTrackScaleLevel */
+    const float *angle;        /* last-frame search only: LastFrame.mvKeysUn[i].angle */
+    const float *view_cos;     /* map-point search only: mTrackViewCos */
+    const uint8_t *desc;       /* pMP->GetDescriptor() [n][32] */
+    const uint8_t *valid;      /* last-frame: pMP && !mvbOutlier[i] ; map-point: mbTrackInView && !isBad() */
+    const uint8_t *has_obs;    /* pMP->Observations() > 0: a match by this point blocks the feature for later points */
+} orbx_proj_points;
+
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (src/ORBmatcher.cc:1396-1553;
+ * Tracking::TrackWithMotionModel).  direction: 0 none, 1 bForward, 2 bBackward (:1412-1413).  match_cur[cur->n] =
+ * index of the point each current feature finally holds (-1 none); *nmatches = the reference's return value
+ * (it counts every accepted point, also one whose feature a later point overwrote). */
+int orbx_search_by_projection_last_frame(int device, const orbx_frame_feats *cur, const orbx_proj_points *pts,
+                                         const float *scale_factors, int nlevels, float th, int direction, float mbf,
+                                         int check_orientation, int32_t *match_cur, int *nmatches);
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:48-129; Tracking::SearchLocalPoints) */
+int orbx_search_by_projection_map_points(int device, const orbx_frame_feats *cur, const orbx_proj_points *pts,
+                                         const float *scale_factors, int nlevels, float th, float nnratio,
+                                         int32_t *match_cur, int *nmatches);
+
 /* ---- MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:266-340) -- */
 
 /* Batched over map points: point p owns descriptors desc[off[p] .. off[p+1]) (its non-bad observations in the

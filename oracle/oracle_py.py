@@ -26,6 +26,42 @@ def build(force=False):
 _lib = None
 
 
+class FrameFeats(C.Structure):
+    _fields_ = [("n", C.c_int), ("x", C.c_void_p), ("y", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p),
+                ("u_right", C.c_void_p), ("desc", C.c_void_p), ("occupied", C.c_void_p),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float)]
+
+
+class ProjPoints(C.Structure):
+    _fields_ = [("n", C.c_int), ("u", C.c_void_p), ("v", C.c_void_p), ("aux", C.c_void_p), ("level", C.c_void_p),
+                ("angle", C.c_void_p), ("view_cos", C.c_void_p), ("desc", C.c_void_p), ("valid", C.c_void_p), ("has_obs", C.c_void_p)]
+
+
+def make_frame_feats(d, cls=None):
+    """dict(x,y,octave,angle,u_right,desc,occupied,bounds=(minx,miny,maxx,maxy)) -> (struct, keepalive)"""
+    keep = {}
+    def arr(k, dt):
+        keep[k] = np.ascontiguousarray(d[k], dtype=dt); return keep[k].ctypes.data
+    s = (cls or FrameFeats)()
+    s.x = arr("x", np.float32); s.y = arr("y", np.float32); s.octave = arr("octave", np.int32); s.angle = arr("angle", np.float32)
+    s.u_right = arr("u_right", np.float32); s.desc = arr("desc", np.uint8); s.occupied = arr("occupied", np.uint8)
+    s.n = len(keep["x"])
+    s.min_x, s.min_y, s.max_x, s.max_y = [float(v) for v in d["bounds"]]
+    return s, keep
+
+
+def make_proj_points(d, cls=None):
+    keep = {}
+    def arr(k, dt):
+        keep[k] = np.ascontiguousarray(d[k], dtype=dt); return keep[k].ctypes.data
+    s = (cls or ProjPoints)()
+    s.u = arr("u", np.float32); s.v = arr("v", np.float32); s.aux = arr("aux", np.float32); s.level = arr("level", np.int32)
+    s.angle = arr("angle", np.float32); s.view_cos = arr("view_cos", np.float32); s.desc = arr("desc", np.uint8)
+    s.valid = arr("valid", np.uint8); s.has_obs = arr("has_obs", np.uint8)
+    s.n = len(keep["u"])
+    return s, keep
+
+
 class FeatSet(C.Structure):
     _fields_ = [("n", C.c_int), ("desc", C.c_void_p), ("nnodes", C.c_int), ("node_id", C.c_void_p),
                 ("node_off", C.c_void_p), ("feat", C.c_void_p), ("flag", C.c_void_p), ("angle", C.c_void_p),
@@ -79,6 +115,8 @@ def lib():
         L.oracle_vocab_words.argtypes = [C.c_void_p]
         L.oracle_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.POINTER(C.c_int)] + [C.c_void_p] * 3 + [C.POINTER(C.c_int)]
         L.oracle_distinctive_descriptor.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_search_by_projection_last.argtypes = [C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.oracle_search_by_projection_points.argtypes = [C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.oracle_three_maxima.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _lib = L
     return _lib
@@ -237,3 +275,19 @@ class Vocabulary:
 def distinctive_descriptor(desc):
     desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
     return lib().oracle_distinctive_descriptor(_p(desc), len(desc))
+
+
+def search_by_projection_last(cur, pts, scale_factors, th, direction, mbf, check_ori):
+    a, ka = make_frame_feats(cur); b, kb = make_proj_points(pts)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    out = np.full(a.n, -1, np.int32)
+    n = lib().oracle_search_by_projection_last(C.byref(a), C.byref(b), _p(sf), th, direction, mbf, int(check_ori), _p(out))
+    return out, n
+
+
+def search_by_projection_points(cur, pts, scale_factors, th, nnratio):
+    a, ka = make_frame_feats(cur); b, kb = make_proj_points(pts)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    out = np.full(a.n, -1, np.int32)
+    n = lib().oracle_search_by_projection_points(C.byref(a), C.byref(b), _p(sf), th, nnratio, _p(out))
+    return out, n

@@ -1181,3 +1181,156 @@ int oracle_distinctive_descriptor(const uint8_t *desc, int n)
     free(row); free(dist);
     return best_idx;
 }
+
+/* ------------------------------------------------------------------ projection-guided searches (f1) */
+
+enum { GRID_COLS = 64, GRID_ROWS = 48 }; /* include/Frame.h:37-38 */
+
+typedef struct { int *idx; int n, cap; } gcell;
+typedef struct { gcell c[GRID_COLS][GRID_ROWS]; float inv_w, inv_h; } fgrid;
+
+/* Frame::AssignFeaturesToGrid + PosInGrid, src/Frame.cc:261-279, :444-457 */
+static fgrid *grid_build(const oracle_frame_feats *f)
+{
+    fgrid *g = calloc(1, sizeof *g);
+    g->inv_w = (float)GRID_COLS / (f->max_x - f->min_x); /* :164-165 */
+    g->inv_h = (float)GRID_ROWS / (f->max_y - f->min_y);
+    for (int i = 0; i < f->n; i++) {
+        const int px = (int)roundf((f->x[i] - f->min_x) * g->inv_w);
+        const int py = (int)roundf((f->y[i] - f->min_y) * g->inv_h);
+        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;
+        gcell *c = &g->c[px][py];
+        if (c->n == c->cap) { c->cap = c->cap ? 2 * c->cap : 4; c->idx = realloc(c->idx, sizeof(int) * c->cap); }
+        c->idx[c->n++] = i;
+    }
+    return g;
+}
+static void grid_free(fgrid *g)
+{
+    for (int i = 0; i < GRID_COLS; i++) for (int j = 0; j < GRID_ROWS; j++) free(g->c[i][j].idx);
+    free(g);
+}
+/* Frame::GetFeaturesInArea, src/Frame.cc:386-442; returns the number of indices written to out (capacity f->n) */
+static int features_in_area(const oracle_frame_feats *f, const fgrid *g, float x, float y, float r, int min_level, int max_level, int *out)
+{
+    int n = 0;
+    const int min_cx = (int)floorf((x - f->min_x - r) * g->inv_w) > 0 ? (int)floorf((x - f->min_x - r) * g->inv_w) : 0;
+    if (min_cx >= GRID_COLS) return 0;
+    int max_cx = (int)ceilf((x - f->min_x + r) * g->inv_w);
+    if (max_cx > GRID_COLS - 1) max_cx = GRID_COLS - 1;
+    if (max_cx < 0) return 0;
+    const int min_cy = (int)floorf((y - f->min_y - r) * g->inv_h) > 0 ? (int)floorf((y - f->min_y - r) * g->inv_h) : 0;
+    if (min_cy >= GRID_ROWS) return 0;
+    int max_cy = (int)ceilf((y - f->min_y + r) * g->inv_h);
+    if (max_cy > GRID_ROWS - 1) max_cy = GRID_ROWS - 1;
+    if (max_cy < 0) return 0;
+    const int check_levels = (min_level > 0) || (max_level >= 0);
+    for (int ix = min_cx; ix <= max_cx; ix++)
+        for (int iy = min_cy; iy <= max_cy; iy++) {
+            const gcell *c = &g->c[ix][iy];
+            for (int j = 0; j < c->n; j++) {
+                const int k = c->idx[j];
+                if (check_levels) {
+                    if (f->octave[k] < min_level) continue;
+                    if (max_level >= 0 && f->octave[k] > max_level) continue;
+                }
+                const float distx = f->x[k] - x, disty = f->y[k] - y;
+                if (fabsf(distx) < r && fabsf(disty) < r) out[n++] = k;
+            }
+        }
+    return n;
+}
+
+/* src/ORBmatcher.cc:1396-1553 */
+int oracle_search_by_projection_last(const oracle_frame_feats *cur, const oracle_proj_points *pts, const float *sf,
+                                     float th, int direction, float mbf, int check_ori, int32_t *match_cur)
+{
+    fgrid *g = grid_build(cur);
+    int *cand = malloc(sizeof(int) * (cur->n ? cur->n : 1));
+    uint8_t *blocked = malloc(cur->n ? cur->n : 1); /* current holder has Observations() > 0 */
+    for (int i = 0; i < cur->n; i++) { match_cur[i] = -1; blocked[i] = cur->occupied[i]; }
+    rot_hist rh; memset(&rh, 0, sizeof rh);
+    int nmatches = 0;
+    for (int i = 0; i < pts->n; i++) {
+        if (!pts->valid[i]) continue;
+        const float invzc = pts->aux[i];
+        if (invzc < 0) continue;
+        const float u = pts->u[i], v = pts->v[i];
+        if (u < cur->min_x || u > cur->max_x) continue;
+        if (v < cur->min_y || v > cur->max_y) continue;
+        const int oct = pts->level[i];
+        const float radius = th * sf[oct];
+        int nc;
+        if (direction == 1) nc = features_in_area(cur, g, u, v, radius, oct, -1, cand);
+        else if (direction == 2) nc = features_in_area(cur, g, u, v, radius, 0, oct, cand);
+        else nc = features_in_area(cur, g, u, v, radius, oct - 1, oct + 1, cand);
+        if (nc == 0) continue;
+        int best_dist = 256, best_idx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = cand[c];
+            if (blocked[i2]) continue;
+            if (cur->u_right[i2] > 0) {
+                const float ur = u - mbf * invzc;
+                const float er = fabsf(ur - cur->u_right[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = oracle_hamming(pts->desc + (size_t)i * 32, cur->desc + (size_t)i2 * 32);
+            if (dist < best_dist) { best_dist = dist; best_idx = i2; }
+        }
+        if (best_dist <= TH_HIGH) {
+            match_cur[best_idx] = i;
+            blocked[best_idx] = pts->has_obs[i];
+            nmatches++;
+            if (check_ori) rh_push(&rh, rot_bin(pts->angle[i], cur->angle[best_idx]), best_idx);
+        }
+    }
+    if (check_ori) nmatches -= rh_filter(&rh, match_cur);
+    grid_free(g); free(cand); free(blocked);
+    return nmatches;
+}
+
+/* src/ORBmatcher.cc:48-129 (+ RadiusByViewingCos :131-137) */
+int oracle_search_by_projection_points(const oracle_frame_feats *cur, const oracle_proj_points *pts, const float *sf,
+                                       float th, float nnratio, int32_t *match_cur)
+{
+    fgrid *g = grid_build(cur);
+    int *cand = malloc(sizeof(int) * (cur->n ? cur->n : 1));
+    uint8_t *blocked = malloc(cur->n ? cur->n : 1);
+    for (int i = 0; i < cur->n; i++) { match_cur[i] = -1; blocked[i] = cur->occupied[i]; }
+    int nmatches = 0;
+    const int b_factor = (double)th != 1.0;
+    for (int i = 0; i < pts->n; i++) {
+        if (!pts->valid[i]) continue;
+        const int level = pts->level[i];
+        float r = (double)pts->view_cos[i] > 0.998 ? 2.5f : 4.0f;
+        if (b_factor) r *= th;
+        const int nc = features_in_area(cur, g, pts->u[i], pts->v[i], r * sf[level], level - 1, level, cand);
+        if (nc == 0) continue;
+        int best_dist = 256, best_level = -1, best_dist2 = 256, best_level2 = -1, best_idx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            if (blocked[idx]) continue;
+            if (cur->u_right[idx] > 0) {
+                const float er = fabsf(pts->aux[i] - cur->u_right[idx]);
+                if (er > r * sf[level]) continue;
+            }
+            const int dist = oracle_hamming(pts->desc + (size_t)i * 32, cur->desc + (size_t)idx * 32);
+            if (dist < best_dist) {
+                best_dist2 = best_dist; best_dist = dist;
+                best_level2 = best_level; best_level = cur->octave[idx];
+                best_idx = idx;
+            } else if (dist < best_dist2) {
+                best_level2 = cur->octave[idx];
+                best_dist2 = dist;
+            }
+        }
+        if (best_dist <= TH_HIGH) {
+            if (best_level == best_level2 && (float)best_dist > nnratio * (float)best_dist2) continue;
+            match_cur[best_idx] = i;
+            blocked[best_idx] = pts->has_obs[i];
+            nmatches++;
+        }
+    }
+    grid_free(g); free(cand); free(blocked);
+    return nmatches;
+}

@@ -136,6 +136,39 @@ int oracle_bow_transform(const oracle_vocab *v, const uint8_t *desc, int n, int 
  * descriptors of its (non-bad) observations in std::map iteration order; returns BestIdx (-1 if n == 0). */
 int oracle_distinctive_descriptor(const uint8_t *desc, int n);
 
+/* ---- projection-guided searches: the two per-frame tracking matchers */
+typedef struct {            /* the current Frame */
+    int n;
+    const float *x, *y;     /* mvKeysUn[i].pt */
+    const int32_t *octave;  /* mvKeysUn[i].octave */
+    const float *angle;     /* mvKeysUn[i].angle */
+    const float *u_right;   /* mvuRight */
+    const uint8_t *desc;    /* mDescriptors [n][32] */
+    const uint8_t *occupied;/* 1: mvpMapPoints[i] != NULL with Observations() > 0 before the call */
+    float min_x, min_y, max_x, max_y; /* mnMinX, mnMinY, mnMaxX, mnMaxY */
+} oracle_frame_feats;
+typedef struct {            /* the projected map points, in the reference's iteration order */
+    int n;
+    const float *u, *v;     /* projection into the current frame (A: u,v of :1428-1429; B: mTrackProjX/Y) */
+    const float *aux;       /* A: invzc (:1425) ; B: mTrackProjXR */
+    const int32_t *level;   /* A: LastFrame.mvKeys[i].octave ; B: mnTrackScaleLevel */
+    const float *angle;     /* A: LastFrame.mvKeysUn[i].angle */
+    const float *view_cos;  /* B: mTrackViewCos */
+    const uint8_t *desc;    /* pMP->GetDescriptor() [n][32] */
+    const uint8_t *valid;   /* A: pMP && !mvbOutlier ; B: mbTrackInView && !isBad() */
+    const uint8_t *has_obs; /* pMP->Observations() > 0 */
+} oracle_proj_points;
+/* Frame::AssignFeaturesToGrid + PosInGrid + GetFeaturesInArea restated inside both searches
+ * (src/Frame.cc:261-279, :386-457).
+ * ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono), src/ORBmatcher.cc:1396-1553.
+ * direction: 0 none, 1 bForward, 2 bBackward (:1412-1413, computed by the caller).
+ * match_cur[cur->n] = index of the point finally held by each current feature, or -1; returns nmatches. */
+int oracle_search_by_projection_last(const oracle_frame_feats *cur, const oracle_proj_points *pts, const float *scale_factors,
+                                     float th, int direction, float mbf, int check_ori, int32_t *match_cur);
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), src/ORBmatcher.cc:48-129 */
+int oracle_search_by_projection_points(const oracle_frame_feats *cur, const oracle_proj_points *pts, const float *scale_factors,
+                                       float th, float nnratio, int32_t *match_cur);
+
 /* ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1687-1728 */
 void oracle_three_maxima(const int *count, int L, int *ind1, int *ind2, int *ind3);
 

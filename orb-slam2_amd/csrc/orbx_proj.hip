@@ -1,0 +1,437 @@
+// orbx_proj.hip — the two per-frame projection-guided matchers of ORB-SLAM2's tracking thread
+// (SURVEY.md 8f row f1):
+//   ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)        reference src/ORBmatcher.cc:1396-1553
+//   ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)   reference src/ORBmatcher.cc:48-129
+// with Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea (src/Frame.cc:261-279, :386-457).
+//
+// The reference walks the map points sequentially and lets every accepted match claim its feature
+// (later points skip features whose holder has Observations() > 0), so the result depends on the order.
+// Exact parallel form: the per-point candidate lists (window, level, uRight tests and Hamming distances) do
+// not depend on the claims and are built in parallel, in GetFeaturesInArea's traversal order; the claims are
+// then the unique fixpoint of
+//     choice(i) = best candidate f of i with  !occupied(f)  and no j < i, has_obs(j), choice(j) == f,
+// a recursion on i, reached by iterating all points in parallel until nothing changes (at most one round
+// per link of the longest conflict chain).  Projections (u, v, 1/z) come from the adaptor, which has the
+// poses: restating cv::gemm's accumulation is not needed.
+#include "orbx_device.h"
+#include <string.h>
+#include <vector>
+
+#define PG_COLS 64 // FRAME_GRID_COLS, include/Frame.h:38
+#define PG_ROWS 48 // FRAME_GRID_ROWS, include/Frame.h:37
+#define PG_CELLS (PG_COLS * PG_ROWS)
+
+struct DevFrame {
+    int n;
+    const float *x, *y, *angle, *u_right;
+    const int32_t *octave;
+    const uint32_t *desc;
+    const uint8_t *occupied;
+    float min_x, min_y, max_x, max_y, inv_w, inv_h;
+};
+struct DevPoints {
+    int n;
+    const float *u, *v, *aux, *angle, *view_cos;
+    const int32_t *level;
+    const uint32_t *desc;
+    const uint8_t *valid, *has_obs;
+};
+struct ProjParams {
+    int mode;          // 0: last frame (A), 1: map points (B)
+    float th, mbf, nnratio;
+    int direction, check_ori;
+    float sf[ORBX_MAX_LEVELS];
+};
+
+// ---- Frame::AssignFeaturesToGrid: CSR over the 64x48 cells, ascending feature index inside a cell
+__global__ __launch_bounds__(256) void k_grid_build(DevFrame F, int *__restrict__ cell_off, int *__restrict__ cell_idx)
+{
+    __shared__ int cnt[PG_CELLS];
+    __shared__ int cur[PG_CELLS];
+    __shared__ int s_w[4];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < PG_CELLS; c += 256) { cnt[c] = 0; cur[c] = 0; }
+    __syncthreads();
+    for (int i = tid; i < F.n; i += 256) {
+        const int px = (int)roundf((F.x[i] - F.min_x) * F.inv_w), py = (int)roundf((F.y[i] - F.min_y) * F.inv_h); // PosInGrid :444-457
+        if (px >= 0 && px < PG_COLS && py >= 0 && py < PG_ROWS) atomicAdd(&cnt[px * PG_ROWS + py], 1);
+    }
+    __syncthreads();
+    const int total = lds_excl_scan(cnt, PG_CELLS, s_w);
+    for (int c = tid; c < PG_CELLS; c += 256) cell_off[c] = cnt[c];
+    if (tid == 0) cell_off[PG_CELLS] = total;
+    for (int i = tid; i < F.n; i += 256) {
+        const int px = (int)roundf((F.x[i] - F.min_x) * F.inv_w), py = (int)roundf((F.y[i] - F.min_y) * F.inv_h);
+        if (px >= 0 && px < PG_COLS && py >= 0 && py < PG_ROWS) {
+            const int c = px * PG_ROWS + py;
+            cell_idx[cnt[c] + atomicAdd(&cur[c], 1)] = i;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int c = tid; c < PG_CELLS; c += 256) { // push_back order = ascending i: insertion sort of the (short) cell list
+        const int b = cnt[c], e = b + cur[c];
+        for (int a = b + 1; a < e; a++) {
+            const int v = cell_idx[a];
+            int j = a - 1;
+            while (j >= b && cell_idx[j] > v) { cell_idx[j + 1] = cell_idx[j]; j--; }
+            cell_idx[j + 1] = v;
+        }
+    }
+}
+
+// window of a point: radius, level range, cell range; false if the point takes no part
+struct Win { float u, v, r; int min_l, max_l, cx0, cx1, cy0, cy1; };
+
+__device__ __forceinline__ bool point_window(const DevFrame &F, const DevPoints &P, const ProjParams &pp, int i, Win *w)
+{
+    if (!P.valid[i]) return false;
+    const float u = P.u[i], v = P.v[i];
+    const int lvl = P.level[i] & (ORBX_MAX_LEVELS - 1);
+    float r;
+    int min_l, max_l;
+    if (pp.mode == 0) {
+        if (P.aux[i] < 0) return false;                                // invzc < 0 (:1426)
+        if (u < F.min_x || u > F.max_x || v < F.min_y || v > F.max_y) return false; // :1431-1434
+        r = pp.th * pp.sf[lvl];                                        // :1439
+        if (pp.direction == 1) { min_l = lvl; max_l = -1; }            // bForward  (:1443)
+        else if (pp.direction == 2) { min_l = 0; max_l = lvl; }        // bBackward (:1445)
+        else { min_l = lvl - 1; max_l = lvl + 1; }
+    } else {
+        float rr = (double)P.view_cos[i] > 0.998 ? 2.5f : 4.0f;        // RadiusByViewingCos (:131-137)
+        if ((double)pp.th != 1.0) rr *= pp.th;                         // bFactor (:52, :66-67)
+        r = rr * pp.sf[lvl];
+        min_l = lvl - 1; max_l = lvl;
+    }
+    // GetFeaturesInArea cell range (src/Frame.cc:391-406)
+    const int a = (int)floorf((u - F.min_x - r) * F.inv_w);
+    const int cx0 = a > 0 ? a : 0;
+    if (cx0 >= PG_COLS) return false;
+    int cx1 = (int)ceilf((u - F.min_x + r) * F.inv_w);
+    cx1 = cx1 < PG_COLS - 1 ? cx1 : PG_COLS - 1;
+    if (cx1 < 0) return false;
+    const int b = (int)floorf((v - F.min_y - r) * F.inv_h);
+    const int cy0 = b > 0 ? b : 0;
+    if (cy0 >= PG_ROWS) return false;
+    int cy1 = (int)ceilf((v - F.min_y + r) * F.inv_h);
+    cy1 = cy1 < PG_ROWS - 1 ? cy1 : PG_ROWS - 1;
+    if (cy1 < 0) return false;
+    w->u = u; w->v = v; w->r = r; w->min_l = min_l; w->max_l = max_l;
+    w->cx0 = cx0; w->cx1 = cx1; w->cy0 = cy0; w->cy1 = cy1;
+    return true;
+}
+
+// claim-independent part of the candidate test: level range, box, right-image coordinate
+__device__ __forceinline__ bool cand_ok(const DevFrame &F, const DevPoints &P, const ProjParams &pp, const Win &w, int i, int k)
+{
+    const int oct = F.octave[k];
+    if (w.min_l > 0 || w.max_l >= 0) { // bCheckLevels (:408)
+        if (oct < w.min_l) return false;
+        if (w.max_l >= 0 && oct > w.max_l) return false;
+    }
+    const float distx = F.x[k] - w.u, disty = F.y[k] - w.v;
+    if (!(fabsf(distx) < w.r && fabsf(disty) < w.r)) return false; // :434
+    const float ur_k = F.u_right[k];
+    if (ur_k > 0) {
+        if (pp.mode == 0) {
+            const float ur = w.u - pp.mbf * P.aux[i];                  // :1467-1471
+            if (fabsf(ur - ur_k) > w.r) return false;
+        } else {
+            if (fabsf(P.aux[i] - ur_k) > w.r) return false;            // :88-92 (r * scale == w.r)
+        }
+    }
+    return true;
+}
+
+// pass 0: count the candidates of every point; pass 1: write them (feature | dist<<16 | octave<<25) in
+// GetFeaturesInArea order (ix, iy, position in cell)
+template <int PASS>
+__global__ __launch_bounds__(64) void k_proj_lists(DevFrame F, DevPoints P, ProjParams pp, const int *__restrict__ cell_off,
+                                                   const int *__restrict__ cell_idx, int *__restrict__ cnt_or_off,
+                                                   uint32_t *__restrict__ entries)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= P.n) return;
+    Win w;
+    int n = 0;
+    if (point_window(F, P, pp, i, &w)) {
+        uint32_t d[8];
+        if (PASS == 1) {
+            const uint4 *s = reinterpret_cast<const uint4 *>(P.desc + (long long)i * 8);
+            const uint4 v0 = s[0], v1 = s[1];
+            d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
+        }
+        const int base = PASS == 1 ? cnt_or_off[i] : 0;
+        for (int ix = w.cx0; ix <= w.cx1; ix++)
+            for (int iy = w.cy0; iy <= w.cy1; iy++) {
+                const int c = ix * PG_ROWS + iy;
+                for (int j = cell_off[c]; j < cell_off[c + 1]; j++) {
+                    const int k = cell_idx[j];
+                    if (!cand_ok(F, P, pp, w, i, k)) continue;
+                    if (PASS == 1) {
+                        const uint4 *s = reinterpret_cast<const uint4 *>(F.desc + (long long)k * 8);
+                        const uint4 v0 = s[0], v1 = s[1];
+                        const int dist = __popc(d[0] ^ v0.x) + __popc(d[1] ^ v0.y) + __popc(d[2] ^ v0.z) + __popc(d[3] ^ v0.w) +
+                                         __popc(d[4] ^ v1.x) + __popc(d[5] ^ v1.y) + __popc(d[6] ^ v1.z) + __popc(d[7] ^ v1.w);
+                        entries[base + n] = (uint32_t)k | ((uint32_t)dist << 16) | ((uint32_t)(F.octave[k] & 31) << 25);
+                    }
+                    n++;
+                }
+            }
+    }
+    if (PASS == 0) cnt_or_off[i] = n;
+}
+
+__global__ __launch_bounds__(256) void k_proj_scan(int n, int *__restrict__ cnt_io, int *__restrict__ total)
+{
+    extern __shared__ __align__(16) int scan_smem[];
+    __shared__ int s_w[4];
+    for (int i = threadIdx.x; i < n; i += 256) scan_smem[i] = cnt_io[i];
+    __syncthreads();
+    const int t = lds_excl_scan(scan_smem, n, s_w);
+    for (int i = threadIdx.x; i < n; i += 256) cnt_io[i] = scan_smem[i];
+    if (threadIdx.x == 0) { cnt_io[n] = t; *total = t; }
+}
+
+// the claim fixpoint + output, one workgroup
+__global__ __launch_bounds__(1024) void k_proj_resolve(DevFrame F, DevPoints P, ProjParams pp, const int *__restrict__ off,
+                                                       const uint32_t *__restrict__ entries, int *__restrict__ choice_a,
+                                                       int *__restrict__ choice_b, int *__restrict__ owner,
+                                                       int32_t *__restrict__ match, int *__restrict__ out_n)
+{
+    __shared__ int s_changed, s_cnt;
+    __shared__ int hist[30];
+    __shared__ int keep3[3];
+    const int tid = threadIdx.x, nt = 1024;
+    int *cur = choice_a, *nxt = choice_b;
+    for (int i = tid; i < P.n; i += nt) cur[i] = -1;
+    __syncthreads();
+    for (int round = 0; round <= P.n; round++) {
+        for (int f = tid; f < F.n; f += nt) owner[f] = 0x7FFFFFFF;
+        if (tid == 0) s_changed = 0;
+        __threadfence_block();
+        __syncthreads();
+        for (int i = tid; i < P.n; i += nt)
+            if (cur[i] >= 0 && P.has_obs[i]) atomicMin(&owner[cur[i]], i);
+        __threadfence_block();
+        __syncthreads();
+        int changed = 0;
+        for (int i = tid; i < P.n; i += nt) {
+            int b1 = 256, b2 = 256, l1 = -1, l2 = -1, bi = -1;
+            for (int e = off[i]; e < off[i + 1]; e++) {
+                const uint32_t en = entries[e];
+                const int f = en & 0xFFFF, dist = (en >> 16) & 0x1FF, lv = en >> 25;
+                // owner[] was written by L2-side atomics: read it past this CU's L1 (agent-scope load)
+                if (F.occupied[f] || __hip_atomic_load(&owner[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < i) continue; // holder has Observations() > 0
+                if (dist < b1) { b2 = b1; l2 = l1; b1 = dist; l1 = lv; bi = f; }
+                else if (dist < b2) { b2 = dist; l2 = lv; }
+            }
+            int c = -1;
+            if (b1 <= 100) { // TH_HIGH
+                if (pp.mode == 0) c = bi;
+                else if (!(l1 == l2 && (float)b1 > pp.nnratio * (float)b2)) c = bi; // :117-121
+            }
+            nxt[i] = c;
+            changed |= c != cur[i];
+        }
+        if (changed) atomicOr(&s_changed, 1);
+        __threadfence_block();
+        __syncthreads();
+        { int *t = cur; cur = nxt; nxt = t; }
+        if (!s_changed) break;
+        __syncthreads();
+    }
+    // ---- outputs: a feature ends up with the LAST point that chose it (:1488 overwrites); every choice counts
+    for (int f = tid; f < F.n; f += nt) match[f] = -1;
+    if (tid < 30) hist[tid] = 0;
+    if (tid == 0) s_cnt = 0;
+    __threadfence_block();
+    __syncthreads();
+    int local = 0;
+    for (int i = tid; i < P.n; i += nt) {
+        const int f = cur[i];
+        if (f < 0) continue;
+        atomicMax(&match[f], i);
+        local++;
+        if (pp.mode == 0 && pp.check_ori) {
+            float rot = P.angle[i] - F.angle[f];               // :1493-1500
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * (1.0f / 30));
+            if (bin == 30) bin = 0;
+            bin = (unsigned)bin < 30u ? bin : 0;
+            atomicAdd(&hist[bin], 1);
+            nxt[i] = bin;
+        }
+    }
+    if (local) atomicAdd(&s_cnt, local);
+    __threadfence_block();
+    __syncthreads();
+    if (pp.mode == 0 && pp.check_ori) {
+        if (tid == 0) { // ComputeThreeMaxima (:1687-1728)
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < 30; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+                else if (s > max3) { max3 = s; i3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+            keep3[0] = i1; keep3[1] = i2; keep3[2] = i3;
+        }
+        __syncthreads();
+        int removed = 0;
+        for (int i = tid; i < P.n; i += nt) {
+            const int f = cur[i];
+            if (f < 0) continue;
+            const int b = nxt[i];
+            if (b != keep3[0] && b != keep3[1] && b != keep3[2]) { match[f] = -1; removed++; } // :1518-1523, one decrement per entry
+        }
+        if (removed) atomicSub(&s_cnt, removed);
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid == 0) *out_n = s_cnt;
+}
+
+// ---------------------------------------------------------------- host side
+
+struct ProjCtx {
+    hipStream_t stream = nullptr;
+    uint8_t *h_blob = nullptr, *d_blob = nullptr; size_t cap = 0;
+    uint8_t *d_work = nullptr; size_t work_cap = 0;
+    uint32_t *d_entries = nullptr; size_t ent_cap = 0;
+    int32_t *h_out = nullptr; size_t out_cap = 0;
+};
+static thread_local ProjCtx g_proj[16];
+
+static size_t pa16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+static int proj_run(int device, const orbx_frame_feats *cur, const orbx_proj_points *pts, const float *sf, int nlevels,
+                    const ProjParams &pp_in, int32_t *match_cur, int *nmatches)
+{
+    if (!cur || !pts || !sf || !match_cur || !nmatches || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || cur->n < 0 || pts->n < 0 ||
+        cur->n >= 65536 || pts->n > (1 << 20)) {
+        orbx_set_error("search_by_projection: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    if (cur->n && (!cur->x || !cur->y || !cur->octave || !cur->angle || !cur->u_right || !cur->desc || !cur->occupied)) { orbx_set_error("frame arrays missing"); return ORBX_E_INVALID; }
+    if (pts->n && (!pts->u || !pts->v || !pts->aux || !pts->level || !pts->desc || !pts->valid || !pts->has_obs ||
+                   (pp_in.mode == 0 && !pts->angle) || (pp_in.mode == 1 && !pts->view_cos))) { orbx_set_error("point arrays missing"); return ORBX_E_INVALID; }
+    if (!(cur->max_x > cur->min_x) || !(cur->max_y > cur->min_y)) { orbx_set_error("empty image bounds"); return ORBX_E_INVALID; }
+    for (int i = 0; i < pts->n; i++)
+        if (pts->valid[i] && (pts->level[i] < 0 || pts->level[i] >= nlevels)) { orbx_set_error("point %d: level %d out of range", i, pts->level[i]); return ORBX_E_INVALID; }
+    for (int i = 0; i < cur->n; i++) match_cur[i] = -1;
+    *nmatches = 0;
+    if (cur->n == 0 || pts->n == 0) return ORBX_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || device >= 16) {
+        orbx_set_error("no usable HIP device %d (liborbx has no CPU fallback)", device);
+        return ORBX_E_NO_DEVICE;
+    }
+    ORBX_HIP(hipSetDevice(device));
+    ProjCtx *c = &g_proj[device];
+    if (!c->stream) ORBX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t nc = (size_t)cur->n, np = (size_t)pts->n;
+    // blob: frame arrays then point arrays
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t r = o; o += pa16(bytes); return r; };
+    const size_t fx = take(4 * nc), fy = take(4 * nc), fo = take(4 * nc), fa = take(4 * nc), fu = take(4 * nc), fd = take(32 * nc), fq = take(nc);
+    const size_t pu = take(4 * np), pv = take(4 * np), pa = take(4 * np), pl = take(4 * np), pg = take(4 * np), pc = take(4 * np),
+                 pd = take(32 * np), pval = take(np), pobs = take(np);
+    const size_t blob = o;
+    if (blob > c->cap) {
+        if (c->h_blob) ORBX_HIP(hipHostFree(c->h_blob));
+        if (c->d_blob) ORBX_HIP(hipFree(c->d_blob));
+        c->h_blob = nullptr; c->d_blob = nullptr;
+        ORBX_HIP(hipHostMalloc((void **)&c->h_blob, blob * 2, hipHostMallocDefault));
+        ORBX_HIP(hipMalloc((void **)&c->d_blob, blob * 2));
+        c->cap = blob * 2;
+    }
+    uint8_t *h = c->h_blob;
+    memcpy(h + fx, cur->x, 4 * nc); memcpy(h + fy, cur->y, 4 * nc); memcpy(h + fo, cur->octave, 4 * nc);
+    memcpy(h + fa, cur->angle, 4 * nc); memcpy(h + fu, cur->u_right, 4 * nc); memcpy(h + fd, cur->desc, 32 * nc); memcpy(h + fq, cur->occupied, nc);
+    memcpy(h + pu, pts->u, 4 * np); memcpy(h + pv, pts->v, 4 * np); memcpy(h + pa, pts->aux, 4 * np); memcpy(h + pl, pts->level, 4 * np);
+    if (pts->angle) memcpy(h + pg, pts->angle, 4 * np); else memset(h + pg, 0, 4 * np);
+    if (pts->view_cos) memcpy(h + pc, pts->view_cos, 4 * np); else memset(h + pc, 0, 4 * np);
+    memcpy(h + pd, pts->desc, 32 * np); memcpy(h + pval, pts->valid, np); memcpy(h + pobs, pts->has_obs, np);
+    ORBX_HIP(hipMemcpyAsync(c->d_blob, h, blob, hipMemcpyHostToDevice, c->stream));
+    const uint8_t *d = c->d_blob;
+    DevFrame F;
+    F.n = cur->n; F.x = (const float *)(d + fx); F.y = (const float *)(d + fy); F.octave = (const int32_t *)(d + fo);
+    F.angle = (const float *)(d + fa); F.u_right = (const float *)(d + fu); F.desc = (const uint32_t *)(d + fd); F.occupied = d + fq;
+    F.min_x = cur->min_x; F.min_y = cur->min_y; F.max_x = cur->max_x; F.max_y = cur->max_y;
+    F.inv_w = (float)PG_COLS / (cur->max_x - cur->min_x);  // src/Frame.cc:164-165
+    F.inv_h = (float)PG_ROWS / (cur->max_y - cur->min_y);
+    DevPoints P;
+    P.n = pts->n; P.u = (const float *)(d + pu); P.v = (const float *)(d + pv); P.aux = (const float *)(d + pa);
+    P.level = (const int32_t *)(d + pl); P.angle = (const float *)(d + pg); P.view_cos = (const float *)(d + pc);
+    P.desc = (const uint32_t *)(d + pd); P.valid = d + pval; P.has_obs = d + pobs;
+    ProjParams pp = pp_in;
+    for (int i = 0; i < ORBX_MAX_LEVELS; i++) pp.sf[i] = i < nlevels ? sf[i] : 0.f;
+    // work: cell_off[3073] | cell_idx[nc] | off[np+1] | total | choice_a[np] | choice_b[np] | owner[nc] | match[nc] | out_n
+    size_t w = 0;
+    auto wtake = [&](size_t bytes) { const size_t r = w; w += pa16(bytes); return r; };
+    const size_t w_coff = wtake(4 * (PG_CELLS + 1)), w_cidx = wtake(4 * nc), w_off = wtake(4 * (np + 1)), w_tot = wtake(16),
+                 w_ca = wtake(4 * np), w_cb = wtake(4 * np), w_own = wtake(4 * nc), w_match = wtake(4 * nc), w_n = wtake(16);
+    if (w > c->work_cap) {
+        if (c->d_work) ORBX_HIP(hipFree(c->d_work));
+        c->d_work = nullptr;
+        ORBX_HIP(hipMalloc((void **)&c->d_work, w * 2));
+        c->work_cap = w * 2;
+    }
+    if ((nc + 4) > c->out_cap) {
+        if (c->h_out) ORBX_HIP(hipHostFree(c->h_out));
+        c->h_out = nullptr;
+        ORBX_HIP(hipHostMalloc((void **)&c->h_out, sizeof(int32_t) * (nc + 4) * 2, hipHostMallocDefault));
+        c->out_cap = (nc + 4) * 2;
+    }
+    uint8_t *wk = c->d_work;
+    int *d_coff = (int *)(wk + w_coff), *d_cidx = (int *)(wk + w_cidx), *d_off = (int *)(wk + w_off), *d_tot = (int *)(wk + w_tot);
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, c->stream, F, d_coff, d_cidx);
+    hipLaunchKernelGGL(k_proj_lists<0>, dim3((pts->n + 63) / 64), dim3(64), 0, c->stream, F, P, pp, d_coff, d_cidx, d_off, (uint32_t *)nullptr);
+    const size_t scan_lds = sizeof(int) * (np + 4);
+    if (scan_lds > 150 * 1024) { orbx_set_error("too many points for one search"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
+    hipLaunchKernelGGL(k_proj_scan, dim3(1), dim3(256), scan_lds, c->stream, pts->n, d_off, d_tot);
+    ORBX_HIP(hipMemcpyAsync(c->h_out, d_tot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    ORBX_HIP(hipStreamSynchronize(c->stream));
+    const size_t total = (size_t)c->h_out[0];
+    if (total > c->ent_cap || !c->d_entries) {
+        if (c->d_entries) ORBX_HIP(hipFree(c->d_entries));
+        c->d_entries = nullptr;
+        ORBX_HIP(hipMalloc((void **)&c->d_entries, sizeof(uint32_t) * (total + 16) * 2));
+        c->ent_cap = (total + 16) * 2;
+    }
+    hipLaunchKernelGGL(k_proj_lists<1>, dim3((pts->n + 63) / 64), dim3(64), 0, c->stream, F, P, pp, d_coff, d_cidx, d_off, c->d_entries);
+    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(1024), 0, c->stream, F, P, pp, d_off, c->d_entries, (int *)(wk + w_ca), (int *)(wk + w_cb),
+                       (int *)(wk + w_own), (int32_t *)(wk + w_match), (int *)(wk + w_n));
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(c->h_out, wk + w_match, 4 * nc, hipMemcpyDeviceToHost, c->stream));
+    ORBX_HIP(hipMemcpyAsync(c->h_out + nc, wk + w_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    ORBX_HIP(hipStreamSynchronize(c->stream));
+    memcpy(match_cur, c->h_out, 4 * nc);
+    *nmatches = c->h_out[nc];
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_by_projection_last_frame(int device, const orbx_frame_feats *cur, const orbx_proj_points *pts,
+                                                    const float *scale_factors, int nlevels, float th, int direction, float mbf,
+                                                    int check_orientation, int32_t *match_cur, int *nmatches)
+{
+    if (direction < 0 || direction > 2) { orbx_set_error("direction must be 0 (none), 1 (forward) or 2 (backward)"); return ORBX_E_INVALID; }
+    ProjParams pp;
+    memset(&pp, 0, sizeof pp);
+    pp.mode = 0; pp.th = th; pp.mbf = mbf; pp.direction = direction; pp.check_ori = check_orientation;
+    return proj_run(device, cur, pts, scale_factors, nlevels, pp, match_cur, nmatches);
+}
+
+extern "C" int orbx_search_by_projection_map_points(int device, const orbx_frame_feats *cur, const orbx_proj_points *pts,
+                                                    const float *scale_factors, int nlevels, float th, float nnratio,
+                                                    int32_t *match_cur, int *nmatches)
+{
+    ProjParams pp;
+    memset(&pp, 0, sizeof pp);
+    pp.mode = 1; pp.th = th; pp.nnratio = nnratio;
+    return proj_run(device, cur, pts, scale_factors, nlevels, pp, match_cur, nmatches);
+}

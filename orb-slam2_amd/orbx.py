@@ -24,6 +24,19 @@ class FeatSet(C.Structure):
                 ("x", C.c_void_p), ("y", C.c_void_p), ("octave", C.c_void_p), ("u_right", C.c_void_p)]
 
 
+class FrameFeats(C.Structure):
+    """orbx_frame_feats (include/orbx.h)"""
+    _fields_ = [("n", C.c_int), ("x", C.c_void_p), ("y", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p),
+                ("u_right", C.c_void_p), ("desc", C.c_void_p), ("occupied", C.c_void_p),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float)]
+
+
+class ProjPoints(C.Structure):
+    """orbx_proj_points (include/orbx.h)"""
+    _fields_ = [("n", C.c_int), ("u", C.c_void_p), ("v", C.c_void_p), ("aux", C.c_void_p), ("level", C.c_void_p),
+                ("angle", C.c_void_p), ("view_cos", C.c_void_p), ("desc", C.c_void_p), ("valid", C.c_void_p), ("has_obs", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -77,6 +90,8 @@ def lib():
     L.orbx_vocab_destroy.argtypes = [vp]
     L.orbx_vocab_destroy.restype = None
     L.orbx_bow_transform.argtypes = [vp, vp, i, i, vp, vp, vp, vp, vp, ip, vp, vp, vp, ip]
+    L.orbx_search_by_projection_last_frame.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, i, f, i, f, i, vp, ip]
+    L.orbx_search_by_projection_map_points.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, i, f, f, vp, ip]
     L.orbx_distinctive_descriptors.argtypes = [i, vp, vp, i, vp]
     L.orbx_profile_enable.argtypes = [vp, i]
     L.orbx_profile_read.argtypes = [vp, vp, vp, i]
@@ -345,6 +360,51 @@ class ORBmatcher:
         out = np.full((len(sets), b.n), -1, np.int32); n = np.zeros(len(sets), np.int32)
         _check(lib().orbx_search_by_bow_kf_f_batch(self.device, arr, len(sets), C.byref(b), self.mfNNratio, int(self.mbCheckOrientation), _p(out), _p(n)))
         return out, n
+
+    @staticmethod
+    def _frame(d):
+        keep = {}
+        def arr(k, dt):
+            keep[k] = np.ascontiguousarray(d[k], dtype=dt); return keep[k].ctypes.data
+        s_ = FrameFeats()
+        s_.x = arr("x", np.float32); s_.y = arr("y", np.float32); s_.octave = arr("octave", np.int32); s_.angle = arr("angle", np.float32)
+        s_.u_right = arr("u_right", np.float32); s_.desc = arr("desc", np.uint8); s_.occupied = arr("occupied", np.uint8)
+        s_.n = len(keep["x"])
+        s_.min_x, s_.min_y, s_.max_x, s_.max_y = [float(v) for v in d["bounds"]]
+        return s_, keep
+
+    @staticmethod
+    def _points(d):
+        keep = {}
+        def arr(k, dt):
+            if d.get(k) is None:
+                return None
+            keep[k] = np.ascontiguousarray(d[k], dtype=dt); return keep[k].ctypes.data
+        s_ = ProjPoints()
+        s_.u = arr("u", np.float32); s_.v = arr("v", np.float32); s_.aux = arr("aux", np.float32); s_.level = arr("level", np.int32)
+        s_.angle = arr("angle", np.float32); s_.view_cos = arr("view_cos", np.float32); s_.desc = arr("desc", np.uint8)
+        s_.valid = arr("valid", np.uint8); s_.has_obs = arr("has_obs", np.uint8)
+        s_.n = len(keep["u"])
+        return s_, keep
+
+    def SearchByProjectionLastFrame(self, CurrentFrame, LastFramePoints, scaleFactors, th, direction=0, mbf=0.0):
+        """SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono), src/ORBmatcher.cc:1396-1553
+        -> (match_cur, nmatches)"""
+        a, ka = self._frame(CurrentFrame); b, kb = self._points(LastFramePoints)
+        sf = np.ascontiguousarray(scaleFactors, np.float32)
+        out = np.full(a.n, -1, np.int32); n = C.c_int()
+        _check(lib().orbx_search_by_projection_last_frame(self.device, C.byref(a), C.byref(b), _p(sf), len(sf), th, direction, mbf,
+                                                          int(self.mbCheckOrientation), _p(out), C.byref(n)))
+        return out, n.value
+
+    def SearchByProjectionMapPoints(self, F, vpMapPoints, scaleFactors, th=3.0):
+        """SearchByProjection(Frame &F, const vector<MapPoint*>&, th), src/ORBmatcher.cc:48-129 -> (match_cur, nmatches)"""
+        a, ka = self._frame(F); b, kb = self._points(vpMapPoints)
+        sf = np.ascontiguousarray(scaleFactors, np.float32)
+        out = np.full(a.n, -1, np.int32); n = C.c_int()
+        _check(lib().orbx_search_by_projection_map_points(self.device, C.byref(a), C.byref(b), _p(sf), len(sf), th, self.mfNNratio,
+                                                          _p(out), C.byref(n)))
+        return out, n.value
 
     def SearchForTriangulation(self, pKF1, pKF2, F12, ex, ey, scaleFactors2, levelSigma2_2, bOnlyStereo=False):
         a, ka = make_featset(pKF1); b, kb = make_featset(pKF2)
