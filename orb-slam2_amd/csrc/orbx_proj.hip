@@ -143,86 +143,96 @@ __device__ __forceinline__ bool cand_ok(const DevFrame &F, const DevPoints &P, c
     return true;
 }
 
-// pass 0: count the candidates of every point; pass 1: write them (feature | dist<<16 | octave<<25) in
-// GetFeaturesInArea order (ix, iy, position in cell)
-template <int PASS>
-__global__ __launch_bounds__(64) void k_proj_lists(DevFrame F, DevPoints P, ProjParams pp, const int *__restrict__ cell_off,
-                                                   const int *__restrict__ cell_idx, int *__restrict__ cnt_or_off,
-                                                   uint32_t *__restrict__ entries)
+// Candidate list of every point, one wave per point.  For a fixed grid column ix the cells (ix, cy0..cy1) are
+// consecutive in the CSR, so the window is a handful of contiguous index ranges whose concatenation is exactly
+// GetFeaturesInArea's traversal order (ix, iy, position in cell): lanes stride over a range, test the candidate and
+// compute the Hamming distance, and a ballot keeps the order when the survivors are appended
+// (entry = feature | dist<<16 | octave<<25).  The wave reserves the window's total range length in the pool with
+// one atomicAdd (an upper bound of its list); beg[i] / cnt[i] locate the list.  If the pool overflows the host
+// grows it and repeats the call (pool_used = entries needed).
+__global__ __launch_bounds__(256) void k_proj_lists(DevFrame F, DevPoints P, ProjParams pp, const int *__restrict__ cell_off,
+                                                    const int *__restrict__ cell_idx, int *__restrict__ beg, int *__restrict__ cnt,
+                                                    uint32_t *__restrict__ entries, int pool_cap, int *__restrict__ pool_used)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= P.n) return;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= P.n) return; // wave-uniform
     Win w;
-    int n = 0;
+    int n = 0, base = 0;
     if (point_window(F, P, pp, i, &w)) {
-        uint32_t d[8];
-        if (PASS == 1) {
-            const uint4 *s = reinterpret_cast<const uint4 *>(P.desc + (long long)i * 8);
-            const uint4 v0 = s[0], v1 = s[1];
-            d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
+        int upper = 0;
+        for (int ix = w.cx0; ix <= w.cx1; ix++) upper += cell_off[ix * PG_ROWS + w.cy1 + 1] - cell_off[ix * PG_ROWS + w.cy0];
+        if (upper) {
+            if (lane == 0) base = atomicAdd(pool_used, upper);
+            base = __shfl(base, 0, WAVE);
         }
-        const int base = PASS == 1 ? cnt_or_off[i] : 0;
-        for (int ix = w.cx0; ix <= w.cx1; ix++)
-            for (int iy = w.cy0; iy <= w.cy1; iy++) {
-                const int c = ix * PG_ROWS + iy;
-                for (int j = cell_off[c]; j < cell_off[c + 1]; j++) {
-                    const int k = cell_idx[j];
-                    if (!cand_ok(F, P, pp, w, i, k)) continue;
-                    if (PASS == 1) {
-                        const uint4 *s = reinterpret_cast<const uint4 *>(F.desc + (long long)k * 8);
-                        const uint4 v0 = s[0], v1 = s[1];
-                        const int dist = __popc(d[0] ^ v0.x) + __popc(d[1] ^ v0.y) + __popc(d[2] ^ v0.z) + __popc(d[3] ^ v0.w) +
-                                         __popc(d[4] ^ v1.x) + __popc(d[5] ^ v1.y) + __popc(d[6] ^ v1.z) + __popc(d[7] ^ v1.w);
-                        entries[base + n] = (uint32_t)k | ((uint32_t)dist << 16) | ((uint32_t)(F.octave[k] & 31) << 25);
+        if (upper && base + upper <= pool_cap) {
+            uint32_t d[8];
+            const uint4 *s = reinterpret_cast<const uint4 *>(P.desc + (long long)i * 8);
+            const uint4 q0 = s[0], q1 = s[1];
+            d[0] = q0.x; d[1] = q0.y; d[2] = q0.z; d[3] = q0.w; d[4] = q1.x; d[5] = q1.y; d[6] = q1.z; d[7] = q1.w;
+            for (int ix = w.cx0; ix <= w.cx1; ix++) {
+                const int j0 = cell_off[ix * PG_ROWS + w.cy0], j1 = cell_off[ix * PG_ROWS + w.cy1 + 1];
+                for (int jb = j0; jb < j1; jb += 64) {
+                    const int j = jb + lane;
+                    bool ok = false;
+                    uint32_t en = 0;
+                    if (j < j1) {
+                        const int k = cell_idx[j];
+                        if (cand_ok(F, P, pp, w, i, k)) {
+                            ok = true;
+                            const uint4 *t = reinterpret_cast<const uint4 *>(F.desc + (long long)k * 8);
+                            const uint4 v0 = t[0], v1 = t[1];
+                            const int dist = __popc(d[0] ^ v0.x) + __popc(d[1] ^ v0.y) + __popc(d[2] ^ v0.z) + __popc(d[3] ^ v0.w) +
+                                             __popc(d[4] ^ v1.x) + __popc(d[5] ^ v1.y) + __popc(d[6] ^ v1.z) + __popc(d[7] ^ v1.w);
+                            en = (uint32_t)k | ((uint32_t)dist << 16) | ((uint32_t)(F.octave[k] & 31) << 25);
+                        }
                     }
-                    n++;
+                    const unsigned long long m = __ballot(ok);
+                    if (ok) entries[base + n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = en;
+                    n += __popcll(m);
                 }
             }
+        } else if (upper) {
+            n = 0; // overflow: the host repeats the call with a larger pool
+        }
     }
-    if (PASS == 0) cnt_or_off[i] = n;
+    if (lane == 0) { beg[i] = base; cnt[i] = n; }
 }
 
-__global__ __launch_bounds__(256) void k_proj_scan(int n, int *__restrict__ cnt_io, int *__restrict__ total)
-{
-    extern __shared__ __align__(16) int scan_smem[];
-    __shared__ int s_w[4];
-    for (int i = threadIdx.x; i < n; i += 256) scan_smem[i] = cnt_io[i];
-    __syncthreads();
-    const int t = lds_excl_scan(scan_smem, n, s_w);
-    for (int i = threadIdx.x; i < n; i += 256) cnt_io[i] = scan_smem[i];
-    if (threadIdx.x == 0) { cnt_io[n] = t; *total = t; }
-}
+// the claim fixpoint + output, one workgroup.  owner[] (the earliest observed point currently choosing each
+// feature) lives in LDS; points below the first index that changed in a round are final and are not evaluated again.
+extern __shared__ __align__(16) int resolve_smem[];
 
-// the claim fixpoint + output, one workgroup
-__global__ __launch_bounds__(1024) void k_proj_resolve(DevFrame F, DevPoints P, ProjParams pp, const int *__restrict__ off,
-                                                       const uint32_t *__restrict__ entries, int *__restrict__ choice_a,
-                                                       int *__restrict__ choice_b, int *__restrict__ owner,
+__global__ __launch_bounds__(1024) void k_proj_resolve(DevFrame F, DevPoints P, ProjParams pp, const int *__restrict__ beg,
+                                                       const int *__restrict__ cnt, const uint32_t *__restrict__ entries,
+                                                       int *__restrict__ choice_a, int *__restrict__ choice_b,
                                                        int32_t *__restrict__ match, int *__restrict__ out_n)
 {
-    __shared__ int s_changed, s_cnt;
+    __shared__ int s_first, s_cnt;
     __shared__ int hist[30];
     __shared__ int keep3[3];
+    int *owner = resolve_smem; // [F.n]
     const int tid = threadIdx.x, nt = 1024;
     int *cur = choice_a, *nxt = choice_b;
-    for (int i = tid; i < P.n; i += nt) cur[i] = -1;
+    for (int i = tid; i < P.n; i += nt) { cur[i] = -1; nxt[i] = -1; }
+    __threadfence_block();
     __syncthreads();
+    int stable = 0; // points [0, stable) are final
     for (int round = 0; round <= P.n; round++) {
         for (int f = tid; f < F.n; f += nt) owner[f] = 0x7FFFFFFF;
-        if (tid == 0) s_changed = 0;
-        __threadfence_block();
+        if (tid == 0) s_first = 0x7FFFFFFF;
         __syncthreads();
         for (int i = tid; i < P.n; i += nt)
             if (cur[i] >= 0 && P.has_obs[i]) atomicMin(&owner[cur[i]], i);
-        __threadfence_block();
         __syncthreads();
-        int changed = 0;
-        for (int i = tid; i < P.n; i += nt) {
+        int first = 0x7FFFFFFF;
+        for (int i = stable + tid; i < P.n; i += nt) {
             int b1 = 256, b2 = 256, l1 = -1, l2 = -1, bi = -1;
-            for (int e = off[i]; e < off[i + 1]; e++) {
+            const int e0 = beg[i], e1 = e0 + cnt[i];
+            for (int e = e0; e < e1; e++) {
                 const uint32_t en = entries[e];
                 const int f = en & 0xFFFF, dist = (en >> 16) & 0x1FF, lv = en >> 25;
-                // owner[] was written by L2-side atomics: read it past this CU's L1 (agent-scope load)
-                if (F.occupied[f] || __hip_atomic_load(&owner[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < i) continue; // holder has Observations() > 0
+                if (F.occupied[f] || owner[f] < i) continue; // mvpMapPoints[f] holds a point with Observations() > 0
                 if (dist < b1) { b2 = b1; l2 = l1; b1 = dist; l1 = lv; bi = f; }
                 else if (dist < b2) { b2 = dist; l2 = lv; }
             }
@@ -232,14 +242,17 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(DevFrame F, DevPoints P, 
                 else if (!(l1 == l2 && (float)b1 > pp.nnratio * (float)b2)) c = bi; // :117-121
             }
             nxt[i] = c;
-            changed |= c != cur[i];
+            if (c != cur[i] && i < first) first = i;
         }
-        if (changed) atomicOr(&s_changed, 1);
+        if (first != 0x7FFFFFFF) atomicMin(&s_first, first);
+        for (int i = tid; i < stable; i += nt) nxt[i] = cur[i]; // the stable prefix keeps its choices in both buffers
         __threadfence_block();
         __syncthreads();
+        const int fc = s_first;
         { int *t = cur; cur = nxt; nxt = t; }
-        if (!s_changed) break;
         __syncthreads();
+        if (fc == 0x7FFFFFFF) break;
+        stable = fc; // nothing below the first change moved: those points depend only on earlier ones and are final
     }
     // ---- outputs: a feature ends up with the LAST point that chose it (:1488 overwrites); every choice counts
     for (int f = tid; f < F.n; f += nt) match[f] = -1;
@@ -369,47 +382,54 @@ static int proj_run(int device, const orbx_frame_feats *cur, const orbx_proj_poi
     P.desc = (const uint32_t *)(d + pd); P.valid = d + pval; P.has_obs = d + pobs;
     ProjParams pp = pp_in;
     for (int i = 0; i < ORBX_MAX_LEVELS; i++) pp.sf[i] = i < nlevels ? sf[i] : 0.f;
-    // work: cell_off[3073] | cell_idx[nc] | off[np+1] | total | choice_a[np] | choice_b[np] | owner[nc] | match[nc] | out_n
+    // work: cell_off[3073] | cell_idx[nc] | beg[np] | cnt[np] | pool_used | choice_a[np] | choice_b[np] | match[nc] | out_n
     size_t w = 0;
     auto wtake = [&](size_t bytes) { const size_t r = w; w += pa16(bytes); return r; };
-    const size_t w_coff = wtake(4 * (PG_CELLS + 1)), w_cidx = wtake(4 * nc), w_off = wtake(4 * (np + 1)), w_tot = wtake(16),
-                 w_ca = wtake(4 * np), w_cb = wtake(4 * np), w_own = wtake(4 * nc), w_match = wtake(4 * nc), w_n = wtake(16);
+    const size_t w_coff = wtake(4 * (PG_CELLS + 1)), w_cidx = wtake(4 * nc), w_beg = wtake(4 * np), w_cnt = wtake(4 * np), w_used = wtake(16),
+                 w_ca = wtake(4 * np), w_cb = wtake(4 * np), w_match = wtake(4 * nc), w_n = wtake(16);
     if (w > c->work_cap) {
         if (c->d_work) ORBX_HIP(hipFree(c->d_work));
         c->d_work = nullptr;
         ORBX_HIP(hipMalloc((void **)&c->d_work, w * 2));
         c->work_cap = w * 2;
     }
-    if ((nc + 4) > c->out_cap) {
+    if ((nc + 8) > c->out_cap) {
         if (c->h_out) ORBX_HIP(hipHostFree(c->h_out));
         c->h_out = nullptr;
-        ORBX_HIP(hipHostMalloc((void **)&c->h_out, sizeof(int32_t) * (nc + 4) * 2, hipHostMallocDefault));
-        c->out_cap = (nc + 4) * 2;
+        ORBX_HIP(hipHostMalloc((void **)&c->h_out, sizeof(int32_t) * (nc + 8) * 2, hipHostMallocDefault));
+        c->out_cap = (nc + 8) * 2;
     }
+    const size_t resolve_lds = sizeof(int) * (nc + 4);
+    if (resolve_lds > 150 * 1024) { orbx_set_error("too many features for one search"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds));
     uint8_t *wk = c->d_work;
-    int *d_coff = (int *)(wk + w_coff), *d_cidx = (int *)(wk + w_cidx), *d_off = (int *)(wk + w_off), *d_tot = (int *)(wk + w_tot);
-    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, c->stream, F, d_coff, d_cidx);
-    hipLaunchKernelGGL(k_proj_lists<0>, dim3((pts->n + 63) / 64), dim3(64), 0, c->stream, F, P, pp, d_coff, d_cidx, d_off, (uint32_t *)nullptr);
-    const size_t scan_lds = sizeof(int) * (np + 4);
-    if (scan_lds > 150 * 1024) { orbx_set_error("too many points for one search"); return ORBX_E_INVALID; }
-    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
-    hipLaunchKernelGGL(k_proj_scan, dim3(1), dim3(256), scan_lds, c->stream, pts->n, d_off, d_tot);
-    ORBX_HIP(hipMemcpyAsync(c->h_out, d_tot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    ORBX_HIP(hipStreamSynchronize(c->stream));
-    const size_t total = (size_t)c->h_out[0];
-    if (total > c->ent_cap || !c->d_entries) {
-        if (c->d_entries) ORBX_HIP(hipFree(c->d_entries));
-        c->d_entries = nullptr;
-        ORBX_HIP(hipMalloc((void **)&c->d_entries, sizeof(uint32_t) * (total + 16) * 2));
-        c->ent_cap = (total + 16) * 2;
+    int *d_coff = (int *)(wk + w_coff), *d_cidx = (int *)(wk + w_cidx), *d_beg = (int *)(wk + w_beg), *d_cnt = (int *)(wk + w_cnt),
+        *d_used = (int *)(wk + w_used);
+    if (!c->d_entries) { // entry pool: grown on demand, the whole call is simply repeated after an overflow
+        const size_t init = 1u << 20;
+        ORBX_HIP(hipMalloc((void **)&c->d_entries, sizeof(uint32_t) * init));
+        c->ent_cap = init;
     }
-    hipLaunchKernelGGL(k_proj_lists<1>, dim3((pts->n + 63) / 64), dim3(64), 0, c->stream, F, P, pp, d_coff, d_cidx, d_off, c->d_entries);
-    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(1024), 0, c->stream, F, P, pp, d_off, c->d_entries, (int *)(wk + w_ca), (int *)(wk + w_cb),
-                       (int *)(wk + w_own), (int32_t *)(wk + w_match), (int *)(wk + w_n));
-    ORBX_HIP(hipGetLastError());
-    ORBX_HIP(hipMemcpyAsync(c->h_out, wk + w_match, 4 * nc, hipMemcpyDeviceToHost, c->stream));
-    ORBX_HIP(hipMemcpyAsync(c->h_out + nc, wk + w_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    ORBX_HIP(hipStreamSynchronize(c->stream));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        ORBX_HIP(hipMemsetAsync(d_used, 0, 16, c->stream));
+        hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, c->stream, F, d_coff, d_cidx);
+        hipLaunchKernelGGL(k_proj_lists, dim3((pts->n + 3) / 4), dim3(256), 0, c->stream, F, P, pp, d_coff, d_cidx, d_beg, d_cnt,
+                           c->d_entries, (int)c->ent_cap, d_used);
+        hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(1024), resolve_lds, c->stream, F, P, pp, d_beg, d_cnt, c->d_entries,
+                           (int *)(wk + w_ca), (int *)(wk + w_cb), (int32_t *)(wk + w_match), (int *)(wk + w_n));
+        ORBX_HIP(hipGetLastError());
+        ORBX_HIP(hipMemcpyAsync(c->h_out, wk + w_match, 4 * nc, hipMemcpyDeviceToHost, c->stream));
+        ORBX_HIP(hipMemcpyAsync(c->h_out + nc, wk + w_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        ORBX_HIP(hipMemcpyAsync(c->h_out + nc + 1, d_used, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        ORBX_HIP(hipStreamSynchronize(c->stream));
+        const size_t used = (size_t)(unsigned)c->h_out[nc + 1];
+        if (used <= c->ent_cap) break;
+        if (attempt == 1) { orbx_set_error("candidate pool overflow"); return ORBX_E_CAPACITY; }
+        ORBX_HIP(hipFree(c->d_entries));
+        c->d_entries = nullptr;
+        ORBX_HIP(hipMalloc((void **)&c->d_entries, sizeof(uint32_t) * used * 2));
+        c->ent_cap = used * 2;
+    }
     memcpy(match_cur, c->h_out, 4 * nc);
     *nmatches = c->h_out[nc];
     return ORBX_OK;
