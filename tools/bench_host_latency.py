@@ -1,3 +1,5 @@
+"""Latency of the host-pointer entry points (orbx_extract, orbx_stereo_match) on one 1241x376 frame.
+Run on the GPU box: python tools/bench_host_latency.py"""
 import os, sys, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

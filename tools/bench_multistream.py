@@ -1,5 +1,8 @@
+"""Experiment: split a step into half batches on several HIP streams / extractor handles (results
+log): overlapping latency-bound kernels of one half with compute-bound kernels of the other.
+Run on the GPU box: python tools/bench_multistream.py"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import __graft_entry__ as ge
 from tools import synth

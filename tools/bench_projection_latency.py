@@ -1,3 +1,5 @@
+"""Latency of orbx_search_by_projection_last_frame (1000 points x 1000 features, uniform and clustered) next to
+the CPU oracle.  Run on the GPU box: python tools/bench_projection_latency.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
