@@ -1,3 +1,5 @@
+"""Per-phase s_memtime cycle shares of k_fast from the diagnostic build.
+Build first: python -c "import __graft_entry__ as g; g.build_diag()"; run on the GPU box."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["ORBX_SO"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diag", "liborbx_diag.so")  # built with -DORBX_DIAG
