@@ -194,10 +194,14 @@ extern __shared__ __align__(16) unsigned char fast_smem[];
 
 #ifdef ORBX_DIAG
 __device__ unsigned long long g_fast_stamp[4096 * 8]; // diagnostic build only: summed phase cycles of k_fast, 4096 slots
-#define STAMP(k) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
-    if (threadIdx.x == 0) atomicAdd(&g_fast_stamp[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + (k)], _t - _t_prev); _t_prev = _t; } while (0)
+__device__ unsigned long long g_desc_stamp[4096 * 8]; // same for k_desc
+#define STAMP_TO(arr, k) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+    if (threadIdx.x == 0) atomicAdd(&arr[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + (k)], _t - _t_prev); _t_prev = _t; } while (0)
+#define STAMP(k) STAMP_TO(g_fast_stamp, k)
+#define DSTAMP(k) STAMP_TO(g_desc_stamp, k)
 #else
 #define STAMP(k) do { } while (0)
+#define DSTAMP(k) do { } while (0)
 #endif
 
 // P / SP = LDS pitches of the pixel tile and the score tile: (48, 40) when every cell of the pyramid fits
@@ -361,6 +365,16 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
 }
 
 #ifdef ORBX_DIAG
+extern "C" int orbx_diag_desc_stamps(unsigned long long *out, int reset)
+{
+    ORBX_HIP(hipDeviceSynchronize());
+    static unsigned long long h[4096 * 8];
+    ORBX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_desc_stamp), sizeof h));
+    for (int k = 0; k < 8; k++) { out[k] = 0; for (int i = 0; i < 4096; i++) out[k] += h[i * 8 + k]; }
+    if (reset) { memset(h, 0, sizeof h); ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_desc_stamp), h, sizeof h)); }
+    return ORBX_OK;
+}
+
 extern "C" int orbx_diag_fast_stamps(unsigned long long *out, int reset)
 {
     ORBX_HIP(hipDeviceSynchronize());
@@ -638,6 +652,13 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     while (l + 1 < g->nlevels && slot >= g->lv[l + 1].kp_off) l++;
     const LevelGeom &L = g->lv[l];
     const int *lc = lvl_cnt + (long long)b * g->nlevels;
+    // the slot's packed keypoint is fetched together with the level counts (its address does not depend on them):
+    // one global round trip less on the critical path of every wave; slots past the level's count hold stale data
+    // that is never used
+#ifdef ORBX_DIAG
+    unsigned long long _t_prev = __builtin_amdgcn_s_memtime();
+#endif
+    const uint32_t p = lvl_kp[(long long)b * g->kp_total + slot];
     int off = 0, total = 0;
     for (int i = 0; i < g->nlevels; i++) { const int c = lc[i]; if (i < l) off += c; total += c; }
     if (slot == 0 && lane == 0) out_n[b] = total < cap ? total : cap;
@@ -645,7 +666,6 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     if (j >= lc[l]) return;
     const int idx = off + j;
     if (idx >= cap) return;
-    const uint32_t p = lvl_kp[(long long)b * g->kp_total + slot];
     const int x = p & 0xFFF, y = (p >> 12) & 0xFFF, resp = p >> 24;
     int pitch;
     const uint8_t *img = orbx_level_ptr(pr, L, l, b, &pitch);
@@ -666,6 +686,7 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
         }
     }
     __syncthreads();
+    DSTAMP(0);
     // ---- IC_Angle: lane = (row v+15, half); integer moments, order-independent
     int m10 = 0, m01 = 0;
     if (lane < 62) {
@@ -679,6 +700,7 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
     const float angle = dev_fast_atan2((float)m01, (float)m10);
+    DSTAMP(1);
     // ---- row pass: 4 outputs per item from 4 aligned dwords, v_dot4_u32_u8 against the packed taps
     const unsigned T0 = (unsigned)c_gauss[0] | ((unsigned)c_gauss[1] << 8) | ((unsigned)c_gauss[2] << 16) | ((unsigned)c_gauss[3] << 24);
     const unsigned T1 = (unsigned)c_gauss[4] | ((unsigned)c_gauss[5] << 8) | ((unsigned)c_gauss[6] << 16);
@@ -700,6 +722,7 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
         *reinterpret_cast<uint2 *>(hb + r * HP + 4 * gq) = st;
     }
     __syncthreads();
+    DSTAMP(2);
     // ---- column pass: lane = column, 43 row-pass values slide through registers
     if (lane < 37) {
         unsigned a[43];
@@ -715,6 +738,7 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
         }
     }
     __syncthreads();
+    DSTAMP(3);
     const float factor_pi = (float)(3.14159265358979323846 / 180.f);
     float sn, cs;
     dev_sincos(angle * factor_pi, &sn, &cs);
@@ -742,6 +766,10 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
         kp.class_id = -1;
         out_kps[(long long)b * cap + idx] = kp;
     }
+    DSTAMP(4);
+#ifdef ORBX_DIAG
+    if (lane == 0) atomicAdd(&g_desc_stamp[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + 7], 1ull);
+#endif
 }
 
 // ================================================================ host side

@@ -28,3 +28,13 @@ names=["load+zero","pretest","fullscore","nms","emit"]
 tot=sum(out[i] for i in range(5))
 print("waves",w, "avg cycles/wave", tot/w)
 for i,nm in enumerate(names): print(f"  {nm:10s} {out[i]/w:9.1f} cycles  {100*out[i]/tot:5.1f}%")
+
+L.orbx_diag_desc_stamps(out,1)
+for _ in range(5): step()
+ex.sync()
+L.orbx_diag_desc_stamps(out,1)
+w=out[7]
+names=["load","orient","rowpass","colpass","sample+store"]
+tot=sum(out[i] for i in range(5))
+print("k_desc waves",w, "avg cycles/wave", tot/w)
+for i,nm in enumerate(names): print(f"  {nm:12s} {out[i]/w:9.1f} cycles  {100*out[i]/tot:5.1f}%")
