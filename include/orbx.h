@@ -73,6 +73,13 @@ int orbx_max_keypoints(const orbx_extractor *e, int w, int h);
 int orbx_extract(orbx_extractor *e, const uint8_t *img, int w, int h, size_t stride,
                  orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out);
 
+/* Same for a colour frame: the cvtColor(CV_RGB2GRAY | CV_BGR2GRAY | CV_RGBA2GRAY | CV_BGRA2GRAY) that
+ * Tracking::GrabImageStereo/RGBD/Monocular apply first (src/Tracking.cc:177-202,:217-231,:254-268) runs on device into the
+ * level-0 staging (first half).  channels 3 or 4; rgb_order 1 = R first (mbRGB), 0 = B first.
+ * gray_out (optional, may be NULL; stride gray_stride) receives the grey image, i.e. what mImGray holds afterwards. */
+int orbx_extract_color(orbx_extractor *e, const uint8_t *img, int w, int h, size_t stride, int channels, int rgb_order,
+                       orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out, uint8_t *gray_out, size_t gray_stride);
+
 /* B images of one size in one pass (host pointers). kps[B*cap], desc[B*cap*32], n_out[B]. */
 int orbx_extract_batch(orbx_extractor *e, const uint8_t *const *imgs, int batch, int w, int h, size_t stride,
                        orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out);

@@ -117,6 +117,8 @@ def lib():
         L.oracle_distinctive_descriptor.argtypes = [C.c_void_p, C.c_int]
         L.oracle_search_by_projection_last.argtypes = [C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.oracle_search_by_projection_points.argtypes = [C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.oracle_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.oracle_cvt_gray.restype = None
         L.oracle_three_maxima.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _lib = L
     return _lib
@@ -291,3 +293,10 @@ def search_by_projection_points(cur, pts, scale_factors, th, nnratio):
     out = np.full(a.n, -1, np.int32)
     n = lib().oracle_search_by_projection_points(C.byref(a), C.byref(b), _p(sf), th, nnratio, _p(out))
     return out, n
+
+
+def cvt_gray(img, rgb_order):
+    img = np.ascontiguousarray(img, np.uint8); h, w, ch = img.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().oracle_cvt_gray(_p(img), w, h, img.strides[0], ch, int(rgb_order), _p(out), out.strides[0])
+    return out

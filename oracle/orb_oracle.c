@@ -1334,3 +1334,17 @@ int oracle_search_by_projection_points(const oracle_frame_feats *cur, const orac
     grid_free(g); free(cand); free(blocked);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------ grayscale ingest (f4, first half) */
+
+/* cv::cvtColor RGB(A)/BGR(A) -> GRAY, 8U (src/Tracking.cc:177-202 call sites) */
+void oracle_cvt_gray(const uint8_t *src, int w, int h, size_t sstride, int channels, int rgb_order, uint8_t *dst, size_t dstride)
+{
+    const int cr = 4899, cg = 9617, cb = 1868; /* R2Y, G2Y, B2Y at yuv_shift = 14 */
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t *p = src + (size_t)y * sstride + (size_t)x * channels;
+            const int r = rgb_order ? p[0] : p[2], g = p[1], b = rgb_order ? p[2] : p[0];
+            dst[(size_t)y * dstride + x] = (uint8_t)((r * cr + g * cg + b * cb + (1 << 13)) >> 14);
+        }
+}

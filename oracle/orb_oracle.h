@@ -169,6 +169,11 @@ int oracle_search_by_projection_last(const oracle_frame_feats *cur, const oracle
 int oracle_search_by_projection_points(const oracle_frame_feats *cur, const oracle_proj_points *pts, const float *scale_factors,
                                        float th, float nnratio, int32_t *match_cur);
 
+/* cv::cvtColor(CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY) for 8U, the conversion Tracking::GrabImage*
+ * applies to colour input (src/Tracking.cc:177-202, :217-231, :254-268) [OpenCV generic path, from memory:
+ * fixed point, yuv_shift 14, R2Y 4899, G2Y 9617, B2Y 1868, rounding 1<<13].  channels 3 or 4; rgb_order 1 = R first. */
+void oracle_cvt_gray(const uint8_t *src, int w, int h, size_t sstride, int channels, int rgb_order, uint8_t *dst, size_t dstride);
+
 /* ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1687-1728 */
 void oracle_three_maxima(const int *count, int L, int *ind1, int *ind2, int *ind3);
 

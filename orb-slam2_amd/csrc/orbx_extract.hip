@@ -1231,6 +1231,70 @@ extern "C" int orbx_extract_batch(orbx_extractor *e, const uint8_t *const *imgs,
     return ORBX_OK;
 }
 
+// cv::cvtColor colour -> grey for 8U (call sites src/Tracking.cc:177-202): fixed point, yuv_shift 14
+__global__ __launch_bounds__(256) void k_gray(const uint8_t *__restrict__ src, int w, int h, int spitch, int channels, int rgb_order,
+                                              uint8_t *__restrict__ dst, int dpitch)
+{
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= h || x4 >= dpitch) return;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = x4 + i;
+        if (x < w) {
+            const uint8_t *p = src + (long long)y * spitch + (long long)x * channels;
+            const int r = rgb_order ? p[0] : p[2], g = p[1], bl = rgb_order ? p[2] : p[0];
+            out |= (uint32_t)((r * 4899 + g * 9617 + bl * 1868 + (1 << 13)) >> 14) << (8 * i);
+        }
+    }
+    *reinterpret_cast<uint32_t *>(dst + (long long)y * dpitch + x4) = out;
+}
+
+extern "C" int orbx_extract_color(orbx_extractor *e, const uint8_t *img, int w, int h, size_t stride, int channels, int rgb_order,
+                                  orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out, uint8_t *gray_out, size_t gray_stride)
+{
+    if (!e || !kps || !desc || !n_out || w < 0 || h < 0 || (channels != 3 && channels != 4) || (gray_out && gray_stride < (size_t)w)) {
+        orbx_set_error("orbx_extract_color: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    if (w == 0 || h == 0) { *n_out = 0; return ORBX_OK; }
+    if (!img || stride < (size_t)w * channels) { orbx_set_error("orbx_extract_color: bad image / stride"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipSetDevice(e->device));
+    int rc = orbx_prepare_geometry(e, w, h);
+    if (rc) return rc;
+    const int need = e->geom.kp_total;
+    if (cap < need) { orbx_set_error("keypoint capacity %d < orbx_max_keypoints() = %d", cap, need); return ORBX_E_CAPACITY; }
+    const size_t pitch = align_up(w, 64), img_bytes = pitch * h;
+    const size_t cpitch = align_up((size_t)w * channels, 64), cbytes = cpitch * h;
+    if ((rc = ensure(&e->d_stage_in, &e->stage_in_cap, img_bytes * e->max_batch))) return rc;
+    if ((rc = ensure_pinned(&e->h_stage_in, &e->h_stage_in_cap, cbytes > img_bytes * e->max_batch ? cbytes : img_bytes * e->max_batch))) return rc;
+    void *d_color;
+    if ((rc = orbx_scratch(e, 6, cbytes, &d_color))) return rc;
+    if ((rc = orbx_ensure_out_staging(e, e->max_batch, need))) return rc;
+    const size_t o_kps = align_up(sizeof(int) * (size_t)e->max_batch, 64);
+    const size_t o_desc = o_kps + align_up(sizeof(orbx_keypoint) * (size_t)need * e->max_batch, 64);
+    const size_t out_bytes = o_desc + (size_t)32 * need * e->max_batch;
+    if ((rc = ensure_pinned(&e->h_out, &e->h_out_cap, out_bytes > img_bytes ? out_bytes : img_bytes))) return rc;
+    for (int y = 0; y < h; y++) memcpy(e->h_stage_in + (size_t)y * cpitch, img + (size_t)y * stride, (size_t)w * channels);
+    ORBX_HIP(hipMemcpyAsync(d_color, e->h_stage_in, cbytes, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_gray, dim3((unsigned)((pitch / 4 + 63) / 64), (h + 3) / 4), dim3(256), 0, e->stream, (const uint8_t *)d_color, w, h, (int)cpitch,
+                       channels, rgb_order, e->d_stage_in, (int)pitch);
+    e->prof_chain = false;
+    rc = orbx_extract_batch_device(e, e->d_stage_in, img_bytes, pitch, 1, w, h, e->d_out_kps, e->d_out_desc, need, e->d_out_n, nullptr);
+    if (rc) return rc;
+    ORBX_HIP(hipMemcpyAsync(e->h_out, e->d_out_n, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    ORBX_HIP(hipMemcpyAsync(e->h_out + o_kps, e->d_out_kps, sizeof(orbx_keypoint) * (size_t)need, hipMemcpyDeviceToHost, e->stream));
+    ORBX_HIP(hipMemcpyAsync(e->h_out + o_desc, e->d_out_desc, (size_t)32 * need, hipMemcpyDeviceToHost, e->stream));
+    rc = orbx_sync(e, nullptr);
+    if (rc) return rc;
+    const int n = *reinterpret_cast<const int *>(e->h_out);
+    *n_out = n;
+    memcpy(kps, e->h_out + o_kps, sizeof(orbx_keypoint) * (size_t)n);
+    memcpy(desc, e->h_out + o_desc, (size_t)32 * n);
+    if (gray_out) ORBX_HIP(hipMemcpy2D(gray_out, gray_stride, e->d_stage_in, pitch, w, h, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
 extern "C" int orbx_extract(orbx_extractor *e, const uint8_t *img, int w, int h, size_t stride,
                             orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out)
 {

@@ -67,6 +67,7 @@ def lib():
     L.orbx_get_features_per_level.argtypes = [vp, vp]
     L.orbx_max_keypoints.argtypes = [vp, i, i]
     L.orbx_extract.argtypes = [vp, vp, i, i, sz, vp, vp, i, ip]
+    L.orbx_extract_color.argtypes = [vp, vp, i, i, sz, i, i, vp, vp, i, ip, vp, sz]
     L.orbx_extract_batch.argtypes = [vp, vp, i, i, i, sz, vp, vp, i, vp]
     L.orbx_extract_batch_device.argtypes = [vp, vp, sz, sz, i, i, i, vp, vp, i, vp, vp]
     L.orbx_sync.argtypes = [vp, vp]
@@ -192,6 +193,18 @@ class ORBextractor:
         kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int()
         _check(self._L.orbx_extract(self._h, _p(image), w, h, image.strides[0], _p(kps), _p(desc), cap, C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_color(self, image, rgb=True, want_gray=False):
+        """colour frame (H x W x 3|4 uint8): cvtColor to grey on device (Tracking::GrabImage*, src/Tracking.cc:177-202), then operator()"""
+        image = np.ascontiguousarray(image, np.uint8)
+        h, w, ch = image.shape
+        cap = self.max_keypoints(w, h)
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int()
+        gray = np.zeros((h, w), np.uint8) if want_gray else None
+        _check(self._L.orbx_extract_color(self._h, _p(image), w, h, image.strides[0], ch, int(rgb), _p(kps), _p(desc), cap, C.byref(n),
+                                          _p(gray), gray.strides[0] if want_gray else 0))
+        out = (kps[:n.value].copy(), desc[:n.value].copy())
+        return out + (gray,) if want_gray else out
 
     def extract_batch(self, images):
         """list/array of equally sized uint8 images -> list of (keypoints, descriptors)"""

@@ -187,6 +187,23 @@ def test_small_image_fewer_levels(pkg, oracle):
     _check_stages(ex, orc, img, "160x120/4 levels")
 
 
+@pytest.mark.parametrize("ch,rgb", [(3, True), (3, False), (4, True), (4, False)])
+def test_color_ingest(pkg, oracle, ch, rgb):
+    """Tracking::GrabImage* colour path: cvtColor on device, then the extractor"""
+    rng = np.random.default_rng(5)
+    base = synth.image(33, 640, 480).astype(np.int32)
+    col = np.stack([np.clip(base + rng.integers(-40, 40, base.shape), 0, 255) for _ in range(ch)], axis=2).astype(np.uint8)
+    ex = _extractor(pkg, 1000, 640, 480)
+    kps, desc, gray = ex.extract_color(col, rgb=rgb, want_gray=True)
+    ogray = oracle.cvt_gray(col, rgb)
+    assert (gray == ogray).all()
+    okps, odesc = oracle.Oracle(1000, 1.2, 8, 20, 7).extract(ogray)
+    assert kps.tobytes() == okps.tobytes() and desc.tobytes() == odesc.tobytes()
+    # the weights are the usual luma weights: a pure-channel image lands on round(255 * w)
+    pure = np.zeros((64, 64, ch), np.uint8); pure[..., 0] = 255
+    assert oracle.cvt_gray(pure, True)[0, 0] == 76 and oracle.cvt_gray(pure, False)[0, 0] == 29
+
+
 def test_strided_input(pkg, oracle):
     big = synth.image(31, 800, 500)
     view = big[10:490, 40:680]          # 640x480 view with row stride 800
