@@ -64,7 +64,7 @@ __device__ void histogram_filter(int32_t *match, const uint8_t *bins, int nslots
     if (tid == 0) *s_cnt = 0;
     __syncthreads();
     if (check_ori) {
-        for (int i = tid; i < nslots; i += 256)
+        for (int i = tid; i < nslots; i += blockDim.x)
             if (bins[i] != 255) atomicAdd(&hist[bins[i]], 1);
         __syncthreads();
         if (tid == 0) {
@@ -82,7 +82,7 @@ __device__ void histogram_filter(int32_t *match, const uint8_t *bins, int nslots
         __syncthreads();
     }
     int local = 0;
-    for (int i = tid; i < nslots; i += 256) {
+    for (int i = tid; i < nslots; i += blockDim.x) {
         const int b = bins[i];
         if (b == 255) continue;
         if (check_ori && b != keep3[0] && b != keep3[1] && b != keep3[2]) match[i] = -1;
@@ -98,7 +98,7 @@ extern __shared__ __align__(16) unsigned char bow_smem[];
 // MODE 0: SearchByBoW(KF, F)  — match[nB] indexed by the F feature, value = KF feature
 // MODE 1: SearchByBoW(KF, KF) — match[nA] indexed by the KF1 feature, value = KF2 feature
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a, const DevFeat *__restrict__ sides_b,
+__global__ __launch_bounds__(1024) void k_bow(const DevFeat *__restrict__ sides_a, const DevFeat *__restrict__ sides_b,
                                              int b_shared, float nnratio, int check_ori, int32_t *__restrict__ match_out,
                                              int match_stride, int *__restrict__ nmatches)
 {
@@ -112,10 +112,11 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
     uint8_t *claimed = bow_smem;                 // [B.n]
     uint8_t *bins = bow_smem + ((B.n + 15) & ~15); // [nslots]
     int32_t *match = match_out + (long long)pair * match_stride;
-    for (int i = tid; i < B.n; i += 256) claimed[i] = 0;
-    for (int i = tid; i < nslots; i += 256) { bins[i] = 255; match[i] = -1; }
+    const int nwaves = blockDim.x >> 6; // the shared vocabulary nodes are dealt over all waves of the workgroup
+    for (int i = tid; i < B.n; i += blockDim.x) claimed[i] = 0;
+    for (int i = tid; i < nslots; i += blockDim.x) { bins[i] = 255; match[i] = -1; }
     __syncthreads();
-    for (int ia = wv; ia < A.nnodes; ia += 4) {
+    for (int ia = wv; ia < A.nnodes; ia += nwaves) {
         const int ib = find_node(B.node_id, B.nnodes, A.node_id[ia]);
         if (ib < 0) continue;
         const int b0 = B.node_off[ib], b1 = B.node_off[ib + 1];
@@ -387,10 +388,10 @@ static int bow_run(int mode, int device, const orbx_featset *as, int na, const o
     if (lds > 150 * 1024) { orbx_set_error("feature sets too large for LDS"); return ORBX_E_INVALID; }
     if (mode == 0) {
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_bow<0>, dim3(na), dim3(256), lds, c->stream, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
+        hipLaunchKernelGGL(k_bow<0>, dim3(na), dim3(1024), lds, c->stream, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
     } else {
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_bow<1>, dim3(na), dim3(256), lds, c->stream, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
+        hipLaunchKernelGGL(k_bow<1>, dim3(na), dim3(1024), lds, c->stream, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
     }
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipMemcpyAsync(c->h_out, c->d_out, out_ints * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -492,7 +493,7 @@ extern "C" int orbx_bowdb_search(orbx_bowdb *db, const orbx_featset *f, float nn
     ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int32_t *d_match = db->d_out;
     int *d_n = db->d_out + (size_t)db->nkf * stride;
-    hipLaunchKernelGGL(k_bow<0>, dim3(db->nkf), dim3(256), lds, db->stream, (const DevFeat *)db->d_blob, (const DevFeat *)db->d_f, 1,
+    hipLaunchKernelGGL(k_bow<0>, dim3(db->nkf), dim3(1024), lds, db->stream, (const DevFeat *)db->d_blob, (const DevFeat *)db->d_f, 1,
                        nnratio, check_orientation, d_match, f->n, d_n);
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipMemcpyAsync(db->h_out, db->d_out, out_ints * sizeof(int32_t), hipMemcpyDeviceToHost, db->stream));

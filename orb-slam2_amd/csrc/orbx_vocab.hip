@@ -133,11 +133,16 @@ __global__ __launch_bounds__(256) void k_bow_build(int n, int npad, const uint32
     }
     __threadfence_block();
     __syncthreads();
-    if (tid == 0) { // normalize(L1): ascending word order, sequential doubles (BowVector.cpp:58-77)
+    if (tid < 64) { // normalize(L1): ascending word order, strictly sequential doubles (BowVector.cpp:58-77).
+        // Wave 0 loads 64 values at a time and adds them in lane order from registers (broadcast reads), so the
+        // dependent chain is 64 register adds per memory round trip instead of one.
         double norm = 0.0;
-        for (int i = 0; i < nb; i++) norm += fabs(bow_val[i]);
-        s_norm = norm;
-        counts[0] = nb;
+        for (int base = 0; base < nb; base += 64) {
+            const double v = base + tid < nb ? fabs(bow_val[base + tid]) : 0.0;
+            const int m = min(64, nb - base);
+            for (int k = 0; k < m; k++) norm += __shfl(v, k, WAVE);
+        }
+        if (tid == 0) { s_norm = norm; counts[0] = nb; }
     }
     __syncthreads();
     const double norm = s_norm;
