@@ -15,25 +15,44 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     return v;
 }
 
+// Wave64 reductions on the DPP data path (row_shr 1/2/4/8 inside each 16-lane row, then row_bcast 15 / 31
+// across rows; the total lands in lane 63 and is broadcast with v_readlane): 6 VALU + DPP steps instead of the six
+// dependent ds_bpermute round trips that __shfl_xor lowers to.  Lanes without a source read `identity`.
+#define ORBX_DPP(v, identity, ctrl, row_mask, bank_mask) \
+    __builtin_amdgcn_update_dpp((int)(identity), (int)(v), ctrl, row_mask, bank_mask, false)
+
 __device__ __forceinline__ int wave_sum(int v)
 {
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
-    return v;
+    v += ORBX_DPP(v, 0, 0x111, 0xf, 0xf); // row_shr:1
+    v += ORBX_DPP(v, 0, 0x112, 0xf, 0xf); // row_shr:2
+    v += ORBX_DPP(v, 0, 0x114, 0xf, 0xe); // row_shr:4
+    v += ORBX_DPP(v, 0, 0x118, 0xf, 0xc); // row_shr:8
+    v += ORBX_DPP(v, 0, 0x142, 0xa, 0xf); // row_bcast:15
+    v += ORBX_DPP(v, 0, 0x143, 0xc, 0xf); // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 {
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) { unsigned t = (unsigned)__shfl_xor((int)v, d, WAVE); v = t < v ? t : v; }
-    return v;
+    const unsigned id = 0xFFFFFFFFu;
+    v = min(v, (unsigned)ORBX_DPP(v, id, 0x111, 0xf, 0xf));
+    v = min(v, (unsigned)ORBX_DPP(v, id, 0x112, 0xf, 0xf));
+    v = min(v, (unsigned)ORBX_DPP(v, id, 0x114, 0xf, 0xe));
+    v = min(v, (unsigned)ORBX_DPP(v, id, 0x118, 0xf, 0xc));
+    v = min(v, (unsigned)ORBX_DPP(v, id, 0x142, 0xa, 0xf));
+    v = min(v, (unsigned)ORBX_DPP(v, id, 0x143, 0xc, 0xf));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 {
-#pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) { unsigned t = (unsigned)__shfl_xor((int)v, d, WAVE); v = t > v ? t : v; }
-    return v;
+    v = max(v, (unsigned)ORBX_DPP(v, 0, 0x111, 0xf, 0xf));
+    v = max(v, (unsigned)ORBX_DPP(v, 0, 0x112, 0xf, 0xf));
+    v = max(v, (unsigned)ORBX_DPP(v, 0, 0x114, 0xf, 0xe));
+    v = max(v, (unsigned)ORBX_DPP(v, 0, 0x118, 0xf, 0xc));
+    v = max(v, (unsigned)ORBX_DPP(v, 0, 0x142, 0xa, 0xf));
+    v = max(v, (unsigned)ORBX_DPP(v, 0, 0x143, 0xc, 0xf));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // exclusive scan of one value per thread over a 256-thread workgroup; s_w = 4 ints of LDS
