@@ -4,22 +4,26 @@
 
 #define WAVE 64
 
+// forward declaration of the DPP helper macro used below
+#define ORBX_DPP(v, identity, ctrl, row_mask, bank_mask) \
+    __builtin_amdgcn_update_dpp((int)(identity), (int)(v), ctrl, row_mask, bank_mask, false)
+
+// inclusive wave64 prefix sum on the DPP path: Kogge-Stone inside each 16-lane row (row_shr 1, 2, 4, 8), then the
+// row totals ripple with row_bcast:15 (into rows 1 and 3) and row_bcast:31 (into rows 2 and 3)
 __device__ __forceinline__ int wave_incl_scan(int v)
 {
-    const int lane = threadIdx.x & (WAVE - 1);
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        int t = __shfl_up(v, d, WAVE);
-        if (lane >= d) v += t;
-    }
+    v += ORBX_DPP(v, 0, 0x111, 0xf, 0xf);
+    v += ORBX_DPP(v, 0, 0x112, 0xf, 0xf);
+    v += ORBX_DPP(v, 0, 0x114, 0xf, 0xf);
+    v += ORBX_DPP(v, 0, 0x118, 0xf, 0xf);
+    v += ORBX_DPP(v, 0, 0x142, 0xa, 0xf);
+    v += ORBX_DPP(v, 0, 0x143, 0xc, 0xf);
     return v;
 }
 
 // Wave64 reductions on the DPP data path (row_shr 1/2/4/8 inside each 16-lane row, then row_bcast 15 / 31
 // across rows; the total lands in lane 63 and is broadcast with v_readlane): 6 VALU + DPP steps instead of the six
 // dependent ds_bpermute round trips that __shfl_xor lowers to.  Lanes without a source read `identity`.
-#define ORBX_DPP(v, identity, ctrl, row_mask, bank_mask) \
-    __builtin_amdgcn_update_dpp((int)(identity), (int)(v), ctrl, row_mask, bank_mask, false)
 
 __device__ __forceinline__ int wave_sum(int v)
 {
