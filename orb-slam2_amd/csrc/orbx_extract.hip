@@ -19,12 +19,12 @@ __constant__ int c_gauss[7];              // 8-bit fixed point 7-tap sigma=2 ker
 // ================================================================ K1: pyramid level (E2)
 // cv::resize INTER_LINEAR 8UC1 from level l-1 to level l.  Coefficient tables are
 // computed on the host with the reference's float/double arithmetic; the kernel is pure integer.
-// A 256-thread workgroup produces a 128x32 output tile: the source rectangle it needs (<= 156x41)
-// is staged in LDS with coalesced aligned dword loads, each thread then computes a 4x4 block
+// A 256-thread workgroup produces a 256x32 output tile: the source rectangle it needs (<= 310x41)
+// is staged in LDS with coalesced aligned dword loads, each thread then computes a 4x8 block
 // (x tables loaded once per thread) and stores one dword per row.
-#define RS_TW 128
+#define RS_TW 256
 #define RS_TH 32
-#define RS_PITCH 176 // LDS bytes per staged source row (>= 156 + 3 + alignment)
+#define RS_PITCH 336 // LDS bytes per staged source row (>= 1.2 * 256 + 2 + 3 + alignment)
 #define RS_ROWS 42
 
 __global__ __launch_bounds__(256) void k_resize(const Geom *__restrict__ g, int l, PyrRef pr,
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_resize(const Geom *__restrict__ g, int 
         }
     }
     __syncthreads();
-    const int x4 = x_t + (tid & 31) * 4, y4 = y_t + (tid >> 5) * 4;
+    const int x4 = x_t + (tid & 63) * 4, y4 = y_t + (tid >> 6) * 8;
     if (x4 >= D.pitch) return;
     int o0[4], o1[4], a0[4], a1[4];
 #pragma unroll
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_resize(const Geom *__restrict__ g, int 
         a1[i] = tx[2 * D.w + x];
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < 8; j++) {
         const int y = y4 + j;
         if (y >= D.h) break;
         const int sy0 = ty[y], b0 = ty[D.h + y], b1 = ty[2 * D.h + y];
