@@ -403,7 +403,9 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
                                               uint32_t *__restrict__ lvl_kp, int lds_pts_cap, int *__restrict__ err_flag)
 {
     constexpr int NB = ORBX_NODE_BITS, NMASK = (1 << NB) - 1;
-    const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    // x = image, y = level: workgroups are dealt to the 8 XCDs by linear id % 8, so every XCD gets the same mix of
+    // levels (x = level would put all level-0 trees, the longest barrier chains, on one XCD), heaviest level first
+    const int l = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
     const LevelGeom &L = g->lv[l];
     const int cap = g->max_node_cap; // multiple of 4
     int *cnt = reinterpret_cast<int *>(tree_smem);
@@ -1135,7 +1137,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
     orbx_prof_end(e, s);
     int *err_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;
     orbx_prof_begin(e, ORBX_STAGE_TREE, s);
-    hipLaunchKernelGGL(k_tree, dim3(G.nlevels, batch), dim3(256), tree_lds_bytes(G, lds_pts_cap(G)), s, e->d_geom,
+    hipLaunchKernelGGL(k_tree, dim3(batch, G.nlevels), dim3(256), tree_lds_bytes(G, lds_pts_cap(G)), s, e->d_geom,
                        e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, lds_pts_cap(G), err_flag);
     orbx_prof_end(e, s);
     orbx_prof_begin(e, ORBX_STAGE_DESC, s);
