@@ -244,6 +244,39 @@ int orbx_search_by_projection_map_points(int device, const orbx_frame_feats *cur
                                          const float *scale_factors, int nlevels, float th, float nnratio,
                                          int32_t *match_cur, int *nmatches);
 
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)
+ * (src/ORBmatcher.cc:1555-1685; Tracking::Relocalization).  pts = pKF->GetMapPointMatches() in keypoint order, projected
+ * by the adaptor with CurrentFrame.mTcw: u, v (:1588-1589), level = PredictScale (:1607), angle = pKF->mvKeysUn[i].angle,
+ * valid = pMP && !isBad() && !sAlreadyFound.count(pMP) && distance range (:1577-1605); aux / view_cos / has_obs unused.
+ * cur->occupied = CurrentFrame.mvpMapPoints[i] != NULL; every accepted match blocks its feature (:1624-1625). */
+int orbx_search_by_projection_keyframe(int device, const orbx_frame_feats *cur, const orbx_proj_points *pts,
+                                       const float *scale_factors, int nlevels, float th, int orb_dist,
+                                       int check_orientation, int32_t *match_cur, int *nmatches);
+/* ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, th)
+ * (src/ORBmatcher.cc:305-415; LoopClosing::ComputeSim3).  pts = vpPoints projected with Scw (:336-352), level = PredictScale
+ * (:374), valid = !isBad() && !spAlreadyFound.count(pMP) && depth > 0 && distance range && viewing angle (:331-372); the
+ * IsInImage test (:355) is done here from kf's bounds.  kf->occupied = vpMatched[idx] != NULL.  match_kf[kf->n] = the
+ * point this call writes to vpMatched[idx], or -1. */
+int orbx_search_by_projection_sim3(int device, const orbx_frame_feats *kf, const orbx_proj_points *pts,
+                                   const float *scale_factors, int nlevels, float th, int32_t *match_kf, int *nmatches);
+/* The search half of ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:873-1038; chi2 = 1,
+ * max_dist = TH_LOW 50, aux = ur = u - bf*invz, inv_sigma2 = pKF->mvInvLevelSigma2), of Fuse(KeyFrame*, Scw, vpPoints, th,
+ * vpReplacePoint) (:1040-1164; chi2 = 0, max_dist = 50) and of each direction of SearchBySim3 (max_dist = TH_HIGH 100):
+ * best_idx[pts->n] = most similar keypoint of kf inside the window with octave in [level-1, level] whose distance is
+ * <= max_dist, else -1; best_dist (may be NULL) its distance; *nfound = points with a result.  Points do not interact;
+ * Replace / AddObservation / vpReplacePoint stay with the adaptor, which also re-checks isBad()/IsInKeyFrame() as
+ * it walks the results in order (those flags can change through its own Replace calls). */
+int orbx_window_best(int device, const orbx_frame_feats *kf, const orbx_proj_points *pts, const float *scale_factors,
+                     const float *inv_sigma2, int nlevels, float th, int chi2, int max_dist, int32_t *best_idx,
+                     int32_t *best_dist, int *nfound);
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (src/ORBmatcher.cc:1166-1394; LoopClosing::ComputeSim3).
+ * pts12 = KF1's map points (one entry per KF1 keypoint; valid = has a point, !vbAlreadyMatched1, !isBad(), depth and range
+ * tests :1221-1259) projected into KF2 with level = PredictScale(dist3D, pKF2); pts21 the reverse direction.
+ * match12[kf1->n] = idx2 where the two directions agree (:1375-1391), else -1; *nfound = the return value. */
+int orbx_search_by_sim3(int device, const orbx_frame_feats *kf1, const orbx_frame_feats *kf2, const orbx_proj_points *pts12,
+                        const orbx_proj_points *pts21, const float *scale_factors1, const float *scale_factors2, int nlevels,
+                        float th, int32_t *match12, int *nfound);
+
 /* ---- MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:266-340) -- */
 
 /* Batched over map points: point p owns descriptors desc[off[p] .. off[p+1]) (its non-bad observations in the

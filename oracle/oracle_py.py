@@ -117,6 +117,11 @@ def lib():
         L.oracle_distinctive_descriptor.argtypes = [C.c_void_p, C.c_int]
         L.oracle_search_by_projection_last.argtypes = [C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.oracle_search_by_projection_points.argtypes = [C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.oracle_search_by_projection_keyframe.argtypes = [C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_search_by_projection_sim3.argtypes = [C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.c_void_p, C.c_float, C.c_void_p]
+        L.oracle_window_best.argtypes = [C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_search_by_sim3.argtypes = [C.POINTER(FrameFeats), C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.POINTER(ProjPoints),
+                                            C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.oracle_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.oracle_cvt_gray.restype = None
         L.oracle_three_maxima.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -292,6 +297,39 @@ def search_by_projection_points(cur, pts, scale_factors, th, nnratio):
     sf = np.ascontiguousarray(scale_factors, np.float32)
     out = np.full(a.n, -1, np.int32)
     n = lib().oracle_search_by_projection_points(C.byref(a), C.byref(b), _p(sf), th, nnratio, _p(out))
+    return out, n
+
+
+def search_by_projection_keyframe(cur, pts, scale_factors, th, orb_dist, check_ori):
+    a, ka = make_frame_feats(cur); b, kb = make_proj_points(pts)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    out = np.full(a.n, -1, np.int32)
+    n = lib().oracle_search_by_projection_keyframe(C.byref(a), C.byref(b), _p(sf), th, int(orb_dist), int(check_ori), _p(out))
+    return out, n
+
+
+def search_by_projection_sim3(kf, pts, scale_factors, th):
+    a, ka = make_frame_feats(kf); b, kb = make_proj_points(pts)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    out = np.full(a.n, -1, np.int32)
+    n = lib().oracle_search_by_projection_sim3(C.byref(a), C.byref(b), _p(sf), th, _p(out))
+    return out, n
+
+
+def window_best(kf, pts, scale_factors, inv_sigma2, th, chi2, max_dist):
+    a, ka = make_frame_feats(kf); b, kb = make_proj_points(pts)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    sg = np.ascontiguousarray(inv_sigma2 if inv_sigma2 is not None else np.zeros(len(sf)), np.float32)
+    bi = np.full(b.n, -1, np.int32); bd = np.full(b.n, 256, np.int32)
+    n = lib().oracle_window_best(C.byref(a), C.byref(b), _p(sf), _p(sg), th, int(chi2), int(max_dist), _p(bi), _p(bd))
+    return bi, bd, n
+
+
+def search_by_sim3(kf1, kf2, pts12, pts21, sf1, sf2, th):
+    a, ka = make_frame_feats(kf1); b, kb = make_frame_feats(kf2); p, kp = make_proj_points(pts12); q, kq = make_proj_points(pts21)
+    s1 = np.ascontiguousarray(sf1, np.float32); s2 = np.ascontiguousarray(sf2, np.float32)
+    out = np.full(a.n, -1, np.int32)
+    n = lib().oracle_search_by_sim3(C.byref(a), C.byref(b), C.byref(p), C.byref(q), _p(s1), _p(s2), th, _p(out))
     return out, n
 
 

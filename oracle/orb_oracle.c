@@ -1335,6 +1335,155 @@ int oracle_search_by_projection_points(const oracle_frame_feats *cur, const orac
     return nmatches;
 }
 
+/* src/ORBmatcher.cc:1555-1685 (Tracking::Relocalization): points = pKF's map points in feature order, the adaptor
+ * projects them with the current pose, applies the isBad / sAlreadyFound / distance-range tests (-> valid) and predicts the
+ * level.  Any accepted match blocks its feature (mvpMapPoints[i2] != NULL, :1624-1625). */
+int oracle_search_by_projection_keyframe(const oracle_frame_feats *cur, const oracle_proj_points *pts, const float *sf,
+                                         float th, int orb_dist, int check_ori, int32_t *match_cur)
+{
+    fgrid *g = grid_build(cur);
+    int *cand = malloc(sizeof(int) * (cur->n ? cur->n : 1));
+    uint8_t *blocked = malloc(cur->n ? cur->n : 1);
+    for (int i = 0; i < cur->n; i++) { match_cur[i] = -1; blocked[i] = cur->occupied[i]; }
+    rot_hist rh; memset(&rh, 0, sizeof rh);
+    int nmatches = 0;
+    for (int i = 0; i < pts->n; i++) {
+        if (!pts->valid[i]) continue;
+        const float u = pts->u[i], v = pts->v[i];
+        if (u < cur->min_x || u > cur->max_x) continue;   /* :1591-1594 */
+        if (v < cur->min_y || v > cur->max_y) continue;
+        const int lvl = pts->level[i];
+        const float radius = th * sf[lvl];                /* :1610 */
+        const int nc = features_in_area(cur, g, u, v, radius, lvl - 1, lvl + 1, cand);
+        if (nc == 0) continue;
+        int best_dist = 256, best_idx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = cand[c];
+            if (blocked[i2]) continue;
+            const int dist = oracle_hamming(pts->desc + (size_t)i * 32, cur->desc + (size_t)i2 * 32);
+            if (dist < best_dist) { best_dist = dist; best_idx = i2; }
+        }
+        if (best_dist <= orb_dist) {
+            match_cur[best_idx] = i;
+            blocked[best_idx] = 1;
+            nmatches++;
+            if (check_ori) rh_push(&rh, rot_bin(pts->angle[i], cur->angle[best_idx]), best_idx);
+        }
+    }
+    if (check_ori) nmatches -= rh_filter(&rh, match_cur);
+    grid_free(g); free(cand); free(blocked);
+    return nmatches;
+}
+
+/* KeyFrame::IsInImage, src/KeyFrame.cc:649-652 */
+static int kf_in_image(const oracle_frame_feats *kf, float x, float y)
+{
+    return x >= kf->min_x && x < kf->max_x && y >= kf->min_y && y < kf->max_y;
+}
+
+/* src/ORBmatcher.cc:305-415 (LoopClosing::ComputeSim3): the adaptor projects vpPoints with Scw and applies the isBad /
+ * spAlreadyFound / depth / distance-range / viewing-angle tests (-> valid); occupied = vpMatched[idx] != NULL on entry.
+ * match_kf[idx] = index of the point written to vpMatched[idx] by this call, or -1. */
+int oracle_search_by_projection_sim3(const oracle_frame_feats *kf, const oracle_proj_points *pts, const float *sf,
+                                     float th, int32_t *match_kf)
+{
+    fgrid *g = grid_build(kf);
+    int *cand = malloc(sizeof(int) * (kf->n ? kf->n : 1));
+    uint8_t *blocked = malloc(kf->n ? kf->n : 1);
+    for (int i = 0; i < kf->n; i++) { match_kf[i] = -1; blocked[i] = kf->occupied[i]; }
+    int nmatches = 0;
+    for (int i = 0; i < pts->n; i++) {
+        if (!pts->valid[i]) continue;
+        const float u = pts->u[i], v = pts->v[i];
+        if (!kf_in_image(kf, u, v)) continue;             /* :355-356 */
+        const int lvl = pts->level[i];
+        const float radius = th * sf[lvl];                /* :377 */
+        const int nc = features_in_area(kf, g, u, v, radius, -1, -1, cand); /* KeyFrame::GetFeaturesInArea: no level test */
+        if (nc == 0) continue;
+        int best_dist = 256, best_idx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            if (blocked[idx]) continue;
+            const int kl = kf->octave[idx];
+            if (kl < lvl - 1 || kl > lvl) continue;
+            const int dist = oracle_hamming(pts->desc + (size_t)i * 32, kf->desc + (size_t)idx * 32);
+            if (dist < best_dist) { best_dist = dist; best_idx = idx; }
+        }
+        if (best_dist <= TH_LOW) {
+            match_kf[best_idx] = i;
+            blocked[best_idx] = 1;
+            nmatches++;
+        }
+    }
+    grid_free(g); free(cand); free(blocked);
+    return nmatches;
+}
+
+/* The search half of both ORBmatcher::Fuse overloads (src/ORBmatcher.cc:873-1038 with chi2 = 1, :1040-1164 with
+ * chi2 = 0) and of each direction of SearchBySim3 (:1166-1394, max_dist = TH_HIGH): per projected point the most
+ * similar keypoint of the keyframe inside the window, levels [pred-1, pred]; no state is shared between points, the
+ * map surgery that follows (Replace / AddObservation / vpReplacePoint) stays with the caller.
+ * aux = ur = u - bf*invz (:914) for chi2 = 1.  best_idx[i] = keypoint or -1, best_dist[i] = its distance. */
+int oracle_window_best(const oracle_frame_feats *kf, const oracle_proj_points *pts, const float *sf, const float *inv_sigma2,
+                       float th, int chi2, int max_dist, int32_t *best_idx_out, int32_t *best_dist_out)
+{
+    fgrid *g = grid_build(kf);
+    int *cand = malloc(sizeof(int) * (kf->n ? kf->n : 1));
+    int nfound = 0;
+    for (int i = 0; i < pts->n; i++) {
+        best_idx_out[i] = -1; best_dist_out[i] = 256;
+        if (!pts->valid[i]) continue;
+        const float u = pts->u[i], v = pts->v[i];
+        if (!kf_in_image(kf, u, v)) continue;
+        const int lvl = pts->level[i];
+        const float radius = th * sf[lvl];
+        const int nc = features_in_area(kf, g, u, v, radius, -1, -1, cand);
+        if (nc == 0) continue;
+        int best_dist = 256, best_idx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            const int kl = kf->octave[idx];
+            if (kl < lvl - 1 || kl > lvl) continue;
+            if (chi2) {
+                const float ex = u - kf->x[idx], ey = v - kf->y[idx];
+                if (kf->u_right[idx] >= 0) {              /* :967-980 */
+                    const float er = pts->aux[i] - kf->u_right[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_sigma2[kl] > 7.8) continue;
+                } else {                                   /* :981-992 */
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_sigma2[kl] > 5.99) continue;
+                }
+            }
+            const int dist = oracle_hamming(pts->desc + (size_t)i * 32, kf->desc + (size_t)idx * 32);
+            if (dist < best_dist) { best_dist = dist; best_idx = idx; }
+        }
+        if (best_dist <= max_dist) { best_idx_out[i] = best_idx; best_dist_out[i] = best_dist; nfound++; }
+    }
+    grid_free(g); free(cand);
+    return nfound;
+}
+
+/* ORBmatcher::SearchBySim3, src/ORBmatcher.cc:1166-1394: pts12 = KF1's map points (one per KF1 keypoint, valid = has a
+ * point, not already matched, not bad, depth/range tests) projected into KF2; pts21 the reverse; match12[i1] = idx2
+ * where both directions agree (:1375-1391), else -1. */
+int oracle_search_by_sim3(const oracle_frame_feats *kf1, const oracle_frame_feats *kf2, const oracle_proj_points *pts12,
+                          const oracle_proj_points *pts21, const float *sf1, const float *sf2, float th, int32_t *match12)
+{
+    int32_t *m1 = malloc(sizeof(int32_t) * (pts12->n ? pts12->n : 1)), *m2 = malloc(sizeof(int32_t) * (pts21->n ? pts21->n : 1));
+    int32_t *d1 = malloc(sizeof(int32_t) * (pts12->n ? pts12->n : 1)), *d2 = malloc(sizeof(int32_t) * (pts21->n ? pts21->n : 1));
+    oracle_window_best(kf2, pts12, sf2, NULL, th, 0, TH_HIGH, m1, d1);
+    oracle_window_best(kf1, pts21, sf1, NULL, th, 0, TH_HIGH, m2, d2);
+    int nfound = 0;
+    for (int i1 = 0; i1 < pts12->n; i1++) {
+        match12[i1] = -1;
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && idx2 < pts21->n && m2[idx2] == i1) { match12[i1] = idx2; nfound++; }
+    }
+    free(m1); free(m2); free(d1); free(d2);
+    return nfound;
+}
+
 /* ------------------------------------------------------------------ grayscale ingest (f4, first half) */
 
 /* cv::cvtColor RGB(A)/BGR(A) -> GRAY, 8U (src/Tracking.cc:177-202 call sites) */

@@ -169,6 +169,19 @@ int oracle_search_by_projection_last(const oracle_frame_feats *cur, const oracle
 int oracle_search_by_projection_points(const oracle_frame_feats *cur, const oracle_proj_points *pts, const float *scale_factors,
                                        float th, float nnratio, int32_t *match_cur);
 
+/* ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:1555-1685 */
+int oracle_search_by_projection_keyframe(const oracle_frame_feats *cur, const oracle_proj_points *pts, const float *scale_factors,
+                                         float th, int orb_dist, int check_ori, int32_t *match_cur);
+/* ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:305-415 */
+int oracle_search_by_projection_sim3(const oracle_frame_feats *kf, const oracle_proj_points *pts, const float *scale_factors,
+                                     float th, int32_t *match_kf);
+/* search half of ORBmatcher::Fuse (both overloads, :873-1164) and of each direction of SearchBySim3 */
+int oracle_window_best(const oracle_frame_feats *kf, const oracle_proj_points *pts, const float *scale_factors,
+                       const float *inv_sigma2, float th, int chi2, int max_dist, int32_t *best_idx, int32_t *best_dist);
+/* ORBmatcher::SearchBySim3, src/ORBmatcher.cc:1166-1394 */
+int oracle_search_by_sim3(const oracle_frame_feats *kf1, const oracle_frame_feats *kf2, const oracle_proj_points *pts12,
+                          const oracle_proj_points *pts21, const float *sf1, const float *sf2, float th, int32_t *match12);
+
 /* cv::cvtColor(CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY) for 8U, the conversion Tracking::GrabImage*
  * applies to colour input (src/Tracking.cc:177-202, :217-231, :254-268) [OpenCV generic path, from memory:
  * fixed point, yuv_shift 14, R2Y 4899, G2Y 9617, B2Y 1868, rounding 1<<13].  channels 3 or 4; rgb_order 1 = R first. */

@@ -36,11 +36,23 @@ struct DevPoints {
     const uint32_t *desc;
     const uint8_t *valid, *has_obs;
 };
+// One parameter block describes every projection-type search of src/ORBmatcher.cc (which tests, which window, which
+// claim rule); the extern "C" entry points below fill it per reference function.
 struct ProjParams {
-    int mode;          // 0: last frame (A), 1: map points (B)
+    int radius_mode;   // 0: th * sf[level]            1: RadiusByViewingCos(view_cos) [* th] * sf[level]
+    int bounds;        // 0: none  1: Frame bounds, inclusive (:1431-1434)  2: KeyFrame::IsInImage (src/KeyFrame.cc:649-652)
+    int need_pos_aux;  // 1: reject aux (= invzc) < 0 (:1426)
+    int lo_off, hi_off;// candidate levels [level + lo_off, level + hi_off] unless direction != 0
+    int direction;     // last-frame search: 1 bForward, 2 bBackward
+    int ur_mode;       // 0: none  1: |u - mbf*aux - uR| > r (:1467-1471)  2: |aux - uR| > r (:88-92)
+    int chi2;          // Fuse: reprojection gate 5.99 / 7.8 with inv_sigma2[octave], aux = ur (:967-992)
+    int max_dist;      // TH_HIGH, TH_LOW or ORBdist
+    int ratio;         // 1: same-level ratio test of the map-point search (:117-121)
+    int check_ori;
+    int claims;        // 0: points are independent (Fuse, SearchBySim3)  1: an accepted match of a point with
+                       // Observations() > 0 blocks its feature  2: every accepted match blocks it
     float th, mbf, nnratio;
-    int direction, check_ori;
-    float sf[ORBX_MAX_LEVELS];
+    float sf[ORBX_MAX_LEVELS], inv_sigma2[ORBX_MAX_LEVELS];
 };
 
 // ---- Frame::AssignFeaturesToGrid: CSR over the 64x48 cells, ascending feature index inside a cell
@@ -90,19 +102,19 @@ __device__ __forceinline__ bool point_window(const DevFrame &F, const DevPoints 
     const int lvl = P.level[i] & (ORBX_MAX_LEVELS - 1);
     float r;
     int min_l, max_l;
-    if (pp.mode == 0) {
-        if (P.aux[i] < 0) return false;                                // invzc < 0 (:1426)
-        if (u < F.min_x || u > F.max_x || v < F.min_y || v > F.max_y) return false; // :1431-1434
+    if (pp.need_pos_aux && P.aux[i] < 0) return false;                 // invzc < 0 (:1426)
+    if (pp.bounds == 1) { if (u < F.min_x || u > F.max_x || v < F.min_y || v > F.max_y) return false; } // :1431-1434
+    else if (pp.bounds == 2) { if (!(u >= F.min_x && u < F.max_x && v >= F.min_y && v < F.max_y)) return false; }
+    if (pp.radius_mode == 0) {
         r = pp.th * pp.sf[lvl];                                        // :1439
-        if (pp.direction == 1) { min_l = lvl; max_l = -1; }            // bForward  (:1443)
-        else if (pp.direction == 2) { min_l = 0; max_l = lvl; }        // bBackward (:1445)
-        else { min_l = lvl - 1; max_l = lvl + 1; }
     } else {
         float rr = (double)P.view_cos[i] > 0.998 ? 2.5f : 4.0f;        // RadiusByViewingCos (:131-137)
         if ((double)pp.th != 1.0) rr *= pp.th;                         // bFactor (:52, :66-67)
         r = rr * pp.sf[lvl];
-        min_l = lvl - 1; max_l = lvl;
     }
+    if (pp.direction == 1) { min_l = lvl; max_l = -1; }                // bForward  (:1443)
+    else if (pp.direction == 2) { min_l = 0; max_l = lvl; }            // bBackward (:1445)
+    else { min_l = lvl + pp.lo_off; max_l = lvl + pp.hi_off; }
     // GetFeaturesInArea cell range (src/Frame.cc:391-406)
     const int a = (int)floorf((u - F.min_x - r) * F.inv_w);
     const int cx0 = a > 0 ? a : 0;
@@ -132,12 +144,24 @@ __device__ __forceinline__ bool cand_ok(const DevFrame &F, const DevPoints &P, c
     const float distx = F.x[k] - w.u, disty = F.y[k] - w.v;
     if (!(fabsf(distx) < w.r && fabsf(disty) < w.r)) return false; // :434
     const float ur_k = F.u_right[k];
-    if (ur_k > 0) {
-        if (pp.mode == 0) {
+    if (pp.ur_mode && ur_k > 0) {
+        if (pp.ur_mode == 1) {
             const float ur = w.u - pp.mbf * P.aux[i];                  // :1467-1471
             if (fabsf(ur - ur_k) > w.r) return false;
         } else {
             if (fabsf(P.aux[i] - ur_k) > w.r) return false;            // :88-92 (r * scale == w.r)
+        }
+    }
+    if (pp.chi2) {                                                     // Fuse, :961-992 (float products, double compare)
+        const float inv = pp.inv_sigma2[oct & (ORBX_MAX_LEVELS - 1)];
+        const float ex = -distx, ey = -disty;
+        if (ur_k >= 0) {
+            const float er = P.aux[i] - ur_k;
+            const float e2 = ex * ex + ey * ey + er * er;
+            if ((double)(e2 * inv) > 7.8) return false;
+        } else {
+            const float e2 = ex * ex + ey * ey;
+            if ((double)(e2 * inv) > 5.99) return false;
         }
     }
     return true;
@@ -206,7 +230,8 @@ extern __shared__ __align__(16) int resolve_smem[];
 __global__ __launch_bounds__(1024) void k_proj_resolve(DevFrame F, DevPoints P, ProjParams pp, const int *__restrict__ beg,
                                                        const int *__restrict__ cnt, const uint32_t *__restrict__ entries,
                                                        int *__restrict__ choice_a, int *__restrict__ choice_b,
-                                                       int32_t *__restrict__ match, int *__restrict__ out_n)
+                                                       int32_t *__restrict__ match, int *__restrict__ out_n,
+                                                       int32_t *__restrict__ pt_choice, int32_t *__restrict__ pt_dist)
 {
     __shared__ int s_first, s_cnt;
     __shared__ int hist[30];
@@ -223,7 +248,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(DevFrame F, DevPoints P, 
         if (tid == 0) s_first = 0x7FFFFFFF;
         __syncthreads();
         for (int i = tid; i < P.n; i += nt)
-            if (cur[i] >= 0 && P.has_obs[i]) atomicMin(&owner[cur[i]], i);
+            if (cur[i] >= 0 && pp.claims && (pp.claims == 2 || P.has_obs[i])) atomicMin(&owner[cur[i]], i);
         __syncthreads();
         int first = 0x7FFFFFFF;
         for (int i = stable + tid; i < P.n; i += nt) {
@@ -232,16 +257,17 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(DevFrame F, DevPoints P, 
             for (int e = e0; e < e1; e++) {
                 const uint32_t en = entries[e];
                 const int f = en & 0xFFFF, dist = (en >> 16) & 0x1FF, lv = en >> 25;
-                if (F.occupied[f] || owner[f] < i) continue; // mvpMapPoints[f] holds a point with Observations() > 0
+                if (pp.claims && (F.occupied[f] || owner[f] < i)) continue; // the feature is held (see ProjParams::claims)
                 if (dist < b1) { b2 = b1; l2 = l1; b1 = dist; l1 = lv; bi = f; }
                 else if (dist < b2) { b2 = dist; l2 = lv; }
             }
             int c = -1;
-            if (b1 <= 100) { // TH_HIGH
-                if (pp.mode == 0) c = bi;
+            if (b1 <= pp.max_dist) {
+                if (!pp.ratio) c = bi;
                 else if (!(l1 == l2 && (float)b1 > pp.nnratio * (float)b2)) c = bi; // :117-121
             }
             nxt[i] = c;
+            pt_dist[i] = c >= 0 ? b1 : 256; // final once the point is stable: an unchanged choice keeps its distance
             if (c != cur[i] && i < first) first = i;
         }
         if (first != 0x7FFFFFFF) atomicMin(&s_first, first);
@@ -263,10 +289,11 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(DevFrame F, DevPoints P, 
     int local = 0;
     for (int i = tid; i < P.n; i += nt) {
         const int f = cur[i];
+        pt_choice[i] = f;
         if (f < 0) continue;
         atomicMax(&match[f], i);
         local++;
-        if (pp.mode == 0 && pp.check_ori) {
+        if (pp.check_ori) {
             float rot = P.angle[i] - F.angle[f];               // :1493-1500
             if (rot < 0.0f) rot += 360.0f;
             int bin = (int)roundf(rot * (1.0f / 30));
@@ -279,7 +306,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(DevFrame F, DevPoints P, 
     if (local) atomicAdd(&s_cnt, local);
     __threadfence_block();
     __syncthreads();
-    if (pp.mode == 0 && pp.check_ori) {
+    if (pp.check_ori) {
         if (tid == 0) { // ComputeThreeMaxima (:1687-1728)
             int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
             for (int i = 0; i < 30; i++) {
@@ -298,7 +325,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(DevFrame F, DevPoints P, 
             const int f = cur[i];
             if (f < 0) continue;
             const int b = nxt[i];
-            if (b != keep3[0] && b != keep3[1] && b != keep3[2]) { match[f] = -1; removed++; } // :1518-1523, one decrement per entry
+            if (b != keep3[0] && b != keep3[1] && b != keep3[2]) { match[f] = -1; pt_choice[i] = -1; removed++; } // :1518-1523, one decrement per entry
         }
         if (removed) atomicSub(&s_cnt, removed);
         __threadfence_block();
@@ -321,21 +348,31 @@ static thread_local ProjCtx g_proj[16];
 static size_t pa16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 static int proj_run(int device, const orbx_frame_feats *cur, const orbx_proj_points *pts, const float *sf, int nlevels,
-                    const ProjParams &pp_in, int32_t *match_cur, int *nmatches)
+                    const ProjParams &pp_in, int32_t *match_cur, int *nmatches, const float *inv_sigma2 = nullptr,
+                    int32_t *pt_choice = nullptr, int32_t *pt_dist = nullptr)
 {
+    int nm_dummy = 0;
+    std::vector<int32_t> mc_dummy;
+    if (!nmatches) nmatches = &nm_dummy;
+    if (!match_cur && cur && cur->n >= 0) { mc_dummy.resize((size_t)cur->n + 1); match_cur = mc_dummy.data(); }
     if (!cur || !pts || !sf || !match_cur || !nmatches || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || cur->n < 0 || pts->n < 0 ||
         cur->n >= 65536 || pts->n > (1 << 20)) {
         orbx_set_error("search_by_projection: invalid argument");
         return ORBX_E_INVALID;
     }
-    if (cur->n && (!cur->x || !cur->y || !cur->octave || !cur->angle || !cur->u_right || !cur->desc || !cur->occupied)) { orbx_set_error("frame arrays missing"); return ORBX_E_INVALID; }
-    if (pts->n && (!pts->u || !pts->v || !pts->aux || !pts->level || !pts->desc || !pts->valid || !pts->has_obs ||
-                   (pp_in.mode == 0 && !pts->angle) || (pp_in.mode == 1 && !pts->view_cos))) { orbx_set_error("point arrays missing"); return ORBX_E_INVALID; }
+    const bool need_aux = pp_in.need_pos_aux || pp_in.ur_mode || pp_in.chi2;
+    if (cur->n && (!cur->x || !cur->y || !cur->octave || !cur->u_right || !cur->desc || (pp_in.check_ori && !cur->angle) ||
+                   (pp_in.claims && !cur->occupied))) { orbx_set_error("frame arrays missing"); return ORBX_E_INVALID; }
+    if (pts->n && (!pts->u || !pts->v || !pts->level || !pts->desc || !pts->valid || (need_aux && !pts->aux) ||
+                   (pp_in.claims == 1 && !pts->has_obs) || (pp_in.check_ori && !pts->angle) ||
+                   (pp_in.radius_mode == 1 && !pts->view_cos))) { orbx_set_error("point arrays missing"); return ORBX_E_INVALID; }
+    if (pp_in.chi2 && !inv_sigma2) { orbx_set_error("inv_sigma2 missing"); return ORBX_E_INVALID; }
     if (!(cur->max_x > cur->min_x) || !(cur->max_y > cur->min_y)) { orbx_set_error("empty image bounds"); return ORBX_E_INVALID; }
     for (int i = 0; i < pts->n; i++)
         if (pts->valid[i] && (pts->level[i] < 0 || pts->level[i] >= nlevels)) { orbx_set_error("point %d: level %d out of range", i, pts->level[i]); return ORBX_E_INVALID; }
     for (int i = 0; i < cur->n; i++) match_cur[i] = -1;
     *nmatches = 0;
+    for (int i = 0; i < pts->n; i++) { if (pt_choice) pt_choice[i] = -1; if (pt_dist) pt_dist[i] = 256; }
     if (cur->n == 0 || pts->n == 0) return ORBX_OK;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || device >= 16) {
@@ -363,11 +400,15 @@ static int proj_run(int device, const orbx_frame_feats *cur, const orbx_proj_poi
     }
     uint8_t *h = c->h_blob;
     memcpy(h + fx, cur->x, 4 * nc); memcpy(h + fy, cur->y, 4 * nc); memcpy(h + fo, cur->octave, 4 * nc);
-    memcpy(h + fa, cur->angle, 4 * nc); memcpy(h + fu, cur->u_right, 4 * nc); memcpy(h + fd, cur->desc, 32 * nc); memcpy(h + fq, cur->occupied, nc);
-    memcpy(h + pu, pts->u, 4 * np); memcpy(h + pv, pts->v, 4 * np); memcpy(h + pa, pts->aux, 4 * np); memcpy(h + pl, pts->level, 4 * np);
+    if (cur->angle) memcpy(h + fa, cur->angle, 4 * nc); else memset(h + fa, 0, 4 * nc);
+    memcpy(h + fu, cur->u_right, 4 * nc); memcpy(h + fd, cur->desc, 32 * nc);
+    if (cur->occupied) memcpy(h + fq, cur->occupied, nc); else memset(h + fq, 0, nc);
+    memcpy(h + pu, pts->u, 4 * np); memcpy(h + pv, pts->v, 4 * np); memcpy(h + pl, pts->level, 4 * np);
+    if (pts->aux) memcpy(h + pa, pts->aux, 4 * np); else memset(h + pa, 0, 4 * np);
     if (pts->angle) memcpy(h + pg, pts->angle, 4 * np); else memset(h + pg, 0, 4 * np);
     if (pts->view_cos) memcpy(h + pc, pts->view_cos, 4 * np); else memset(h + pc, 0, 4 * np);
-    memcpy(h + pd, pts->desc, 32 * np); memcpy(h + pval, pts->valid, np); memcpy(h + pobs, pts->has_obs, np);
+    memcpy(h + pd, pts->desc, 32 * np); memcpy(h + pval, pts->valid, np);
+    if (pts->has_obs) memcpy(h + pobs, pts->has_obs, np); else memset(h + pobs, 1, np);
     ORBX_HIP(hipMemcpyAsync(c->d_blob, h, blob, hipMemcpyHostToDevice, c->stream));
     const uint8_t *d = c->d_blob;
     DevFrame F;
@@ -381,23 +422,28 @@ static int proj_run(int device, const orbx_frame_feats *cur, const orbx_proj_poi
     P.level = (const int32_t *)(d + pl); P.angle = (const float *)(d + pg); P.view_cos = (const float *)(d + pc);
     P.desc = (const uint32_t *)(d + pd); P.valid = d + pval; P.has_obs = d + pobs;
     ProjParams pp = pp_in;
-    for (int i = 0; i < ORBX_MAX_LEVELS; i++) pp.sf[i] = i < nlevels ? sf[i] : 0.f;
-    // work: cell_off[3073] | cell_idx[nc] | beg[np] | cnt[np] | pool_used | choice_a[np] | choice_b[np] | match[nc] | out_n
+    for (int i = 0; i < ORBX_MAX_LEVELS; i++) {
+        pp.sf[i] = i < nlevels ? sf[i] : 0.f;
+        pp.inv_sigma2[i] = (inv_sigma2 && i < nlevels) ? inv_sigma2[i] : 0.f;
+    }
+    // work: cell_off[3073] | cell_idx[nc] | beg[np] | cnt[np] | pool_used | choice_a[np] | choice_b[np] | match[nc] | out_n |
+    //       pt_choice[np] | pt_dist[np]
     size_t w = 0;
     auto wtake = [&](size_t bytes) { const size_t r = w; w += pa16(bytes); return r; };
     const size_t w_coff = wtake(4 * (PG_CELLS + 1)), w_cidx = wtake(4 * nc), w_beg = wtake(4 * np), w_cnt = wtake(4 * np), w_used = wtake(16),
-                 w_ca = wtake(4 * np), w_cb = wtake(4 * np), w_match = wtake(4 * nc), w_n = wtake(16);
+                 w_ca = wtake(4 * np), w_cb = wtake(4 * np), w_match = wtake(4 * nc), w_n = wtake(16), w_pc = wtake(4 * np),
+                 w_pd = wtake(4 * np);
     if (w > c->work_cap) {
         if (c->d_work) ORBX_HIP(hipFree(c->d_work));
         c->d_work = nullptr;
         ORBX_HIP(hipMalloc((void **)&c->d_work, w * 2));
         c->work_cap = w * 2;
     }
-    if ((nc + 8) > c->out_cap) {
+    if ((nc + 2 * np + 8) > c->out_cap) {
         if (c->h_out) ORBX_HIP(hipHostFree(c->h_out));
         c->h_out = nullptr;
-        ORBX_HIP(hipHostMalloc((void **)&c->h_out, sizeof(int32_t) * (nc + 8) * 2, hipHostMallocDefault));
-        c->out_cap = (nc + 8) * 2;
+        ORBX_HIP(hipHostMalloc((void **)&c->h_out, sizeof(int32_t) * (nc + 2 * np + 8) * 2, hipHostMallocDefault));
+        c->out_cap = (nc + 2 * np + 8) * 2;
     }
     const size_t resolve_lds = sizeof(int) * (nc + 4);
     if (resolve_lds > 150 * 1024) { orbx_set_error("too many features for one search"); return ORBX_E_INVALID; }
@@ -416,11 +462,14 @@ static int proj_run(int device, const orbx_frame_feats *cur, const orbx_proj_poi
         hipLaunchKernelGGL(k_proj_lists, dim3((pts->n + 3) / 4), dim3(256), 0, c->stream, F, P, pp, d_coff, d_cidx, d_beg, d_cnt,
                            c->d_entries, (int)c->ent_cap, d_used);
         hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(1024), resolve_lds, c->stream, F, P, pp, d_beg, d_cnt, c->d_entries,
-                           (int *)(wk + w_ca), (int *)(wk + w_cb), (int32_t *)(wk + w_match), (int *)(wk + w_n));
+                           (int *)(wk + w_ca), (int *)(wk + w_cb), (int32_t *)(wk + w_match), (int *)(wk + w_n),
+                           (int32_t *)(wk + w_pc), (int32_t *)(wk + w_pd));
         ORBX_HIP(hipGetLastError());
         ORBX_HIP(hipMemcpyAsync(c->h_out, wk + w_match, 4 * nc, hipMemcpyDeviceToHost, c->stream));
         ORBX_HIP(hipMemcpyAsync(c->h_out + nc, wk + w_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         ORBX_HIP(hipMemcpyAsync(c->h_out + nc + 1, d_used, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        if (pt_choice) ORBX_HIP(hipMemcpyAsync(c->h_out + nc + 8, wk + w_pc, 4 * np, hipMemcpyDeviceToHost, c->stream));
+        if (pt_dist) ORBX_HIP(hipMemcpyAsync(c->h_out + nc + 8 + np, wk + w_pd, 4 * np, hipMemcpyDeviceToHost, c->stream));
         ORBX_HIP(hipStreamSynchronize(c->stream));
         const size_t used = (size_t)(unsigned)c->h_out[nc + 1];
         if (used <= c->ent_cap) break;
@@ -432,6 +481,8 @@ static int proj_run(int device, const orbx_frame_feats *cur, const orbx_proj_poi
     }
     memcpy(match_cur, c->h_out, 4 * nc);
     *nmatches = c->h_out[nc];
+    if (pt_choice) memcpy(pt_choice, c->h_out + nc + 8, 4 * np);
+    if (pt_dist) memcpy(pt_dist, c->h_out + nc + 8 + np, 4 * np);
     return ORBX_OK;
 }
 
@@ -442,7 +493,9 @@ extern "C" int orbx_search_by_projection_last_frame(int device, const orbx_frame
     if (direction < 0 || direction > 2) { orbx_set_error("direction must be 0 (none), 1 (forward) or 2 (backward)"); return ORBX_E_INVALID; }
     ProjParams pp;
     memset(&pp, 0, sizeof pp);
-    pp.mode = 0; pp.th = th; pp.mbf = mbf; pp.direction = direction; pp.check_ori = check_orientation;
+    pp.radius_mode = 0; pp.bounds = 1; pp.need_pos_aux = 1; pp.lo_off = -1; pp.hi_off = 1; pp.direction = direction;
+    pp.ur_mode = 1; pp.max_dist = 100; pp.check_ori = check_orientation; pp.claims = 1;
+    pp.th = th; pp.mbf = mbf;
     return proj_run(device, cur, pts, scale_factors, nlevels, pp, match_cur, nmatches);
 }
 
@@ -452,6 +505,64 @@ extern "C" int orbx_search_by_projection_map_points(int device, const orbx_frame
 {
     ProjParams pp;
     memset(&pp, 0, sizeof pp);
-    pp.mode = 1; pp.th = th; pp.nnratio = nnratio;
+    pp.radius_mode = 1; pp.lo_off = -1; pp.hi_off = 0; pp.ur_mode = 2; pp.max_dist = 100; pp.ratio = 1; pp.claims = 1;
+    pp.th = th; pp.nnratio = nnratio;
     return proj_run(device, cur, pts, scale_factors, nlevels, pp, match_cur, nmatches);
+}
+
+extern "C" int orbx_search_by_projection_keyframe(int device, const orbx_frame_feats *cur, const orbx_proj_points *pts,
+                                                  const float *scale_factors, int nlevels, float th, int orb_dist,
+                                                  int check_orientation, int32_t *match_cur, int *nmatches)
+{
+    ProjParams pp;
+    memset(&pp, 0, sizeof pp);
+    pp.bounds = 1; pp.lo_off = -1; pp.hi_off = 1; pp.max_dist = orb_dist; pp.check_ori = check_orientation; pp.claims = 2;
+    pp.th = th;
+    return proj_run(device, cur, pts, scale_factors, nlevels, pp, match_cur, nmatches);
+}
+
+extern "C" int orbx_search_by_projection_sim3(int device, const orbx_frame_feats *kf, const orbx_proj_points *pts,
+                                              const float *scale_factors, int nlevels, float th, int32_t *match_kf, int *nmatches)
+{
+    ProjParams pp;
+    memset(&pp, 0, sizeof pp);
+    pp.bounds = 2; pp.lo_off = -1; pp.hi_off = 0; pp.max_dist = 50; pp.claims = 2;
+    pp.th = th;
+    return proj_run(device, kf, pts, scale_factors, nlevels, pp, match_kf, nmatches);
+}
+
+extern "C" int orbx_window_best(int device, const orbx_frame_feats *kf, const orbx_proj_points *pts, const float *scale_factors,
+                                const float *inv_sigma2, int nlevels, float th, int chi2, int max_dist, int32_t *best_idx,
+                                int32_t *best_dist, int *nfound)
+{
+    if (!best_idx || max_dist < 0 || max_dist > 256) { orbx_set_error("orbx_window_best: invalid argument"); return ORBX_E_INVALID; }
+    ProjParams pp;
+    memset(&pp, 0, sizeof pp);
+    pp.bounds = 2; pp.lo_off = -1; pp.hi_off = 0; pp.max_dist = max_dist; pp.chi2 = chi2 ? 1 : 0; pp.claims = 0;
+    pp.th = th;
+    return proj_run(device, kf, pts, scale_factors, nlevels, pp, nullptr, nfound, inv_sigma2, best_idx, best_dist);
+}
+
+extern "C" int orbx_search_by_sim3(int device, const orbx_frame_feats *kf1, const orbx_frame_feats *kf2,
+                                   const orbx_proj_points *pts12, const orbx_proj_points *pts21, const float *scale_factors1,
+                                   const float *scale_factors2, int nlevels, float th, int32_t *match12, int *nfound)
+{
+    if (!kf1 || !kf2 || !pts12 || !pts21 || !match12 || !nfound || pts12->n != kf1->n || pts21->n != kf2->n) {
+        orbx_set_error("orbx_search_by_sim3: invalid argument (one projected point per keypoint on each side)");
+        return ORBX_E_INVALID;
+    }
+    std::vector<int32_t> m1((size_t)pts12->n + 1), m2((size_t)pts21->n + 1);
+    int n1 = 0, n2 = 0;
+    int rc = orbx_window_best(device, kf2, pts12, scale_factors2, nullptr, nlevels, th, 0, 100, m1.data(), nullptr, &n1); // :1218-1292
+    if (rc) return rc;
+    rc = orbx_window_best(device, kf1, pts21, scale_factors1, nullptr, nlevels, th, 0, 100, m2.data(), nullptr, &n2);     // :1295-1372
+    if (rc) return rc;
+    int found = 0;
+    for (int i1 = 0; i1 < pts12->n; i1++) { // the agreement check, :1375-1391
+        const int idx2 = m1[i1];
+        match12[i1] = -1;
+        if (idx2 >= 0 && m2[idx2] == i1) { match12[i1] = idx2; found++; }
+    }
+    *nfound = found;
+    return ORBX_OK;
 }

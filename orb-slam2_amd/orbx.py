@@ -93,6 +93,11 @@ def lib():
     L.orbx_bow_transform.argtypes = [vp, vp, i, i, vp, vp, vp, vp, vp, ip, vp, vp, vp, ip]
     L.orbx_search_by_projection_last_frame.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, i, f, i, f, i, vp, ip]
     L.orbx_search_by_projection_map_points.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, i, f, f, vp, ip]
+    L.orbx_search_by_projection_keyframe.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, i, f, i, i, vp, ip]
+    L.orbx_search_by_projection_sim3.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, i, f, vp, ip]
+    L.orbx_window_best.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, vp, i, f, i, i, vp, vp, ip]
+    L.orbx_search_by_sim3.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.POINTER(ProjPoints),
+                                      vp, vp, i, f, vp, ip]
     L.orbx_distinctive_descriptors.argtypes = [i, vp, vp, i, vp]
     L.orbx_profile_enable.argtypes = [vp, i]
     L.orbx_profile_read.argtypes = [vp, vp, vp, i]
@@ -381,7 +386,8 @@ class ORBmatcher:
             keep[k] = np.ascontiguousarray(d[k], dtype=dt); return keep[k].ctypes.data
         s_ = FrameFeats()
         s_.x = arr("x", np.float32); s_.y = arr("y", np.float32); s_.octave = arr("octave", np.int32); s_.angle = arr("angle", np.float32)
-        s_.u_right = arr("u_right", np.float32); s_.desc = arr("desc", np.uint8); s_.occupied = arr("occupied", np.uint8)
+        s_.u_right = arr("u_right", np.float32); s_.desc = arr("desc", np.uint8)
+        s_.occupied = arr("occupied", np.uint8) if d.get("occupied") is not None else None
         s_.n = len(keep["x"])
         s_.min_x, s_.min_y, s_.max_x, s_.max_y = [float(v) for v in d["bounds"]]
         return s_, keep
@@ -417,6 +423,44 @@ class ORBmatcher:
         out = np.full(a.n, -1, np.int32); n = C.c_int()
         _check(lib().orbx_search_by_projection_map_points(self.device, C.byref(a), C.byref(b), _p(sf), len(sf), th, self.mfNNratio,
                                                           _p(out), C.byref(n)))
+        return out, n.value
+
+    def SearchByProjectionKeyFrame(self, CurrentFrame, KFPoints, scaleFactors, th, ORBdist):
+        """SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:1555-1685
+        -> (match_cur, nmatches)"""
+        a, ka = self._frame(CurrentFrame); b, kb = self._points(KFPoints)
+        sf = np.ascontiguousarray(scaleFactors, np.float32)
+        out = np.full(a.n, -1, np.int32); n = C.c_int()
+        _check(lib().orbx_search_by_projection_keyframe(self.device, C.byref(a), C.byref(b), _p(sf), len(sf), th, int(ORBdist),
+                                                        int(self.mbCheckOrientation), _p(out), C.byref(n)))
+        return out, n.value
+
+    def SearchByProjectionSim3(self, pKF, vpPoints, scaleFactors, th):
+        """SearchByProjection(KeyFrame *pKF, Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:305-415 -> (match_kf, nmatches)"""
+        a, ka = self._frame(pKF); b, kb = self._points(vpPoints)
+        sf = np.ascontiguousarray(scaleFactors, np.float32)
+        out = np.full(a.n, -1, np.int32); n = C.c_int()
+        _check(lib().orbx_search_by_projection_sim3(self.device, C.byref(a), C.byref(b), _p(sf), len(sf), th, _p(out), C.byref(n)))
+        return out, n.value
+
+    def Fuse(self, pKF, vpMapPoints, scaleFactors, invLevelSigma2=None, th=3.0, max_dist=50):
+        """search half of both Fuse overloads (src/ORBmatcher.cc:873-1164): invLevelSigma2 given -> the chi2-gated
+        variant of Fuse(pKF, vpMapPoints, th).  -> (best_idx, best_dist, nfound)"""
+        a, ka = self._frame(pKF); b, kb = self._points(vpMapPoints)
+        sf = np.ascontiguousarray(scaleFactors, np.float32)
+        sg = None if invLevelSigma2 is None else np.ascontiguousarray(invLevelSigma2, np.float32)
+        bi = np.full(b.n, -1, np.int32); bd = np.full(b.n, 256, np.int32); n = C.c_int()
+        _check(lib().orbx_window_best(self.device, C.byref(a), C.byref(b), _p(sf), None if sg is None else _p(sg), len(sf), th,
+                                      0 if sg is None else 1, int(max_dist), _p(bi), _p(bd), C.byref(n)))
+        return bi, bd, n.value
+
+    def SearchBySim3(self, pKF1, pKF2, pts12, pts21, scaleFactors1, scaleFactors2, th):
+        """SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th), src/ORBmatcher.cc:1166-1394 -> (match12, nFound)"""
+        a, ka = self._frame(pKF1); b, kb = self._frame(pKF2); p, kp = self._points(pts12); q, kq = self._points(pts21)
+        s1 = np.ascontiguousarray(scaleFactors1, np.float32); s2 = np.ascontiguousarray(scaleFactors2, np.float32)
+        out = np.full(a.n, -1, np.int32); n = C.c_int()
+        _check(lib().orbx_search_by_sim3(self.device, C.byref(a), C.byref(b), C.byref(p), C.byref(q), _p(s1), _p(s2), len(s1), th,
+                                         _p(out), C.byref(n)))
         return out, n.value
 
     def SearchForTriangulation(self, pKF1, pKF2, F12, ex, ey, scaleFactors2, levelSigma2_2, bOnlyStereo=False):

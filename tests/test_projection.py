@@ -194,3 +194,145 @@ def test_hip_projection_edge_cases(pkg, oracle):
     with pytest.raises(pkg.OrbxError):
         bad = dict(pts); bad["level"] = pts["level"].copy(); bad["level"][0] = 12
         mt.SearchByProjectionLastFrame(cur, bad, sf, 7.0)
+
+
+# ---------------------------------------------------------------- the other projection-type searches of row f1:
+# SearchByProjection(Frame, KeyFrame, ...) :1555-1685, SearchByProjection(KeyFrame, Scw, ...) :305-415,
+# Fuse x2 :873-1164 (search half), SearchBySim3 :1166-1394
+
+def _py_grid(cur):
+    mnx, mny, mxx, mxy = [f32(v) for v in cur["bounds"]]
+    inv_w = f32(f32(64) / f32(mxx - mnx)); inv_h = f32(f32(48) / f32(mxy - mny))
+    grid = {}
+    for i in range(len(cur["x"])):
+        px = int(math.floor(abs(float(f32(f32(cur["x"][i] - mnx) * inv_w))) + 0.5)) * (1 if f32(cur["x"][i] - mnx) >= 0 else -1)
+        py = int(math.floor(abs(float(f32(f32(cur["y"][i] - mny) * inv_h))) + 0.5)) * (1 if f32(cur["y"][i] - mny) >= 0 else -1)
+        if 0 <= px < 64 and 0 <= py < 48:
+            grid.setdefault((px, py), []).append(i)
+    return grid, inv_w, inv_h
+
+
+def _py_search2(kf, pts, sf, kind, th, max_dist, inv_sigma2=None):
+    """kind: 'reloc' (Frame bounds, levels l-1..l+1, blocking), 'loop' (IsInImage, l-1..l, blocking),
+    'best' (IsInImage, l-1..l, independent, optional chi2)"""
+    mnx, mny, mxx, mxy = [f32(v) for v in kf["bounds"]]
+    grid, inv_w, inv_h = _py_grid(kf)
+    n = len(kf["x"])
+    match = np.full(n, -1, np.int32)
+    blocked = kf["occupied"].astype(bool).copy() if kind != "best" else np.zeros(n, bool)
+    bi_out = np.full(len(pts["u"]), -1, np.int32); bd_out = np.full(len(pts["u"]), 256, np.int32)
+    nm = 0
+    for i in range(len(pts["u"])):
+        if not pts["valid"][i]: continue
+        u, v, lvl = f32(pts["u"][i]), f32(pts["v"][i]), int(pts["level"][i])
+        if kind == "reloc":
+            if u < mnx or u > mxx or v < mny or v > mxy: continue
+        else:
+            if not (u >= mnx and u < mxx and v >= mny and v < mxy): continue
+        r = f32(f32(th) * sf[lvl])
+        cand = _py_area(kf, grid, inv_w, inv_h, u, v, r, lvl - 1, lvl + 1) if kind == "reloc" else _py_area(kf, grid, inv_w, inv_h, u, v, r, -1, -1)
+        b1 = 256; bi = -1
+        for k in cand:
+            if blocked[k]: continue
+            kl = int(kf["octave"][k])
+            if kind != "reloc" and (kl < lvl - 1 or kl > lvl): continue
+            if inv_sigma2 is not None:
+                ex = f32(u - kf["x"][k]); ey = f32(v - kf["y"][k])
+                if kf["u_right"][k] >= 0:
+                    er = f32(pts["aux"][i] - kf["u_right"][k])
+                    e2 = f32(f32(f32(ex * ex) + f32(ey * ey)) + f32(er * er))
+                    if float(f32(e2 * inv_sigma2[kl])) > 7.8: continue
+                else:
+                    e2 = f32(f32(ex * ex) + f32(ey * ey))
+                    if float(f32(e2 * inv_sigma2[kl])) > 5.99: continue
+            d = int(POP[pts["desc"][i] ^ kf["desc"][k]].sum())
+            if d < b1: b1, bi = d, k
+        if b1 <= max_dist:
+            nm += 1
+            bi_out[i] = bi; bd_out[i] = b1
+            if kind != "best":
+                match[bi] = i; blocked[bi] = True
+    return match, nm, bi_out, bd_out
+
+
+def _sim3_scene(seed, n=700):
+    """two keyframes seeing the same synthetic structure; point i of each side belongs to keypoint i"""
+    c1, p1, sf = _scene(seed, n, n, stereo_frac=0.0)
+    rng = np.random.Generator(np.random.PCG64(seed + 100))
+    perm = rng.permutation(n)
+    c2 = dict(c1)
+    for k in ("x", "y", "octave", "angle", "u_right", "desc", "occupied"):
+        c2[k] = c1[k][perm].copy()
+    c2["x"] = (c2["x"] + rng.normal(0, 1.0, n)).astype(f32); c2["y"] = (c2["y"] + rng.normal(0, 1.0, n)).astype(f32)
+    c2["desc"] = synth.flip_bits(rng, c2["desc"], 0.05)
+    inv = np.argsort(perm)
+    def side(src_kf, dst_kf, dst_of_src):
+        m = len(src_kf["x"])
+        return dict(u=(dst_kf["x"][dst_of_src] + rng.normal(0, 2.5, m)).astype(f32), v=(dst_kf["y"][dst_of_src] + rng.normal(0, 2.5, m)).astype(f32),
+                    aux=np.zeros(m, f32), level=np.clip(dst_kf["octave"][dst_of_src] + rng.integers(0, 2, m), 0, 7).astype(np.int32),
+                    angle=np.zeros(m, f32), view_cos=np.ones(m, f32), desc=src_kf["desc"], valid=(rng.random(m) < 0.85).astype(np.uint8),
+                    has_obs=np.ones(m, np.uint8))
+    return c1, c2, side(c1, c2, inv), side(c2, c1, perm), sf
+
+
+@pytest.mark.parametrize("seed,dense", [(11, False), (12, True)])
+def test_oracle_vs_python_other_searches(oracle, seed, dense):
+    cur, pts, sf = _scene(seed, 500, 400, dense=dense)
+    inv_s2 = (1.0 / (sf * sf)).astype(f32)
+    m, n = oracle.search_by_projection_keyframe(cur, pts, sf, 10.0, 100, False)
+    pm, pn, _, _ = _py_search2(cur, pts, sf, "reloc", 10.0, 100)
+    assert n == pn and (m == pm).all()
+    m, n = oracle.search_by_projection_sim3(cur, pts, sf, 10.0)
+    pm, pn, _, _ = _py_search2(cur, pts, sf, "loop", 10.0, 50)
+    assert n == pn and (m == pm).all()
+    p2 = dict(pts); p2["aux"] = (pts["u"] - 8).astype(f32)
+    for chi2 in (0, 1):
+        bi, bd, n = oracle.window_best(cur, p2, sf, inv_s2, 4.0, chi2, 50)
+        _, pn, pbi, pbd = _py_search2(cur, p2, sf, "best", 4.0, 50, inv_s2 if chi2 else None)
+        assert n == pn and (bi == pbi).all() and (bd == pbd).all(), chi2
+    assert n > 20
+
+
+def test_oracle_sim3_agreement(oracle):
+    c1, c2, p12, p21, sf = _sim3_scene(13, 400)
+    m12, n = oracle.search_by_sim3(c1, c2, p12, p21, sf, sf, 7.5)
+    _, _, b1, _ = _py_search2(c2, p12, sf, "best", 7.5, 100)
+    _, _, b2, _ = _py_search2(c1, p21, sf, "best", 7.5, 100)
+    exp = np.array([b1[i] if b1[i] >= 0 and b2[b1[i]] == i else -1 for i in range(len(b1))], np.int32)
+    assert (m12 == exp).all() and n == (exp >= 0).sum() and n > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,dense", [(14, False), (15, True), (16, True)])
+def test_hip_other_searches_parity(pkg, oracle, seed, dense):
+    cur, pts, sf = _scene(seed, 1500, 1200, dense=dense)
+    inv_s2 = (1.0 / (sf * sf)).astype(f32)
+    for ori in (True, False):
+        mt = pkg.ORBmatcher(0.9, ori)
+        for th, od in ((10.0, 100), (3.0, 64)):
+            got, n = mt.SearchByProjectionKeyFrame(cur, pts, sf, th, od)
+            exp, en = oracle.search_by_projection_keyframe(cur, pts, sf, th, od, ori)
+            assert n == en and (got == exp).all(), (ori, th)
+    mt = pkg.ORBmatcher(0.9, True)
+    for th in (10.0, 4.0):
+        got, n = mt.SearchByProjectionSim3(cur, pts, sf, th)
+        exp, en = oracle.search_by_projection_sim3(cur, pts, sf, th)
+        assert n == en and (got == exp).all(), th
+    p2 = dict(pts); p2["aux"] = (pts["u"] - 8).astype(f32)
+    for th, chi2, md in ((3.0, 1, 50), (4.0, 0, 50), (7.5, 0, 100), (12.0, 1, 50)):
+        bi, bd, n = mt.Fuse(cur, p2, sf, inv_s2 if chi2 else None, th, md)
+        ebi, ebd, en = oracle.window_best(cur, p2, sf, inv_s2, th, chi2, md)
+        assert n == en and (bi == ebi).all() and (bd == ebd).all(), (th, chi2)
+    assert n > 30
+
+
+@pytest.mark.gpu
+def test_hip_search_by_sim3(pkg, oracle):
+    for seed in (17, 18):
+        c1, c2, p12, p21, sf = _sim3_scene(seed, 1100)
+        got, n = pkg.ORBmatcher(0.75, True).SearchBySim3(c1, c2, p12, p21, sf, sf, 7.5)
+        exp, en = oracle.search_by_sim3(c1, c2, p12, p21, sf, sf, 7.5)
+        assert n == en and (got == exp).all() and n > 300
+    with pytest.raises(pkg.OrbxError):
+        bad = {k: v[:-1] if isinstance(v, np.ndarray) else v for k, v in p12.items()}
+        pkg.ORBmatcher(0.75, True).SearchBySim3(c1, c2, bad, p21, sf, sf, 7.5)
