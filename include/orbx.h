@@ -277,6 +277,14 @@ int orbx_search_by_sim3(int device, const orbx_frame_feats *kf1, const orbx_fram
                         const orbx_proj_points *pts21, const float *scale_factors1, const float *scale_factors2, int nlevels,
                         float th, int32_t *match12, int *nfound);
 
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBmatcher.cc:430-556;
+ * Tracking::MonocularInitialization).  prev_matched_xy[f1->n][2] = vbPrevMatched; matches12[f1->n] = vnMatches12;
+ * *nmatches = the return value.  The update of vbPrevMatched (:544-546: the matched F2 keypoint's position) is a
+ * copy the adaptor does from matches12.  Only level-0 keypoints of either frame take part (:451-455). */
+int orbx_search_for_initialization(int device, const orbx_frame_feats *f1, const orbx_frame_feats *f2,
+                                   const float *prev_matched_xy, int window_size, float nnratio, int check_orientation,
+                                   int32_t *matches12, int *nmatches);
+
 /* ---- MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:266-340) -- */
 
 /* Batched over map points: point p owns descriptors desc[off[p] .. off[p+1]) (its non-bad observations in the

@@ -120,6 +120,7 @@ def lib():
         L.oracle_search_by_projection_keyframe.argtypes = [C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.oracle_search_by_projection_sim3.argtypes = [C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.c_void_p, C.c_float, C.c_void_p]
         L.oracle_window_best.argtypes = [C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_search_for_initialization.argtypes = [C.POINTER(FrameFeats), C.POINTER(FrameFeats), C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.oracle_search_by_sim3.argtypes = [C.POINTER(FrameFeats), C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.POINTER(ProjPoints),
                                             C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.oracle_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
@@ -330,6 +331,14 @@ def search_by_sim3(kf1, kf2, pts12, pts21, sf1, sf2, th):
     s1 = np.ascontiguousarray(sf1, np.float32); s2 = np.ascontiguousarray(sf2, np.float32)
     out = np.full(a.n, -1, np.int32)
     n = lib().oracle_search_by_sim3(C.byref(a), C.byref(b), C.byref(p), C.byref(q), _p(s1), _p(s2), th, _p(out))
+    return out, n
+
+
+def search_for_initialization(f1, f2, prev_xy, window_size, nnratio, check_ori):
+    a, ka = make_frame_feats(f1); b, kb = make_frame_feats(f2)
+    xy = np.ascontiguousarray(prev_xy, np.float32).reshape(-1, 2)
+    out = np.full(a.n, -1, np.int32)
+    n = lib().oracle_search_for_initialization(C.byref(a), C.byref(b), _p(xy), int(window_size), nnratio, int(check_ori), _p(out))
     return out, n
 
 

@@ -1484,6 +1484,59 @@ int oracle_search_by_sim3(const oracle_frame_feats *kf1, const oracle_frame_feat
     return nfound;
 }
 
+/* ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:430-556 (without the vbPrevMatched update, :544-546) */
+int oracle_search_for_initialization(const oracle_frame_feats *f1, const oracle_frame_feats *f2, const float *prev_xy,
+                                     int window_size, float nnratio, int check_ori, int32_t *matches12)
+{
+    fgrid *g = grid_build(f2);
+    int *cand = malloc(sizeof(int) * (f2->n ? f2->n : 1));
+    int *matched_dist = malloc(sizeof(int) * (f2->n ? f2->n : 1));
+    int *matches21 = malloc(sizeof(int) * (f2->n ? f2->n : 1));
+    for (int i = 0; i < f2->n; i++) { matched_dist[i] = INT_MAX; matches21[i] = -1; }
+    for (int i = 0; i < f1->n; i++) matches12[i] = -1;
+    rot_hist rh; memset(&rh, 0, sizeof rh);
+    int nmatches = 0;
+    for (int i1 = 0; i1 < f1->n; i1++) {
+        const int level1 = f1->octave[i1];
+        if (level1 > 0) continue;
+        const int nc = features_in_area(f2, g, prev_xy[2 * i1], prev_xy[2 * i1 + 1], (float)window_size, level1, level1, cand);
+        if (nc == 0) continue;
+        int best_dist = INT_MAX, best_dist2 = INT_MAX, best_idx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = cand[c];
+            const int dist = oracle_hamming(f1->desc + (size_t)i1 * 32, f2->desc + (size_t)i2 * 32);
+            if (matched_dist[i2] <= dist) continue;
+            if (dist < best_dist) { best_dist2 = best_dist; best_dist = dist; best_idx2 = i2; }
+            else if (dist < best_dist2) best_dist2 = dist;
+        }
+        if (best_dist <= TH_LOW) {
+            if ((float)best_dist < (float)best_dist2 * nnratio) {
+                if (matches21[best_idx2] >= 0) { matches12[matches21[best_idx2]] = -1; nmatches--; }
+                matches12[i1] = best_idx2;
+                matches21[best_idx2] = i1;
+                matched_dist[best_idx2] = best_dist;
+                nmatches++;
+                if (check_ori) rh_push(&rh, rot_bin(f1->angle[i1], f2->angle[best_idx2]), i1);
+            }
+        }
+    }
+    if (check_ori) { /* :514-541: only entries still standing are removed */
+        int cnt[HISTO_LENGTH], i1, i2, i3;
+        for (int b = 0; b < HISTO_LENGTH; b++) cnt[b] = rh.n[b];
+        oracle_three_maxima(cnt, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            if (b == i1 || b == i2 || b == i3) continue;
+            for (int j = 0; j < rh.n[b]; j++) {
+                const int idx1 = rh.v[b][j];
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    for (int b = 0; b < HISTO_LENGTH; b++) free(rh.v[b]);
+    grid_free(g); free(cand); free(matched_dist); free(matches21);
+    return nmatches;
+}
+
 /* ------------------------------------------------------------------ grayscale ingest (f4, first half) */
 
 /* cv::cvtColor RGB(A)/BGR(A) -> GRAY, 8U (src/Tracking.cc:177-202 call sites) */

@@ -182,6 +182,10 @@ int oracle_window_best(const oracle_frame_feats *kf, const oracle_proj_points *p
 int oracle_search_by_sim3(const oracle_frame_feats *kf1, const oracle_frame_feats *kf2, const oracle_proj_points *pts12,
                           const oracle_proj_points *pts21, const float *sf1, const float *sf2, float th, int32_t *match12);
 
+/* ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:430-556; prev_xy[f1->n][2] = vbPrevMatched (not updated) */
+int oracle_search_for_initialization(const oracle_frame_feats *f1, const oracle_frame_feats *f2, const float *prev_xy,
+                                     int window_size, float nnratio, int check_ori, int32_t *matches12);
+
 /* cv::cvtColor(CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY) for 8U, the conversion Tracking::GrabImage*
  * applies to colour input (src/Tracking.cc:177-202, :217-231, :254-268) [OpenCV generic path, from memory:
  * fixed point, yuv_shift 14, R2Y 4899, G2Y 9617, B2Y 1868, rounding 1<<13].  channels 3 or 4; rgb_order 1 = R first. */

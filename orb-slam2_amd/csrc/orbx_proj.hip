@@ -39,7 +39,7 @@ struct DevPoints {
 // One parameter block describes every projection-type search of src/ORBmatcher.cc (which tests, which window, which
 // claim rule); the extern "C" entry points below fill it per reference function.
 struct ProjParams {
-    int radius_mode;   // 0: th * sf[level]            1: RadiusByViewingCos(view_cos) [* th] * sf[level]
+    int radius_mode;   // 0: th * sf[level]   1: RadiusByViewingCos(view_cos) [* th] * sf[level]   2: th (a fixed window)
     int bounds;        // 0: none  1: Frame bounds, inclusive (:1431-1434)  2: KeyFrame::IsInImage (src/KeyFrame.cc:649-652)
     int need_pos_aux;  // 1: reject aux (= invzc) < 0 (:1426)
     int lo_off, hi_off;// candidate levels [level + lo_off, level + hi_off] unless direction != 0
@@ -49,6 +49,7 @@ struct ProjParams {
     int max_dist;      // TH_HIGH, TH_LOW or ORBdist
     int ratio;         // 1: same-level ratio test of the map-point search (:117-121)
     int check_ori;
+    int init_search;   // 1: SearchForInitialization's sequential rule (k_init_resolve)
     int claims;        // 0: points are independent (Fuse, SearchBySim3)  1: an accepted match of a point with
                        // Observations() > 0 blocks its feature  2: every accepted match blocks it
     float th, mbf, nnratio;
@@ -107,6 +108,8 @@ __device__ __forceinline__ bool point_window(const DevFrame &F, const DevPoints 
     else if (pp.bounds == 2) { if (!(u >= F.min_x && u < F.max_x && v >= F.min_y && v < F.max_y)) return false; }
     if (pp.radius_mode == 0) {
         r = pp.th * pp.sf[lvl];                                        // :1439
+    } else if (pp.radius_mode == 2) {
+        r = pp.th;                                                     // SearchForInitialization's windowSize (:461)
     } else {
         float rr = (double)P.view_cos[i] > 0.998 ? 2.5f : 4.0f;        // RadiusByViewingCos (:131-137)
         if ((double)pp.th != 1.0) rr *= pp.th;                         // bFactor (:52, :66-67)
@@ -334,6 +337,99 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(DevFrame F, DevPoints P, 
     if (tid == 0) *out_n = s_cnt;
 }
 
+// ORBmatcher::SearchForInitialization's matching loop (src/ORBmatcher.cc:447-511) is sequential by construction: a
+// candidate is skipped when the match it already holds is at least as good (vMatchedDistance, :470) and an accepted
+// match steals the feature from its previous holder (:491-496).  The candidate lists with their distances come from
+// k_proj_lists (all pairs in parallel); this kernel replays the decisions in order with ONE wave: per point a
+// coalesced sweep over its list, the two smallest distances and the first position of the minimum by wave
+// reductions, then the scalar bookkeeping.  md / m21 (vMatchedDistance, vnMatches21) live in LDS.
+__global__ __launch_bounds__(64) void k_init_resolve(DevFrame F, DevPoints P, ProjParams pp, const int *__restrict__ beg,
+                                                     const int *__restrict__ cnt, const uint32_t *__restrict__ entries,
+                                                     int *__restrict__ bins, int32_t *__restrict__ pt_choice,
+                                                     int32_t *__restrict__ pt_dist, int *__restrict__ out_n)
+{
+    uint16_t *md = reinterpret_cast<uint16_t *>(resolve_smem);          // [F.n] 0xFFFF = INT_MAX
+    uint16_t *m21 = md + ((F.n + 7) & ~7);                               // [F.n] holder + 1, 0 = none
+    __shared__ int hist[30];
+    const int lane = threadIdx.x;
+    for (int f = lane; f < F.n; f += 64) { md[f] = 0xFFFF; m21[f] = 0; }
+    for (int i = lane; i < P.n; i += 64) { pt_choice[i] = -1; pt_dist[i] = 256; bins[i] = -1; }
+    if (lane < 30) hist[lane] = 0;
+    __threadfence_block();
+    __syncthreads();
+    int nm = 0;
+    for (int i1 = 0; i1 < P.n; i1++) {
+        const int c = cnt[i1];
+        if (c == 0) continue; // wave-uniform
+        const int e0 = beg[i1];
+        unsigned k1 = 0xFFFFFFFFu, d2 = 0x7FFFFFFFu; // lane-local: smallest (dist<<16 | position), second smallest distance
+        for (int eb = 0; eb < c; eb += 64) {
+            const int e = eb + lane;
+            if (e < c) {
+                const uint32_t en = entries[e0 + e];
+                const unsigned f = en & 0xFFFF, d = (en >> 16) & 0x1FF;
+                if (!(md[f] <= d)) {                                   // :470
+                    const unsigned key = (d << 16) | (unsigned)e;     // lists are shorter than 65536 (host check)
+                    if (key < k1) { d2 = k1 >> 16; k1 = key; }
+                    else if (d < d2) d2 = d;
+                }
+            }
+        }
+        if (k1 == 0xFFFFFFFFu) d2 = 0x7FFFFFFFu; else if (d2 == 0xFFFFu) d2 = 0x7FFFFFFFu;
+        const unsigned best = wave_min_u32(k1);
+        // second smallest over the wave: the winner lane contributes its own second, every other lane its first
+        const unsigned mine = (k1 == best) ? d2 : (k1 == 0xFFFFFFFFu ? 0x7FFFFFFFu : (k1 >> 16));
+        const unsigned second = wave_min_u32(mine);
+        if (best == 0xFFFFFFFFu) continue;
+        const int bd = (int)(best >> 16), be = (int)(best & 0xFFFF);
+        if (bd <= 50 && (float)bd < (float)(int)second * pp.nnratio) {  // TH_LOW (:485), ratio (:487)
+            const int f = (int)(entries[e0 + be] & 0xFFFF);
+            if (lane == 0) {
+                const int prev = (int)m21[f] - 1;
+                if (prev >= 0) pt_choice[prev] = -1;                   // :489-493
+                pt_choice[i1] = f; pt_dist[i1] = bd;
+                m21[f] = (uint16_t)(i1 + 1); md[f] = (uint16_t)bd;
+                if (pp.check_ori) {
+                    float rot = P.angle[i1] - F.angle[f];              // :501-509
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * (1.0f / 30));
+                    if (bin == 30) bin = 0;
+                    bin = (unsigned)bin < 30u ? bin : 0;
+                    hist[bin]++; bins[i1] = bin;
+                }
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // nmatches = matches still standing (every steal removed one, :492), then the orientation filter (:514-541)
+    int i1k = -1, i2k = -1, i3k = -1;
+    if (pp.check_ori) {
+        int max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < 30; i++) {
+            const int sv = hist[i];
+            if (sv > max1) { max3 = max2; max2 = max1; max1 = sv; i3k = i2k; i2k = i1k; i1k = i; }
+            else if (sv > max2) { max3 = max2; max2 = sv; i3k = i2k; i2k = i; }
+            else if (sv > max3) { max3 = sv; i3k = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { i2k = -1; i3k = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { i3k = -1; }
+    }
+    int local = 0;
+    for (int i = lane; i < P.n; i += 64) {
+        if (pt_choice[i] < 0) continue;
+        if (pp.check_ori) {
+            const int b = bins[i];
+            if (b != i1k && b != i2k && b != i3k) { pt_choice[i] = -1; continue; }
+        }
+        local++;
+    }
+    nm = wave_sum(local);
+    if (lane == 0) *out_n = nm;
+}
+
 // ---------------------------------------------------------------- host side
 
 struct ProjCtx {
@@ -445,9 +541,12 @@ static int proj_run(int device, const orbx_frame_feats *cur, const orbx_proj_poi
         ORBX_HIP(hipHostMalloc((void **)&c->h_out, sizeof(int32_t) * (nc + 2 * np + 8) * 2, hipHostMallocDefault));
         c->out_cap = (nc + 2 * np + 8) * 2;
     }
-    const size_t resolve_lds = sizeof(int) * (nc + 4);
-    if (resolve_lds > 150 * 1024) { orbx_set_error("too many features for one search"); return ORBX_E_INVALID; }
-    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds));
+    const size_t resolve_lds = pp.init_search ? 2 * sizeof(uint16_t) * ((nc + 7) & ~(size_t)7) + 16 : sizeof(int) * (nc + 4);
+    if (resolve_lds > 150 * 1024 || (pp.init_search && np >= 65535)) { orbx_set_error("too many features for one search"); return ORBX_E_INVALID; }
+    if (pp.init_search)
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds));
+    else
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds));
     uint8_t *wk = c->d_work;
     int *d_coff = (int *)(wk + w_coff), *d_cidx = (int *)(wk + w_cidx), *d_beg = (int *)(wk + w_beg), *d_cnt = (int *)(wk + w_cnt),
         *d_used = (int *)(wk + w_used);
@@ -461,9 +560,13 @@ static int proj_run(int device, const orbx_frame_feats *cur, const orbx_proj_poi
         hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, c->stream, F, d_coff, d_cidx);
         hipLaunchKernelGGL(k_proj_lists, dim3((pts->n + 3) / 4), dim3(256), 0, c->stream, F, P, pp, d_coff, d_cidx, d_beg, d_cnt,
                            c->d_entries, (int)c->ent_cap, d_used);
-        hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(1024), resolve_lds, c->stream, F, P, pp, d_beg, d_cnt, c->d_entries,
-                           (int *)(wk + w_ca), (int *)(wk + w_cb), (int32_t *)(wk + w_match), (int *)(wk + w_n),
-                           (int32_t *)(wk + w_pc), (int32_t *)(wk + w_pd));
+        if (pp.init_search)
+            hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(64), resolve_lds, c->stream, F, P, pp, d_beg, d_cnt, c->d_entries,
+                               (int *)(wk + w_ca), (int32_t *)(wk + w_pc), (int32_t *)(wk + w_pd), (int *)(wk + w_n));
+        else
+            hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(1024), resolve_lds, c->stream, F, P, pp, d_beg, d_cnt, c->d_entries,
+                               (int *)(wk + w_ca), (int *)(wk + w_cb), (int32_t *)(wk + w_match), (int *)(wk + w_n),
+                               (int32_t *)(wk + w_pc), (int32_t *)(wk + w_pd));
         ORBX_HIP(hipGetLastError());
         ORBX_HIP(hipMemcpyAsync(c->h_out, wk + w_match, 4 * nc, hipMemcpyDeviceToHost, c->stream));
         ORBX_HIP(hipMemcpyAsync(c->h_out + nc, wk + w_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -541,6 +644,35 @@ extern "C" int orbx_window_best(int device, const orbx_frame_feats *kf, const or
     pp.bounds = 2; pp.lo_off = -1; pp.hi_off = 0; pp.max_dist = max_dist; pp.chi2 = chi2 ? 1 : 0; pp.claims = 0;
     pp.th = th;
     return proj_run(device, kf, pts, scale_factors, nlevels, pp, nullptr, nfound, inv_sigma2, best_idx, best_dist);
+}
+
+extern "C" int orbx_search_for_initialization(int device, const orbx_frame_feats *f1, const orbx_frame_feats *f2,
+                                              const float *prev_matched_xy, int window_size, float nnratio, int check_orientation,
+                                              int32_t *matches12, int *nmatches)
+{
+    if (!f1 || !f2 || !prev_matched_xy || !matches12 || !nmatches || f1->n < 0 || window_size < 0) {
+        orbx_set_error("orbx_search_for_initialization: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    if (f1->n && (!f1->octave || !f1->desc || (check_orientation && !f1->angle))) { orbx_set_error("frame arrays missing"); return ORBX_E_INVALID; }
+    const size_t n1 = (size_t)f1->n;
+    std::vector<float> u(n1 + 1), v(n1 + 1);
+    std::vector<int32_t> lvl(n1 + 1, 0);
+    std::vector<uint8_t> valid(n1 + 1);
+    for (size_t i = 0; i < n1; i++) {
+        u[i] = prev_matched_xy[2 * i]; v[i] = prev_matched_xy[2 * i + 1];
+        valid[i] = f1->octave[i] > 0 ? 0 : 1;                          // :451-453
+    }
+    orbx_proj_points pts;
+    memset(&pts, 0, sizeof pts);
+    pts.n = f1->n; pts.u = u.data(); pts.v = v.data(); pts.level = lvl.data(); pts.angle = f1->angle; pts.desc = f1->desc;
+    pts.valid = valid.data();
+    ProjParams pp;
+    memset(&pp, 0, sizeof pp);
+    pp.radius_mode = 2; pp.lo_off = 0; pp.hi_off = 0; pp.max_dist = 50; pp.check_ori = check_orientation; pp.init_search = 1;
+    pp.th = (float)window_size; pp.nnratio = nnratio;
+    const float sf1[1] = { 1.0f };
+    return proj_run(device, f2, &pts, sf1, 1, pp, nullptr, nmatches, nullptr, matches12, nullptr);
 }
 
 extern "C" int orbx_search_by_sim3(int device, const orbx_frame_feats *kf1, const orbx_frame_feats *kf2,

@@ -96,6 +96,7 @@ def lib():
     L.orbx_search_by_projection_keyframe.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, i, f, i, i, vp, ip]
     L.orbx_search_by_projection_sim3.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, i, f, vp, ip]
     L.orbx_window_best.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, vp, i, f, i, i, vp, vp, ip]
+    L.orbx_search_for_initialization.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(FrameFeats), vp, i, f, i, vp, ip]
     L.orbx_search_by_sim3.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.POINTER(ProjPoints),
                                       vp, vp, i, f, vp, ip]
     L.orbx_distinctive_descriptors.argtypes = [i, vp, vp, i, vp]
@@ -453,6 +454,18 @@ class ORBmatcher:
         _check(lib().orbx_window_best(self.device, C.byref(a), C.byref(b), _p(sf), None if sg is None else _p(sg), len(sf), th,
                                       0 if sg is None else 1, int(max_dist), _p(bi), _p(bd), C.byref(n)))
         return bi, bd, n.value
+
+    def SearchForInitialization(self, F1, F2, vbPrevMatched, windowSize=100):
+        """SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize), src/ORBmatcher.cc:430-556
+        -> (vnMatches12, nmatches, updated vbPrevMatched)"""
+        a, ka = self._frame(F1); b, kb = self._frame(F2)
+        xy = np.ascontiguousarray(vbPrevMatched, np.float32).reshape(-1, 2)
+        out = np.full(a.n, -1, np.int32); n = C.c_int()
+        _check(lib().orbx_search_for_initialization(self.device, C.byref(a), C.byref(b), _p(xy), int(windowSize), self.mfNNratio,
+                                                    int(self.mbCheckOrientation), _p(out), C.byref(n)))
+        new_xy = xy.copy(); m = out >= 0   # :544-546
+        new_xy[m, 0] = kb["x"][out[m]]; new_xy[m, 1] = kb["y"][out[m]]
+        return out, n.value, new_xy
 
     def SearchBySim3(self, pKF1, pKF2, pts12, pts21, scaleFactors1, scaleFactors2, th):
         """SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th), src/ORBmatcher.cc:1166-1394 -> (match12, nFound)"""

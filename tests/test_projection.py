@@ -336,3 +336,82 @@ def test_hip_search_by_sim3(pkg, oracle):
     with pytest.raises(pkg.OrbxError):
         bad = {k: v[:-1] if isinstance(v, np.ndarray) else v for k, v in p12.items()}
         pkg.ORBmatcher(0.75, True).SearchBySim3(c1, c2, bad, p21, sf, sf, 7.5)
+
+
+# ---------------------------------------------------------------- SearchForInitialization (:430-556)
+
+def _init_scene(seed, n=900, shift=6.0, noise=0.04):
+    c1, _, sf = _scene(seed, n, 10, stereo_frac=0.0)
+    rng = np.random.Generator(np.random.PCG64(seed + 7))
+    c1["octave"] = np.where(rng.random(n) < 0.55, 0, rng.integers(1, 8, n)).astype(np.int32)
+    perm = rng.permutation(n)
+    c2 = dict(c1)
+    for k in ("x", "y", "octave", "angle", "u_right", "desc", "occupied"):
+        c2[k] = c1[k][perm].copy()
+    c2["x"] = (c2["x"] + shift + rng.normal(0, 1.5, n)).astype(f32); c2["y"] = (c2["y"] + rng.normal(0, 1.5, n)).astype(f32)
+    c2["angle"] = ((c2["angle"] + rng.normal(0, 6, n)) % 360).astype(f32)
+    c2["desc"] = synth.flip_bits(rng, c2["desc"], noise)
+    # a handful of look-alike features so that matches get stolen and the ratio test bites
+    dup = rng.integers(0, n, 60); src = rng.integers(0, n, 60)
+    c2["desc"][dup] = synth.flip_bits(rng, c2["desc"][src], 0.02); c2["octave"][dup] = c2["octave"][src]
+    prev = np.stack([c1["x"], c1["y"]], 1).astype(f32)
+    return c1, c2, prev
+
+
+def _py_init(f1, f2, prev, win, ratio, check_ori):
+    grid, inv_w, inv_h = _py_grid(f2)
+    n1, n2 = len(f1["x"]), len(f2["x"])
+    m12 = np.full(n1, -1, np.int32); m21 = np.full(n2, -1, np.int32); md = np.full(n2, 2**31 - 1, np.int64)
+    nm = 0; rot = []
+    for i1 in range(n1):
+        if f1["octave"][i1] > 0: continue
+        cand = _py_area(f2, grid, inv_w, inv_h, f32(prev[i1, 0]), f32(prev[i1, 1]), f32(win), 0, 0)
+        b1 = b2 = 2**31 - 1; bi = -1
+        for k in cand:
+            d = int(POP[f1["desc"][i1] ^ f2["desc"][k]].sum())
+            if md[k] <= d: continue
+            if d < b1: b2, b1, bi = b1, d, k
+            elif d < b2: b2 = d
+        if b1 <= 50 and f32(b1) < f32(f32(b2) * f32(ratio)):
+            if m21[bi] >= 0: m12[m21[bi]] = -1; nm -= 1
+            m12[i1] = bi; m21[bi] = i1; md[bi] = b1; nm += 1
+            if check_ori:
+                rt = f32(f1["angle"][i1] - f2["angle"][bi])
+                if rt < 0: rt = f32(rt + f32(360))
+                b = int(math.floor(float(f32(rt * f32(f32(1) / f32(30)))) + 0.5))
+                rot.append((0 if b == 30 else b, i1))
+    if check_ori:
+        hist = np.bincount([b for b, _ in rot], minlength=30)
+        mx1 = mx2 = mx3 = 0; i1 = i2 = i3 = -1
+        for i, s_ in enumerate(hist):
+            if s_ > mx1: mx3, mx2, mx1, i3, i2, i1 = mx2, mx1, s_, i2, i1, i
+            elif s_ > mx2: mx3, mx2, i3, i2 = mx2, s_, i2, i
+            elif s_ > mx3: mx3, i3 = s_, i
+        if f32(mx2) < f32(0.1) * f32(mx1): i2 = i3 = -1
+        elif f32(mx3) < f32(0.1) * f32(mx1): i3 = -1
+        for b, idx1 in rot:
+            if b not in (i1, i2, i3) and m12[idx1] >= 0:
+                m12[idx1] = -1; nm -= 1
+    return m12, nm
+
+
+def test_oracle_vs_python_initialization(oracle):
+    f1, f2, prev = _init_scene(31, 500)
+    for ori in (True, False):
+        m, n = oracle.search_for_initialization(f1, f2, prev, 100, 0.9, ori)
+        pm, pn = _py_init(f1, f2, prev, 100, 0.9, ori)
+        assert n == pn and (m == pm).all()
+    assert n > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,win,ratio", [(32, 1500, 100, 0.9), (33, 2000, 100, 0.9), (34, 800, 30, 0.7), (35, 1200, 300, 0.95)])
+def test_hip_search_for_initialization(pkg, oracle, seed, n, win, ratio):
+    f1, f2, prev = _init_scene(seed, n)
+    for ori in (True, False):
+        got, gn, new_xy = pkg.ORBmatcher(ratio, ori).SearchForInitialization(f1, f2, prev, win)
+        exp, en = oracle.search_for_initialization(f1, f2, prev, win, ratio, ori)
+        assert gn == en and (got == exp).all(), (ori, gn, en, np.nonzero(got != exp)[0][:5])
+        m = exp >= 0
+        assert (new_xy[m, 0] == f2["x"][exp[m]]).all() and (new_xy[~m] == prev[~m]).all()
+    assert en > 0.25 * n * 0.5
