@@ -80,6 +80,22 @@ int orbx_extract(orbx_extractor *e, const uint8_t *img, int w, int h, size_t str
 int orbx_extract_color(orbx_extractor *e, const uint8_t *img, int w, int h, size_t stride, int channels, int rgb_order,
                        orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out, uint8_t *gray_out, size_t gray_stride);
 
+/* ---- stereo rectification (second half) ----------------------------------
+ * cv::remap(imLeft, imLeftRect, M1l, M2l, cv::INTER_LINEAR) of Examples/Stereo/stereo_euroc.cc:136-137 (8-bit grey,
+ * BORDER_CONSTANT 0).  map_x / map_y = the CV_32FC1 pair cv::initUndistortRectifyMap returns (:103-104), dst_h x dst_w
+ * floats each, dense; converted once to OpenCV's fixed-point form on the device. */
+typedef struct orbx_rectifier orbx_rectifier;
+int orbx_rectifier_create(int device, int src_w, int src_h, int dst_w, int dst_h, const float *map_x, const float *map_y,
+                          orbx_rectifier **out);
+void orbx_rectifier_destroy(orbx_rectifier *r);
+int orbx_rectifier_size(const orbx_rectifier *r, int *dst_w, int *dst_h);
+/* batch of device images -> rectified device images (d_dst, dst_pitch and dst_stride multiples of 4); asynchronous on `stream` */
+int orbx_remap_batch_device(const orbx_rectifier *r, const void *d_src, size_t src_stride, size_t src_pitch, int batch,
+                            void *d_dst, size_t dst_stride, size_t dst_pitch, void *stream);
+/* raw grey frame (host) -> rectify on device -> extract; rect_out (optional) receives the rectified image */
+int orbx_extract_rectified(orbx_extractor *e, const orbx_rectifier *r, const uint8_t *img, int w, int h, size_t stride,
+                           orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out, uint8_t *rect_out, size_t rect_stride);
+
 /* B images of one size in one pass (host pointers). kps[B*cap], desc[B*cap*32], n_out[B]. */
 int orbx_extract_batch(orbx_extractor *e, const uint8_t *const *imgs, int batch, int w, int h, size_t stride,
                        orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out);

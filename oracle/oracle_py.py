@@ -342,6 +342,17 @@ def search_for_initialization(f1, f2, prev_xy, window_size, nnratio, check_ori):
     return out, n
 
 
+def remap_bilinear(img, map_x, map_y):
+    img = np.ascontiguousarray(img, np.uint8); sh, sw = img.shape
+    mx = np.ascontiguousarray(map_x, np.float32); my = np.ascontiguousarray(map_y, np.float32); dh, dw = mx.shape
+    out = np.zeros((dh, dw), np.uint8)
+    L = lib()
+    L.oracle_remap_bilinear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t]
+    L.oracle_remap_bilinear.restype = None
+    L.oracle_remap_bilinear(_p(img), sw, sh, sw, _p(mx), _p(my), _p(out), dw, dh, dw)
+    return out
+
+
 def cvt_gray(img, rgb_order):
     img = np.ascontiguousarray(img, np.uint8); h, w, ch = img.shape
     out = np.zeros((h, w), np.uint8)

@@ -1550,3 +1550,76 @@ void oracle_cvt_gray(const uint8_t *src, int w, int h, size_t sstride, int chann
             dst[(size_t)y * dstride + x] = (uint8_t)((r * cr + g * cg + b * cb + (1 << 13)) >> 14);
         }
 }
+
+/* ------------------------------------------------------------------ stereo rectification (f4, second half) */
+
+/* cv::remap(src, dst, map1 CV_32FC1, map2 CV_32FC1, INTER_LINEAR, BORDER_CONSTANT, Scalar()) for 8UC1, the call of
+ * Examples/Stereo/stereo_euroc.cc:136-137 [OpenCV generic path restated from memory: imgwarp.cpp initInterTab2D,
+ * remap()'s CV_32FC1 branch, remapBilinear<FixedPtCast<int,uchar,15>, short>].  The bilinear table is built the way
+ * OpenCV builds it, including saturate_cast<short> and the sum fix-up (which, with ksize 2, looks at entries k1,k2 in
+ * {1,2}, i.e. at the fourth tap and into the next, still zero, table entry). */
+static short g_bilinear_tab[32 * 32 + 1][4];
+static int g_bilinear_ready = 0;
+static void init_bilinear_tab(void)
+{
+    if (g_bilinear_ready) return;
+    memset(g_bilinear_tab, 0, sizeof g_bilinear_tab);
+    float tab1[32][2];
+    for (int i = 0; i < 32; i++) { const float x = (float)i * (1.f / 32); tab1[i][0] = 1.f - x; tab1[i][1] = x; } /* interpolateLinear */
+    short *flat = &g_bilinear_tab[0][0];
+    for (int i = 0; i < 32; i++)
+        for (int j = 0; j < 32; j++) {
+            short *itab = flat + (size_t)(i * 32 + j) * 4;
+            int isum = 0;
+            for (int k1 = 0; k1 < 2; k1++)
+                for (int k2 = 0; k2 < 2; k2++) {
+                    const float v = tab1[i][k1] * tab1[j][k2];
+                    const long r = lrintf(v * 32768.f);
+                    itab[k1 * 2 + k2] = (short)(r > 32767 ? 32767 : r < -32768 ? -32768 : r);
+                    isum += itab[k1 * 2 + k2];
+                }
+            if (isum != 32768) {
+                const int diff = isum - 32768;
+                int Mk1 = 1, Mk2 = 1, mk1 = 1, mk2 = 1;
+                for (int k1 = 1; k1 < 3; k1++)
+                    for (int k2 = 1; k2 < 3; k2++) {
+                        if (itab[k1 * 2 + k2] < itab[mk1 * 2 + mk2]) { mk1 = k1; mk2 = k2; }
+                        else if (itab[k1 * 2 + k2] > itab[Mk1 * 2 + Mk2]) { Mk1 = k1; Mk2 = k2; }
+                    }
+                if (diff < 0) itab[Mk1 * 2 + Mk2] = (short)(itab[Mk1 * 2 + Mk2] - diff);
+                else itab[mk1 * 2 + mk2] = (short)(itab[mk1 * 2 + mk2] - diff);
+            }
+        }
+    g_bilinear_ready = 1;
+}
+
+void oracle_remap_bilinear(const uint8_t *src, int sw, int sh, size_t sstride, const float *map_x, const float *map_y,
+                           uint8_t *dst, int dw, int dh, size_t dstride)
+{
+    init_bilinear_tab();
+    const int width1 = sw - 1 > 0 ? sw - 1 : 0, height1 = sh - 1 > 0 ? sh - 1 : 0;
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            const int fsx = (int)lrintf(map_x[(size_t)y * dw + x] * 32), fsy = (int)lrintf(map_y[(size_t)y * dw + x] * 32);
+            int sx = fsx >> 5, sy = fsy >> 5;
+            sx = sx < -32768 ? -32768 : sx > 32767 ? 32767 : sx;
+            sy = sy < -32768 ? -32768 : sy > 32767 ? 32767 : sy;
+            const short *w = g_bilinear_tab[(fsy & 31) * 32 + (fsx & 31)];
+            int val;
+            if ((unsigned)sx < (unsigned)width1 && (unsigned)sy < (unsigned)height1) {
+                const uint8_t *S = src + (size_t)sy * sstride + sx;
+                val = S[0] * w[0] + S[1] * w[1] + S[sstride] * w[2] + S[sstride + 1] * w[3];
+            } else if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
+                dst[(size_t)y * dstride + x] = 0;
+                continue;
+            } else {
+                const int x0 = (unsigned)sx < (unsigned)sw ? sx : -1, x1 = (unsigned)(sx + 1) < (unsigned)sw ? sx + 1 : -1; /* borderInterpolate, BORDER_CONSTANT */
+                const int y0 = (unsigned)sy < (unsigned)sh ? sy : -1, y1 = (unsigned)(sy + 1) < (unsigned)sh ? sy + 1 : -1;
+                const int v0 = x0 >= 0 && y0 >= 0 ? src[(size_t)y0 * sstride + x0] : 0, v1 = x1 >= 0 && y0 >= 0 ? src[(size_t)y0 * sstride + x1] : 0;
+                const int v2 = x0 >= 0 && y1 >= 0 ? src[(size_t)y1 * sstride + x0] : 0, v3 = x1 >= 0 && y1 >= 0 ? src[(size_t)y1 * sstride + x1] : 0;
+                val = v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3];
+            }
+            val = (val + (1 << 14)) >> 15;
+            dst[(size_t)y * dstride + x] = (uint8_t)(val < 0 ? 0 : val > 255 ? 255 : val);
+        }
+}

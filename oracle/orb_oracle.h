@@ -191,6 +191,10 @@ int oracle_search_for_initialization(const oracle_frame_feats *f1, const oracle_
  * fixed point, yuv_shift 14, R2Y 4899, G2Y 9617, B2Y 1868, rounding 1<<13].  channels 3 or 4; rgb_order 1 = R first. */
 void oracle_cvt_gray(const uint8_t *src, int w, int h, size_t sstride, int channels, int rgb_order, uint8_t *dst, size_t dstride);
 
+/* cv::remap(..., INTER_LINEAR) with CV_32FC1 maps on 8UC1, BORDER_CONSTANT 0 (Examples/Stereo/stereo_euroc.cc:136-137) */
+void oracle_remap_bilinear(const uint8_t *src, int sw, int sh, size_t sstride, const float *map_x, const float *map_y,
+                           uint8_t *dst, int dw, int dh, size_t dstride);
+
 /* ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1687-1728 */
 void oracle_three_maxima(const int *count, int L, int *ind1, int *ind2, int *ind3);
 

@@ -1297,6 +1297,52 @@ extern "C" int orbx_extract_color(orbx_extractor *e, const uint8_t *img, int w, 
     return ORBX_OK;
 }
 
+// EuRoC stereo front end (Examples/Stereo/stereo_euroc.cc:136-137 then Tracking::GrabImageStereo): the raw grey frame is
+// uploaded, rectified on device (orbx_remap.hip) straight into the level-0 staging, and extracted.
+extern "C" int orbx_extract_rectified(orbx_extractor *e, const orbx_rectifier *r, const uint8_t *img, int w, int h, size_t stride,
+                                      orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out, uint8_t *rect_out, size_t rect_stride)
+{
+    int rw = 0, rh = 0;
+    if (!e || !r || !img || !kps || !desc || !n_out || w < 1 || h < 1 || stride < (size_t)w || orbx_rectifier_size(r, &rw, &rh) ||
+        (rect_out && rect_stride < (size_t)rw)) {
+        orbx_set_error("orbx_extract_rectified: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    ORBX_HIP(hipSetDevice(e->device));
+    int rc = orbx_prepare_geometry(e, rw, rh);
+    if (rc) return rc;
+    const int need = e->geom.kp_total;
+    if (cap < need) { orbx_set_error("keypoint capacity %d < orbx_max_keypoints() = %d", cap, need); return ORBX_E_CAPACITY; }
+    const size_t pitch = align_up(rw, 64), img_bytes = pitch * rh;
+    const size_t spitch = align_up((size_t)w, 64), sbytes = spitch * h;
+    if ((rc = ensure(&e->d_stage_in, &e->stage_in_cap, img_bytes * e->max_batch))) return rc;
+    if ((rc = ensure_pinned(&e->h_stage_in, &e->h_stage_in_cap, sbytes > img_bytes * e->max_batch ? sbytes : img_bytes * e->max_batch))) return rc;
+    void *d_raw;
+    if ((rc = orbx_scratch(e, 6, sbytes, &d_raw))) return rc;
+    if ((rc = orbx_ensure_out_staging(e, e->max_batch, need))) return rc;
+    const size_t o_kps = align_up(sizeof(int) * (size_t)e->max_batch, 64);
+    const size_t o_desc = o_kps + align_up(sizeof(orbx_keypoint) * (size_t)need * e->max_batch, 64);
+    const size_t out_bytes = o_desc + (size_t)32 * need * e->max_batch;
+    if ((rc = ensure_pinned(&e->h_out, &e->h_out_cap, out_bytes > img_bytes ? out_bytes : img_bytes))) return rc;
+    for (int y = 0; y < h; y++) memcpy(e->h_stage_in + (size_t)y * spitch, img + (size_t)y * stride, (size_t)w);
+    ORBX_HIP(hipMemcpyAsync(d_raw, e->h_stage_in, sbytes, hipMemcpyHostToDevice, e->stream));
+    if ((rc = orbx_remap_batch_device(r, d_raw, sbytes, spitch, 1, e->d_stage_in, img_bytes, pitch, e->stream))) return rc;
+    e->prof_chain = false;
+    rc = orbx_extract_batch_device(e, e->d_stage_in, img_bytes, pitch, 1, rw, rh, e->d_out_kps, e->d_out_desc, need, e->d_out_n, nullptr);
+    if (rc) return rc;
+    ORBX_HIP(hipMemcpyAsync(e->h_out, e->d_out_n, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    ORBX_HIP(hipMemcpyAsync(e->h_out + o_kps, e->d_out_kps, sizeof(orbx_keypoint) * (size_t)need, hipMemcpyDeviceToHost, e->stream));
+    ORBX_HIP(hipMemcpyAsync(e->h_out + o_desc, e->d_out_desc, (size_t)32 * need, hipMemcpyDeviceToHost, e->stream));
+    rc = orbx_sync(e, nullptr);
+    if (rc) return rc;
+    const int n = *reinterpret_cast<const int *>(e->h_out);
+    *n_out = n;
+    memcpy(kps, e->h_out + o_kps, sizeof(orbx_keypoint) * (size_t)n);
+    memcpy(desc, e->h_out + o_desc, (size_t)32 * n);
+    if (rect_out) ORBX_HIP(hipMemcpy2D(rect_out, rect_stride, e->d_stage_in, pitch, rw, rh, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
 extern "C" int orbx_extract(orbx_extractor *e, const uint8_t *img, int w, int h, size_t stride,
                             orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out)
 {

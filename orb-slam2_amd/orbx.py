@@ -96,6 +96,11 @@ def lib():
     L.orbx_search_by_projection_keyframe.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, i, f, i, i, vp, ip]
     L.orbx_search_by_projection_sim3.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, i, f, vp, ip]
     L.orbx_window_best.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, vp, i, f, i, i, vp, vp, ip]
+    L.orbx_rectifier_create.argtypes = [i, i, i, i, i, vp, vp, C.POINTER(vp)]
+    L.orbx_rectifier_destroy.argtypes = [vp]; L.orbx_rectifier_destroy.restype = None
+    L.orbx_rectifier_size.argtypes = [vp, ip, ip]
+    L.orbx_remap_batch_device.argtypes = [vp, vp, C.c_size_t, C.c_size_t, i, vp, C.c_size_t, C.c_size_t, vp]
+    L.orbx_extract_rectified.argtypes = [vp, vp, vp, i, i, C.c_size_t, vp, vp, i, ip, vp, C.c_size_t]
     L.orbx_search_for_initialization.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(FrameFeats), vp, i, f, i, vp, ip]
     L.orbx_search_by_sim3.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.POINTER(ProjPoints),
                                       vp, vp, i, f, vp, ip]
@@ -211,6 +216,19 @@ class ORBextractor:
                                           _p(gray), gray.strides[0] if want_gray else 0))
         out = (kps[:n.value].copy(), desc[:n.value].copy())
         return out + (gray,) if want_gray else out
+
+    def extract_rectified(self, rectifier, image, want_rect=False):
+        """raw grey frame -> cv::remap on device (Examples/Stereo/stereo_euroc.cc:136-137) -> operator()"""
+        image = np.ascontiguousarray(image, np.uint8)
+        h, w = image.shape
+        rw, rh = rectifier.size
+        cap = self.max_keypoints(rw, rh)
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int()
+        rect = np.zeros((rh, rw), np.uint8) if want_rect else None
+        _check(self._L.orbx_extract_rectified(self._h, rectifier._h, _p(image), w, h, image.strides[0], _p(kps), _p(desc), cap, C.byref(n),
+                                              _p(rect), rect.strides[0] if want_rect else 0))
+        out = (kps[:n.value].copy(), desc[:n.value].copy())
+        return out + (rect,) if want_rect else out
 
     def extract_batch(self, images):
         """list/array of equally sized uint8 images -> list of (keypoints, descriptors)"""
@@ -485,6 +503,30 @@ class ORBmatcher:
         _check(lib().orbx_search_for_triangulation(self.device, C.byref(a), C.byref(b), _p(F), ex, ey, _p(sf), _p(sg), len(sf),
                                                    int(bOnlyStereo), int(self.mbCheckOrientation), _p(pairs), cap, C.byref(n)))
         return pairs[:n.value].copy()
+
+
+class Rectifier:
+    """cv::remap(src, dst, M1, M2, INTER_LINEAR) with the CV_32FC1 maps of cv::initUndistortRectifyMap
+    (reference Examples/Stereo/stereo_euroc.cc:103-104, :136-137), held on the device in OpenCV's fixed-point form."""
+
+    def __init__(self, src_size, map_x, map_y, device=0):
+        self._L = lib()
+        mx = np.ascontiguousarray(map_x, np.float32); my = np.ascontiguousarray(map_y, np.float32)
+        if mx.ndim != 2 or mx.shape != my.shape:
+            raise OrbxError(-1, "map_x / map_y must be equal 2-D float32 arrays")
+        h = C.c_void_p()
+        _check(self._L.orbx_rectifier_create(device, int(src_size[0]), int(src_size[1]), mx.shape[1], mx.shape[0], _p(mx), _p(my), C.byref(h)))
+        self._h = h; self.size = (mx.shape[1], mx.shape[0]); self.src_size = (int(src_size[0]), int(src_size[1]))
+
+    def remap_batch_device(self, d_src, src_stride, src_pitch, batch, d_dst, dst_stride, dst_pitch, stream=None):
+        _check(self._L.orbx_remap_batch_device(self._h, d_src, src_stride, src_pitch, batch, d_dst, dst_stride, dst_pitch, stream))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.orbx_rectifier_destroy(self._h); self._h = None
+        except Exception:
+            pass
 
 
 def ComputeDistinctiveDescriptors(descriptor_sets, device=0):
