@@ -301,6 +301,13 @@ int orbx_search_for_initialization(int device, const orbx_frame_feats *f1, const
                                    const float *prev_matched_xy, int window_size, float nnratio, int check_orientation,
                                    int32_t *matches12, int *nmatches);
 
+/* ---- Frame::UndistortKeyPoints (src/Frame.cc:470-515) -------------------
+ * cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) on n keypoint positions xy[n][2] -> xy_out[n][2] (may alias).
+ * fx, fy, cx, cy = mK's float entries; dist_coef = mDistCoef (k1 k2 p1 p2 [k3]).  dist_coef[0] == 0 copies (:472-476).
+ * Frame::ComputeImageBounds (:517-552) is the same call on the four image corners followed by min/max on the host. */
+int orbx_undistort_keypoints(int device, const float *xy, int n, float fx, float fy, float cx, float cy,
+                             const float *dist_coef, int ndist, float *xy_out);
+
 /* ---- MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:266-340) -- */
 
 /* Batched over map points: point p owns descriptors desc[off[p] .. off[p+1]) (its non-bad observations in the

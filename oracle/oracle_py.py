@@ -353,6 +353,16 @@ def remap_bilinear(img, map_x, map_y):
     return out
 
 
+def undistort_points(xy, fx, fy, cx, cy, dist):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2); d = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros_like(xy)
+    L = lib()
+    L.oracle_undistort_points.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p]
+    L.oracle_undistort_points.restype = None
+    L.oracle_undistort_points(_p(xy), len(xy), fx, fy, cx, cy, _p(d), len(d), _p(out))
+    return out
+
+
 def cvt_gray(img, rgb_order):
     img = np.ascontiguousarray(img, np.uint8); h, w, ch = img.shape
     out = np.zeros((h, w), np.uint8)

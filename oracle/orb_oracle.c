@@ -1623,3 +1623,33 @@ void oracle_remap_bilinear(const uint8_t *src, int sw, int sh, size_t sstride, c
             dst[(size_t)y * dstride + x] = (uint8_t)(val < 0 ? 0 : val > 255 ? 255 : val);
         }
 }
+
+/* ------------------------------------------------------------------ Frame::UndistortKeyPoints (f2) */
+
+/* cv::undistortPoints(src, dst, K, D, noArray(), P = K) on CV_32FC2 points, src/Frame.cc:470-515 [cvUndistortPoints of
+ * OpenCV 3.2 restated from memory: double arithmetic, iters = 5; rational / thin-prism / tilt terms are zero for
+ * ORB-SLAM2's 4- or 5-coefficient models and drop out exactly]. */
+void oracle_undistort_points(const float *xy, int n, float fx_, float fy_, float cx_, float cy_, const float *dist, int ndist,
+                             float *out)
+{
+    double k[14] = { 0 };
+    for (int i = 0; i < ndist && i < 14; i++) k[i] = dist[i];
+    const double fx = fx_, fy = fy_, ifx = 1. / fx, ify = 1. / fy, cx = cx_, cy = cy_;
+    for (int i = 0; i < n; i++) {
+        double x = xy[2 * i], y = xy[2 * i + 1], x0, y0;
+        x = (x - cx) * ifx;
+        y = (y - cy) * ify;
+        x0 = x; y0 = y;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double dx = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+            const double dy = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+            x = (x0 - dx) * icdist;
+            y = (y0 - dy) * icdist;
+        }
+        const double xx = fx * x + 0 * y + cx, yy = 0 * x + fy * y + cy, ww = 1. / (0 * x + 0 * y + 1);
+        out[2 * i] = (float)(xx * ww);
+        out[2 * i + 1] = (float)(yy * ww);
+    }
+}

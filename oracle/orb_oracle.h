@@ -195,6 +195,9 @@ void oracle_cvt_gray(const uint8_t *src, int w, int h, size_t sstride, int chann
 void oracle_remap_bilinear(const uint8_t *src, int sw, int sh, size_t sstride, const float *map_x, const float *map_y,
                            uint8_t *dst, int dw, int dh, size_t dstride);
 
+/* cv::undistortPoints(pts, pts, K, D, noArray(), K), src/Frame.cc:470-515 */
+void oracle_undistort_points(const float *xy, int n, float fx, float fy, float cx, float cy, const float *dist, int ndist, float *out);
+
 /* ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1687-1728 */
 void oracle_three_maxima(const int *count, int L, int *ind1, int *ind2, int *ind3);
 

@@ -96,6 +96,7 @@ def lib():
     L.orbx_search_by_projection_keyframe.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, i, f, i, i, vp, ip]
     L.orbx_search_by_projection_sim3.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, i, f, vp, ip]
     L.orbx_window_best.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, vp, i, f, i, i, vp, vp, ip]
+    L.orbx_undistort_keypoints.argtypes = [i, vp, i, f, f, f, f, vp, i, vp]
     L.orbx_rectifier_create.argtypes = [i, i, i, i, i, vp, vp, C.POINTER(vp)]
     L.orbx_rectifier_destroy.argtypes = [vp]; L.orbx_rectifier_destroy.restype = None
     L.orbx_rectifier_size.argtypes = [vp, ip, ip]
@@ -503,6 +504,14 @@ class ORBmatcher:
         _check(lib().orbx_search_for_triangulation(self.device, C.byref(a), C.byref(b), _p(F), ex, ey, _p(sf), _p(sg), len(sf),
                                                    int(bOnlyStereo), int(self.mbCheckOrientation), _p(pairs), cap, C.byref(n)))
         return pairs[:n.value].copy()
+
+
+def UndistortKeyPoints(xy, fx, fy, cx, cy, distCoef, device=0):
+    """Frame::UndistortKeyPoints (reference src/Frame.cc:470-515): cv::undistortPoints(mat, mat, mK, mDistCoef, Mat(), mK)"""
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2); d = np.ascontiguousarray(distCoef, np.float32)
+    out = np.zeros_like(xy)
+    _check(lib().orbx_undistort_keypoints(device, _p(xy), len(xy), fx, fy, cx, cy, _p(d), len(d), _p(out)))
+    return out
 
 
 class Rectifier:
