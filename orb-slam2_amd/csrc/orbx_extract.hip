@@ -49,9 +49,20 @@ __global__ __launch_bounds__(256) void k_resize(const Geom *__restrict__ g, int 
         const int ndw = ((sx_max - sxa) >> 2) + 1; // <= 41
         const FastDiv fd(ndw);
         const uint8_t *s0 = src + (long long)sy_min * spitch + sxa;
-        for (int i = tid; i < nrows * ndw; i += 256) {
-            const int r = fd.div(i), c = i - r * ndw;
-            reinterpret_cast<uint32_t *>(src_t + r * RS_PITCH)[c] = *reinterpret_cast<const uint32_t *>(s0 + (long long)r * spitch + 4 * c);
+        const int total = nrows * ndw; // <= 42 * 84: two batches of eight loads per thread, each issued before it is consumed
+        for (int i0 = 0; i0 < total; i0 += 8 * 256) {
+            uint32_t tv[8];
+            int to[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = i0 + 256 * k + tid;
+                const int r = fd.div(i), c = i - r * ndw;
+                to[k] = r * (RS_PITCH / 4) + c;
+                if (i < total) tv[k] = *reinterpret_cast<const uint32_t *>(s0 + (long long)r * spitch + 4 * c);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (i0 + 256 * k + tid < total) reinterpret_cast<uint32_t *>(src_t)[to[k]] = tv[k];
         }
     } else {
         sxa = sx_min;
@@ -246,10 +257,22 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
         // (r, c) of element i = lane + 64k advances by (64 / ndw, 64 % ndw) with carry: no per-element division
         int r = fd.div(lane), c = lane - r * ndw;
         const int dr = fd.div(64), dc = 64 - dr * ndw;
-        for (int i = lane; i < th * ndw; i += 64) {
-            reinterpret_cast<uint32_t *>(tile + r * P)[c] = *reinterpret_cast<const uint32_t *>(src + (unsigned)(r * pitch + 4 * c));
-            r += dr; c += dc;
-            if (c >= ndw) { c -= ndw; r++; }
+        // loads go out in batches of eight before any is consumed (a rolled load/store loop is one global round trip
+        // per iteration); a 30-px cell needs one batch, the largest cells of the (72, 64) variant three
+        const int total = th * ndw;
+        for (int i0 = 0; i0 < total; i0 += 8 * 64) {
+            uint32_t tv[8];
+            int tr[8], tc[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                tr[k] = r; tc[k] = c;
+                if (i0 + 64 * k + lane < total) tv[k] = *reinterpret_cast<const uint32_t *>(src + (unsigned)(r * pitch + 4 * c));
+                r += dr; c += dc;
+                if (c >= ndw) { c -= ndw; r++; }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (i0 + 64 * k + lane < total) reinterpret_cast<uint32_t *>(tile + tr[k] * P)[tc[k]] = tv[k];
         }
     } else {
         xo = 0;
@@ -671,14 +694,28 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     const int x = p & 0xFFF, y = (p >> 12) & 0xFFF, resp = p >> 24;
     int pitch;
     const uint8_t *img = orbx_level_ptr(pr, L, l, b, &pitch);
+#ifdef ORBX_DIAG
+    asm volatile("" :: "v"(x), "s"(pitch));
+    DSTAMP(5); // prologue: level search, level counts, packed keypoint
+#endif
     // ---- stage the 43x43 patch; xo = LDS column of patch column 0
     int xo = (x - 21) & 3;
     const int x0a = x - 21 - xo;
     if (x >= 21 && x + 21 < L.w && y >= 21 && y + 21 < L.h && x0a + 48 <= pitch && (((uintptr_t)img | (unsigned)pitch) & 3) == 0) {
         const uint8_t *src = img + (long long)(y - 21) * pitch + x0a;
-        for (int i = lane; i < 43 * 12; i += 64) {
+        // all nine loads of a lane are issued before the first one is consumed: a rolled loop waits for every load
+        // before the next is issued (nine dependent global round trips per wave, 41 % of the wave's life)
+        uint32_t pv[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int i = lane + 64 * k;
             const int r = i / 12, c = i - r * 12;
-            reinterpret_cast<uint32_t *>(raw)[i] = *reinterpret_cast<const uint32_t *>(src + (long long)r * pitch + 4 * c);
+            if (i < 43 * 12) pv[k] = *reinterpret_cast<const uint32_t *>(src + (long long)r * pitch + 4 * c);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int i = lane + 64 * k;
+            if (i < 43 * 12) reinterpret_cast<uint32_t *>(raw)[i] = pv[k];
         }
     } else { // image edge (BORDER_REFLECT_101 of the cloned level, :1312-1314) or unaligned input
         xo = 0;
@@ -687,6 +724,7 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
             raw[r * RP + c] = img[(long long)reflect101(y - 21 + r, L.h) * pitch + reflect101(x - 21 + c, L.w)];
         }
     }
+    DSTAMP(6); // patch loads issued and consumed (the last LDS stores may still be in flight)
     __syncthreads();
     DSTAMP(0);
     // ---- IC_Angle: lane = (row v+15, half); integer moments, order-independent

@@ -34,7 +34,7 @@ for _ in range(5): step()
 ex.sync()
 L.orbx_diag_desc_stamps(out,1)
 w=out[7]
-names=["load","orient","rowpass","colpass","sample+store"]
-tot=sum(out[i] for i in range(5))
+names=["sync after load","orient","rowpass","colpass","sample+store","prologue (levels, counts, kp)","patch load"]
+tot=sum(out[i] for i in range(7))
 print("k_desc waves",w, "avg cycles/wave", tot/w)
-for i,nm in enumerate(names): print(f"  {nm:12s} {out[i]/w:9.1f} cycles  {100*out[i]/tot:5.1f}%")
+for i in (5,6,0,1,2,3,4): print(f"  {names[i]:30s} {out[i]/w:9.1f} cycles  {100*out[i]/tot:5.1f}%")
