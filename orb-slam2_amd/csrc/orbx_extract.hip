@@ -12,22 +12,24 @@
 #include <stdio.h>
 #include <string.h>
 
-__constant__ signed char c_pat[4][256];   // x0,y0,x1,y1 (src/ORBextractor.cc:160-418, data)
+__constant__ uint32_t c_pat4[256];        // x0 | y0<<8 | x1<<16 | y1<<24, signed bytes (src/ORBextractor.cc:160-418, data)
 __constant__ int c_umax[16];              // src/ORBextractor.cc:510-533
 __constant__ int c_gauss[7];              // 8-bit fixed point 7-tap sigma=2 kernel
 
 // ================================================================ K1: pyramid level (E2)
 // cv::resize INTER_LINEAR 8UC1 from level l-1 to level l.  Coefficient tables are
 // computed on the host with the reference's float/double arithmetic; the kernel is pure integer.
-// A 256-thread workgroup produces a 256x32 output tile: the source rectangle it needs (<= 310x41)
-// is staged in LDS with coalesced aligned dword loads, each thread then computes a 4x8 block
-// (x tables loaded once per thread) and stores one dword per row.
-#define RS_TW 256
-#define RS_TH 32
-#define RS_PITCH 336 // LDS bytes per staged source row (>= 1.2 * 256 + 2 + 3 + alignment)
-#define RS_ROWS 42
+// A one-wave workgroup produces a 128x16 output tile: the source rectangle it needs (<= 156x21) is staged
+// in LDS with aligned dword loads issued in batches, each lane then computes a 4x8 block (x tables loaded once
+// per lane) and stores one dword per row.  One-wave workgroups need no barrier partners and drift apart in time,
+// so loads of one tile overlap arithmetic of another on the same CU.
+#define RS_TW 128
+#define RS_TH 16
+#define RS_NT 64     // threads per workgroup = (RS_TW / 4) * (RS_TH / 8): one wave, no workgroup barrier partners
+#define RS_PITCH 176 // LDS bytes per staged source row (>= 1.2 * RS_TW + 2 + 3 + alignment)
+#define RS_ROWS 22
 
-__global__ __launch_bounds__(256) void k_resize(const Geom *__restrict__ g, int l, PyrRef pr,
+__global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, int l, PyrRef pr,
                                                 uint8_t *__restrict__ pyr_w, const int16_t *__restrict__ tabs)
 {
     __shared__ __align__(16) uint8_t src_t[RS_ROWS * RS_PITCH];
@@ -50,32 +52,32 @@ __global__ __launch_bounds__(256) void k_resize(const Geom *__restrict__ g, int 
         const FastDiv fd(ndw);
         const uint8_t *s0 = src + (long long)sy_min * spitch + sxa;
         const int total = nrows * ndw; // <= 42 * 84: two batches of eight loads per thread, each issued before it is consumed
-        for (int i0 = 0; i0 < total; i0 += 8 * 256) {
+        for (int i0 = 0; i0 < total; i0 += 8 * RS_NT) {
             uint32_t tv[8];
             int to[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int i = i0 + 256 * k + tid;
+                const int i = i0 + RS_NT * k + tid;
                 const int r = fd.div(i), c = i - r * ndw;
                 to[k] = r * (RS_PITCH / 4) + c;
                 if (i < total) tv[k] = *reinterpret_cast<const uint32_t *>(s0 + (long long)r * spitch + 4 * c);
             }
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                if (i0 + 256 * k + tid < total) reinterpret_cast<uint32_t *>(src_t)[to[k]] = tv[k];
+                if (i0 + RS_NT * k + tid < total) reinterpret_cast<uint32_t *>(src_t)[to[k]] = tv[k];
         }
     } else {
         sxa = sx_min;
         const int nb = sx_max - sxa + 1;
         const FastDiv fd(nb);
         const uint8_t *s0 = src + (long long)sy_min * spitch + sxa;
-        for (int i = tid; i < nrows * nb; i += 256) {
+        for (int i = tid; i < nrows * nb; i += RS_NT) {
             const int r = fd.div(i), c = i - r * nb;
             src_t[r * RS_PITCH + c] = s0[(long long)r * spitch + c];
         }
     }
     __syncthreads();
-    const int x4 = x_t + (tid & 63) * 4, y4 = y_t + (tid >> 6) * 8;
+    const int x4 = x_t + (tid & (RS_TW / 4 - 1)) * 4, y4 = y_t + (tid / (RS_TW / 4)) * 8;
     if (x4 >= D.pitch) return;
     int o0[4], o1[4], a0[4], a1[4];
 #pragma unroll
@@ -666,7 +668,8 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
 // compared with one ballot per 64 pairs (computeOrbDescriptor, :116-157).
 __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef pr, const int *__restrict__ lvl_cnt,
                                              const uint32_t *__restrict__ lvl_kp, orbx_keypoint *__restrict__ out_kps,
-                                             uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap)
+                                             uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap,
+                                             unsigned long long umax_packed)
 {
     constexpr int RP = 48, HP = 40, BP = 40; // LDS pitches: raw bytes, row-pass u16, blurred bytes
     __shared__ __align__(16) uint8_t raw[43 * RP + 16];
@@ -684,6 +687,11 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     unsigned long long _t_prev = __builtin_amdgcn_s_memtime();
 #endif
     const uint32_t p = lvl_kp[(long long)b * g->kp_total + slot];
+    // the lane's four pattern words (lane-indexed constant data = vector loads) are requested here, with the first
+    // memory round trip, not in the sampling phase where they would cost a round trip of their own
+    uint32_t pat4[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) pat4[jj] = c_pat4[lane + 64 * jj];
     int off = 0, total = 0;
     for (int i = 0; i < g->nlevels; i++) { const int c = lc[i]; if (i < l) off += c; total += c; }
     if (slot == 0 && lane == 0) out_n[b] = total < cap ? total : cap;
@@ -730,11 +738,18 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     // ---- IC_Angle: lane = (row v+15, half); integer moments, order-independent
     int m10 = 0, m01 = 0;
     if (lane < 62) {
-        const int v = (lane >> 1) - 15, dmax = c_umax[v < 0 ? -v : v];
+        // umax (values <= 15) arrives packed in a kernel argument, 4 bits per row: a divergent index into a
+        // __constant__ array is a vector global load, i.e. one more memory round trip on every wave's critical path
+        const int v = (lane >> 1) - 15, dmax = (int)((umax_packed >> (4 * (v < 0 ? -v : v))) & 15);
         const int u0 = (lane & 1) ? 0 : -dmax, u1 = (lane & 1) ? dmax : -1;
-        const uint8_t *row = raw + (21 + v) * RP + xo + 21;
+        const uint8_t *row = raw + (21 + v) * RP + xo + 21 + u0;
+        const int n = u1 - u0 + 1; // <= 16
         int rs = 0;
-        for (int u = u0; u <= u1; u++) { const int I = row[u]; rs += I; m10 += u * I; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) { // unrolled: the 16 LDS reads are in flight together instead of one latency each
+            const int I = k < n ? row[k] : 0;
+            rs += I; m10 += (u0 + k) * I;
+        }
         m01 = v * rs;
     }
     m10 = wave_sum(m10);
@@ -787,7 +802,9 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
 #pragma unroll
     for (int jj = 0; jj < 4; jj++) {
         const int pi = lane + 64 * jj;
-        const float x0 = (float)c_pat[0][pi], y0 = (float)c_pat[1][pi], x1 = (float)c_pat[2][pi], y1 = (float)c_pat[3][pi];
+        const uint32_t pw = pat4[jj];
+        const float x0 = (float)(signed char)(pw & 0xFF), y0 = (float)(signed char)((pw >> 8) & 0xFF),
+                    x1 = (float)(signed char)((pw >> 16) & 0xFF), y1 = (float)(signed char)(pw >> 24);
         const int r0 = dev_cv_round(x0 * bb + y0 * a), q0 = dev_cv_round(x0 * a - y0 * bb);
         const int r1 = dev_cv_round(x1 * bb + y1 * a), q1 = dev_cv_round(x1 * a - y1 * bb);
         const int t0 = bl[(18 + r0) * BP + 18 + q0], t1 = bl[(18 + r1) * BP + 18 + q1];
@@ -942,7 +959,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         linear_tables(S.w, L.w, &tabs[L.tab_x], &tabs[L.tab_x + L.w], &tabs[L.tab_x + 2 * L.w]);
         linear_tables(S.h, L.h, &tabs[L.tab_y], &tabs[L.tab_y + L.h], &tabs[L.tab_y + 2 * L.h]);
     }
-    for (int l = 1; l < e->nlevels; l++) { // does every 128x32 tile's source rectangle fit k_resize's LDS tile?
+    for (int l = 1; l < e->nlevels; l++) { // does every output tile's source rectangle fit k_resize's LDS tile?
         LevelGeom &L = G.lv[l];
         const LevelGeom &S = G.lv[l - 1];
         const int16_t *tx = &tabs[L.tab_x], *ty = &tabs[L.tab_y];
@@ -1013,10 +1030,11 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
 
 static int upload_constants(orbx_extractor *e)
 {
-    signed char pat[4][256];
-    memcpy(pat[0], ORB_PAT_X0, 256); memcpy(pat[1], ORB_PAT_Y0, 256);
-    memcpy(pat[2], ORB_PAT_X1, 256); memcpy(pat[3], ORB_PAT_Y1, 256);
-    ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pat), pat, sizeof pat));
+    uint32_t pat[256];
+    for (int i = 0; i < 256; i++)
+        pat[i] = (uint32_t)(uint8_t)ORB_PAT_X0[i] | ((uint32_t)(uint8_t)ORB_PAT_Y0[i] << 8) | ((uint32_t)(uint8_t)ORB_PAT_X1[i] << 16) |
+                 ((uint32_t)(uint8_t)ORB_PAT_Y1[i] << 24);
+    ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pat4), pat, sizeof pat));
     ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), e->umax, sizeof(int) * 16));
     // cv::getGaussianKernel(7, 2, CV_32F) -> 8-bit fixed point
     float cf[7]; double sum = 0; const double scale2x = -0.5 / (2.0 * 2.0);
@@ -1158,7 +1176,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
         const LevelGeom &L = G.lv[l];
         orbx_prof_begin(e, ORBX_STAGE_RESIZE, s);
         if (L.resize_lds)
-            hipLaunchKernelGGL(k_resize, dim3((L.w + RS_TW - 1) / RS_TW, (L.h + RS_TH - 1) / RS_TH, batch), dim3(256), 0, s,
+            hipLaunchKernelGGL(k_resize, dim3((L.w + RS_TW - 1) / RS_TW, (L.h + RS_TH - 1) / RS_TH, batch), dim3(RS_NT), 0, s,
                                e->d_geom, l, pr, e->d_pyr, e->d_tabs);
         else
             hipLaunchKernelGGL(k_resize_direct, dim3((L.pitch / 4 + 63) / 64, (L.h + 3) / 4, batch), dim3(256), 0, s,
@@ -1179,8 +1197,10 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
                        e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, lds_pts_cap(G), err_flag);
     orbx_prof_end(e, s);
     orbx_prof_begin(e, ORBX_STAGE_DESC, s);
+    unsigned long long umax_packed = 0;
+    for (int v = 0; v < 16; v++) umax_packed |= (unsigned long long)(e->umax[v] & 15) << (4 * v);
     hipLaunchKernelGGL(k_desc, dim3(G.kp_total, batch), dim3(64), 0, s, e->d_geom, pr, e->d_lvl_cnt, e->d_lvl_kp,
-                       (orbx_keypoint *)d_kps, (uint8_t *)d_desc, (int *)d_n_out, cap);
+                       (orbx_keypoint *)d_kps, (uint8_t *)d_desc, (int *)d_n_out, cap, umax_packed);
     orbx_prof_end(e, s);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
