@@ -30,10 +30,10 @@ sys.path.insert(0, ROOT)
 W, H, NFEAT, NLEVELS = 1241, 376, 1000, 8   # headline workload; --workload may rebind W/H/NFEAT
 WORKLOADS = {
     # name: (w, h, nfeatures, kind, default frames per step, metric string)
-    "stereo1000": (1241, 376, 1000, "stereo", 64, "frames/sec ORB extract+match, 1241x376 @1000 feats; bit-exact vs CPU"),
-    "stereo2000": (1241, 376, 2000, "stereo", 64, "frames/sec ORB extract + L/R stereo match, KITTI 1241x376 @2000 feats (BASELINE config 2)"),
+    "stereo1000": (1241, 376, 1000, "stereo", 256, "frames/sec ORB extract+match, 1241x376 @1000 feats; bit-exact vs CPU"),
+    "stereo2000": (1241, 376, 2000, "stereo", 128, "frames/sec ORB extract + L/R stereo match, KITTI 1241x376 @2000 feats (BASELINE config 2)"),
     "euroc_bow": (752, 480, 1000, "bow", 32, "frames/sec ORB extract + SearchByBoW vs 500-KF map, EuRoC 752x480 @1000 feats (BASELINE config 3)"),
-    "fhd4000": (1920, 1080, 4000, "mono", 16, "frames/sec ORB extract, 1920x1080 @4000 feats (BASELINE config 4)"),
+    "fhd4000": (1920, 1080, 4000, "mono", 64, "frames/sec ORB extract, 1920x1080 @4000 feats (BASELINE config 4)"),
 }
 BF, FX = 386.1448, 718.856          # reference Examples/Stereo/KITTI00-02.yaml:8,25
 MIN_Z = BF / FX                     # mb = mbf/fx (src/Frame.cc:118)
@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (0 = the workload's default)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="stereo1000",
                     help="stereo1000 is the BASELINE.json headline metric; the others are the remaining single-GPU configs")
-    ap.add_argument("--cpu-frames", type=int, default=60, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=240, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs (tiled to the batch)")
     args = ap.parse_args()
     global W, H, NFEAT
@@ -184,6 +184,8 @@ def main():
         bow = {"db": pkg.BowDatabase(kfs, device=local), "voc": voc, "frames": frames_fs, "ms": 0.0, "tms": 0.0, "queries": 0, "matches": 0}
 
     def step():
+        if bow is not None and prof_on[0]:
+            ex.profile_enable(True)   # the BoW part below idles the extractor's stream: start a fresh event chain
         extract()
         if stereo:
             orbx.stereo_match_batch_device(ex, 0, ex, B, B, kps.data_ptr(), desc.data_ptr(), nout.data_ptr(),
@@ -202,6 +204,8 @@ def main():
             bow["ms"] += (time.perf_counter() - tq) * 1e3
             bow["queries"] += B
 
+    prof_on = [False]
+
     def local_sync():
         stream.synchronize()
         torch.cuda.synchronize()
@@ -212,6 +216,7 @@ def main():
     if bow is not None:
         bow["ms"], bow["tms"], bow["queries"], bow["matches"] = 0.0, 0.0, 0, 0
     ex.profile_read(reset=True)
+    prof_on[0] = True
     ex.profile_enable(True)           # HIP events on the launch stream, around every kernel of the timed steps
     elapsed = st.timed_steps(step, args.steps, local_sync, world, device=dev)   # barrier + sync both sides, MAX over ranks
     ex.profile_enable(False)

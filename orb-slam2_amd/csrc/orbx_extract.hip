@@ -1214,6 +1214,7 @@ extern "C" int orbx_sync(orbx_extractor *e, void *stream)
     // the kernel error flag rides the same stream into pinned memory: one synchronisation, no blocking pageable copy
     ORBX_HIP(hipMemcpyAsync(e->h_flag, e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels, sizeof(int), hipMemcpyDeviceToHost, s));
     ORBX_HIP(hipStreamSynchronize(s));
+    e->prof_chain = false; // the stream idles from here on: the next launch must not share its begin event with the last one
     const int flag = *e->h_flag;
     if (flag) { orbx_set_error("quadtree kernel reported a node-table overflow"); return ORBX_E_CAPACITY; }
     return ORBX_OK;
