@@ -92,7 +92,7 @@ struct orbx_extractor {
     float *d_out_ur, *d_out_depth;
     // stereo scratch
     int *d_st_dist; size_t st_cap;         // SAD per left keypoint (or -1)
-    uint16_t *d_st_entries; size_t st_ent_cap; // row table entries (vRowIndices)
+    void *d_st_entries; size_t st_ent_cap;  // row table entries (vRowIndices): (iR | octave<<16, x)
     void *scratch[8]; size_t scratch_cap[8]; // host-API upload buffers
     // state of the most recent extract
     const uint8_t *last_img0; size_t last_img_stride, last_pitch; int last_batch;

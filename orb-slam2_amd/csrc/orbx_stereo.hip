@@ -26,7 +26,7 @@ extern __shared__ __align__(16) int prep_smem[];
 
 __global__ __launch_bounds__(256) void k_stereo_prep(const Geom *__restrict__ g, const orbx_keypoint *__restrict__ kR,
                                                      const int *__restrict__ nR, int cap, StereoTabs tabs,
-                                                     int *__restrict__ row_off, uint16_t *__restrict__ entries, int ent_cap)
+                                                     int *__restrict__ row_off, uint2 *__restrict__ entries, int ent_cap)
 {
     __shared__ int s_w[4];
     const int p = blockIdx.x, tid = threadIdx.x;
@@ -45,13 +45,17 @@ __global__ __launch_bounds__(256) void k_stereo_prep(const Geom *__restrict__ g,
     int *ro = row_off + (long long)p * (rows + 1);
     for (int i = tid; i < rows; i += 256) ro[i] = min(cnt[i], ent_cap);
     if (tid == 0) ro[rows] = min(total, ent_cap);
-    uint16_t *en = entries + (long long)p * ent_cap;
+    // an entry carries what the coarse stage tests (index, octave, x): the 28-byte keypoint record of every candidate
+    // is not gathered again per left keypoint, and the winner's x is known without another round trip
+    uint2 *en = entries + (long long)p * ent_cap;
     for (int ir = tid; ir < n_r; ir += 256) {
-        const float y = kr[ir].y, r = 2.0f * tabs.sf[kr[ir].octave & (ORBX_MAX_LEVELS - 1)];
+        const orbx_keypoint q = kr[ir];
+        const float y = q.y, r = 2.0f * tabs.sf[q.octave & (ORBX_MAX_LEVELS - 1)];
         const int maxr = min((int)ceilf(y + r), rows - 1), minr = max((int)floorf(y - r), 0);
+        const uint2 ent = make_uint2((unsigned)ir | ((unsigned)q.octave << 16), __float_as_uint(q.x));
         for (int yi = minr; yi <= maxr; yi++) {
             const int pos = cnt[yi] + atomicAdd(&cur[yi], 1);
-            if (pos < ent_cap) en[pos] = (uint16_t)ir;
+            if (pos < ent_cap) en[pos] = ent;
         }
     }
 }
@@ -62,8 +66,10 @@ __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrR
                                                 const uint32_t *__restrict__ dR, const int *__restrict__ nR, int cap,
                                                 float bf, float max_d, StereoTabs tabs, float *__restrict__ u_right,
                                                 float *__restrict__ depth, int *__restrict__ st_dist,
-                                                const int *__restrict__ row_off, const uint16_t *__restrict__ entries, int ent_cap)
+                                                const int *__restrict__ row_off, const uint2 *__restrict__ entries, int ent_cap)
 {
+    constexpr int SW_BYTES = 11 * 16 + 11 * 28 + 4; // per wave: left window rows (16 B) + right window rows (28 B)
+    __shared__ __align__(16) uint8_t s_win[4 * ((SW_BYTES + 15) & ~15)];
     const int p = blockIdx.y, lane = threadIdx.x & 63;
     const int il = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n_l = nL[p];
@@ -80,18 +86,22 @@ __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrR
     float out_u = -1.0f, out_z = -1.0f;
     int out_sad = -1;
     unsigned best = 0xFFFFFFFFu;
+    float best_x = 0.f; // x of the best right keypoint (uniform after the reduction)
     if (row >= 0 && row < n_rows && !(max_u < 0)) {
         uint32_t a[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) a[i] = dL[ol * 8 + i];
         const int *ro = row_off + (long long)p * (n_rows + 1);
-        const uint16_t *en = entries + (long long)p * ent_cap;
+        const uint2 *en = entries + (long long)p * ent_cap;
         const int e1 = ro[row + 1];
+        unsigned mine = 0xFFFFFFFFu;
+        float mine_x = 0.f;
         for (int base = ro[row]; base < e1; base += 64) { // right keypoints whose row band holds this row (:622)
             if (base + lane < e1) {
-                const int ir = en[base + lane];
-                const orbx_keypoint q = kr[ir];
-                if (q.octave >= level_l - 1 && q.octave <= level_l + 1 && q.x >= min_u && q.x <= max_u) {
+                const uint2 ent = en[base + lane];
+                const int ir = (int)(ent.x & 0xFFFFu), oct = (int)(short)(ent.x >> 16);
+                const float qx = __uint_as_float(ent.y);
+                if (oct >= level_l - 1 && oct <= level_l + 1 && qx >= min_u && qx <= max_u) {
                     uint32_t bq[8];
                     const uint4 *src = reinterpret_cast<const uint4 *>(dr + (long long)ir * 8);
                     const uint4 v0 = src[0], v1 = src[1];
@@ -100,17 +110,20 @@ __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrR
                     const int dist = hamming256(a, bq);
                     if (dist < 100) { // bestDist starts at TH_HIGH, strict <
                         const unsigned key = ((unsigned)dist << 16) | (unsigned)ir;
-                        best = key < best ? key : best;
+                        if (key < mine) { mine = key; mine_x = qx; }
                     }
                 }
             }
         }
-        best = wave_min_u32(best);
+        best = wave_min_u32(mine);
+        if (best != 0xFFFFFFFFu) { // the key holds iR, so exactly one lane owns the minimum
+            const unsigned long long own = __ballot(mine == best);
+            best_x = __shfl(mine_x, (int)__builtin_ctzll(own), WAVE);
+        }
     }
     const int best_dist = best == 0xFFFFFFFFu ? 100 : (int)(best >> 16);
     if (best_dist < 75) { // thOrbDist = (TH_HIGH+TH_LOW)/2
-        const int best_r = (int)(best & 0xFFFF);
-        const float ur0 = kr[best_r].x;
+        const float ur0 = best_x;
         const float sfac = tabs.isf[level_l];
         const float sul = roundf(kp.x * sfac), svl = roundf(kp.y * sfac), sur0 = roundf(ur0 * sfac);
         const LevelGeom &LV = g->lv[level_l];
@@ -120,21 +133,62 @@ __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrR
             const uint8_t *imL = orbx_level_ptr(prL, LV, level_l, img_l0 + p, &pl);
             const uint8_t *imR = orbx_level_ptr(prR, LV, level_l, img_r0 + p, &prr);
             const int cy = (int)svl, cxl = (int)sul;
-            const int lc = lvl_px(imL, pl, LV.w, LV.h, cxl, cy);
             // each lane owns window pixels e = lane and lane+64 (< 121)
             const int e0 = lane, e1 = lane + 64;
             const int dy0 = e0 / 11 - 5, dx0 = e0 % 11 - 5;
             const int dy1 = e1 / 11 - 5, dx1 = e1 % 11 - 5;
-            const int il0 = lvl_px(imL, pl, LV.w, LV.h, cxl + dx0, cy + dy0) - lc;
-            const int il1 = e1 < 121 ? lvl_px(imL, pl, LV.w, LV.h, cxl + dx1, cy + dy1) - lc : 0;
-            // all right-image loads first (independent, in flight together): the 11 shifts of window pixel
-            // (dx,dy) are the 11 consecutive columns sur0+dx-5 .. sur0+dx+5 of row cy+dy
             const int cx0 = (int)sur0;
-            int r0[11], r1[11];
+            int lc, il0, il1, r0[11], r1[11];
+            // Fast path (every window of a keypoint the extractor produced): both windows lie inside the level, so
+            // they are fetched as aligned dwords (left 11 rows x 4 dwords = 1 load instruction, right 11 x 7 = 2) into
+            // the wave's LDS slice and the 24 per-lane pixels are LDS byte reads.  Gathering them straight from
+            // global memory is 25 byte-gather instructions of 64 scattered addresses each per wave, which made the
+            // kernel texture-addresser bound.  Windows that touch the border take the reflect-101 byte path.
+            const bool inside = cy - 5 >= 0 && cy + 5 < LV.h && cxl - 5 >= 0 && cxl + 5 < LV.w && cx0 - 10 >= 0 && cx0 + 10 < LV.w &&
+                                ((((uintptr_t)imL | (uintptr_t)imR | (unsigned)pl | (unsigned)prr) & 3) == 0);
+            if (inside) {
+                uint8_t *wl = s_win + (threadIdx.x >> 6) * ((SW_BYTES + 15) & ~15), *wr = wl + 11 * 16;
+                const int xla = (cxl - 5) & ~3, xra = (cx0 - 10) & ~3;
+                // right: 77 dwords (clamped at the row end: the extra bytes of a clamped dword are never read)
+                uint32_t vr0, vr1 = 0, vl = 0;
+                {
+                    const int rr = lane / 7, cc = lane - rr * 7;
+                    const int xo_ = min(xra + 4 * cc, (prr - 4));
+                    vr0 = *reinterpret_cast<const uint32_t *>(imR + (long long)(cy - 5 + rr) * prr + xo_);
+                    if (lane < 13) {
+                        const int i2 = lane + 64, r2 = i2 / 7, c2 = i2 - r2 * 7;
+                        vr1 = *reinterpret_cast<const uint32_t *>(imR + (long long)(cy - 5 + r2) * prr + min(xra + 4 * c2, prr - 4));
+                    }
+                    if (lane < 44) {
+                        const int r3 = lane >> 2, c3 = lane & 3;
+                        vl = *reinterpret_cast<const uint32_t *>(imL + (long long)(cy - 5 + r3) * pl + min(xla + 4 * c3, pl - 4));
+                    }
+                    reinterpret_cast<uint32_t *>(wr)[lane] = vr0;        // row pitch 28 bytes = 7 dwords: index = r*7 + c
+                    if (lane < 13) reinterpret_cast<uint32_t *>(wr)[lane + 64] = vr1;
+                    if (lane < 44) reinterpret_cast<uint32_t *>(wl)[lane] = vl; // row pitch 16 bytes
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int ol_ = cxl - xla, or_ = cx0 - xra; // byte offset of the window centre column in a staged row
+                lc = wl[5 * 16 + ol_];
+                il0 = wl[(dy0 + 5) * 16 + ol_ + dx0] - lc;
+                il1 = e1 < 121 ? wl[(dy1 + 5) * 16 + ol_ + dx1] - lc : 0;
 #pragma unroll
-            for (int k = 0; k < 11; k++) {
-                r0[k] = lvl_px(imR, prr, LV.w, LV.h, cx0 + dx0 + k - 5, cy + dy0);
-                r1[k] = e1 < 121 ? lvl_px(imR, prr, LV.w, LV.h, cx0 + dx1 + k - 5, cy + dy1) : 0;
+                for (int k = 0; k < 11; k++) {
+                    r0[k] = wr[(dy0 + 5) * 28 + or_ + dx0 + k - 5];
+                    r1[k] = e1 < 121 ? wr[(dy1 + 5) * 28 + or_ + dx1 + k - 5] : 0;
+                }
+            } else {
+                lc = lvl_px(imL, pl, LV.w, LV.h, cxl, cy);
+                il0 = lvl_px(imL, pl, LV.w, LV.h, cxl + dx0, cy + dy0) - lc;
+                il1 = e1 < 121 ? lvl_px(imL, pl, LV.w, LV.h, cxl + dx1, cy + dy1) - lc : 0;
+                // all right-image loads first (independent, in flight together): the 11 shifts of window pixel
+                // (dx,dy) are the 11 consecutive columns sur0+dx-5 .. sur0+dx+5 of row cy+dy
+#pragma unroll
+                for (int k = 0; k < 11; k++) {
+                    r0[k] = lvl_px(imR, prr, LV.w, LV.h, cx0 + dx0 + k - 5, cy + dy0);
+                    r1[k] = e1 < 121 ? lvl_px(imR, prr, LV.w, LV.h, cx0 + dx1 + k - 5, cy + dy1) : 0;
+                }
             }
             int dists[11];
             // lane 60 is the window centre (dy = 0, dx = 0): its r0[k] is the centre pixel of shift k
@@ -270,7 +324,7 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
     {
         int rc;
         if ((rc = orbx_scratch(L, 7, (size_t)batch * (rows + 1) * sizeof(int), &d_row_off))) return rc;
-        const size_t need_e = (size_t)batch * ent_cap * sizeof(uint16_t);
+        const size_t need_e = (size_t)batch * ent_cap * sizeof(uint2);
         if (need_e > L->st_ent_cap || !L->d_st_entries) {
             ORBX_HIP(hipStreamSynchronize(s));
             if (L->d_st_entries) ORBX_HIP(hipFree(L->d_st_entries));
@@ -288,11 +342,11 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
     const float max_d = bf / min_z; // src/Frame.cc:609
     orbx_prof_begin(L, ORBX_STAGE_STEREO, s);
     hipLaunchKernelGGL(k_stereo_prep, dim3(batch), dim3(256), (size_t)2 * ((rows + 4) & ~3) * sizeof(int), s, L->d_geom,
-                       (const orbx_keypoint *)d_kR, (const int *)d_nR, cap, tabs, (int *)d_row_off, (uint16_t *)d_entries, ent_cap);
+                       (const orbx_keypoint *)d_kR, (const int *)d_nR, cap, tabs, (int *)d_row_off, (uint2 *)d_entries, ent_cap);
     hipLaunchKernelGGL(k_stereo, dim3((cap + 3) / 4, batch), dim3(256), 0, s, L->d_geom, pl, pr, img_l0, img_r0,
                        (const orbx_keypoint *)d_kL, (const uint32_t *)d_dL, (const int *)d_nL,
                        (const orbx_keypoint *)d_kR, (const uint32_t *)d_dR, (const int *)d_nR, cap, bf, max_d, tabs,
-                       (float *)d_u_right, (float *)d_depth, L->d_st_dist, (const int *)d_row_off, (const uint16_t *)d_entries, ent_cap);
+                       (float *)d_u_right, (float *)d_depth, L->d_st_dist, (const int *)d_row_off, (const uint2 *)d_entries, ent_cap);
     orbx_prof_end(L, s);
     orbx_prof_begin(L, ORBX_STAGE_STEREO_CUT, s);
     hipLaunchKernelGGL(k_stereo_cut, dim3(batch), dim3(256), 0, s, (const int *)d_nL, cap, (float *)d_u_right,
