@@ -42,8 +42,8 @@ __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, in
     uint8_t *dst = pyr_w + (long long)b * pr.pyr_stride + D.pyr_off;
     const int16_t *tx = tabs + D.tab_x, *ty = tabs + D.tab_y;
     const int x_last = min(x_t + RS_TW, D.w) - 1, y_last = min(y_t + RS_TH, D.h) - 1;
-    const int sx_min = tx[x_t], sx_max = min(tx[x_last] + 1, S.w - 1);
-    const int sy_min = ty[y_t], sy_max = min(ty[y_last] + 1, S.h - 1);
+    const int sx_min = tx[4 * x_t], sx_max = min(tx[4 * x_last] + 1, S.w - 1);
+    const int sy_min = ty[4 * y_t], sy_max = min(ty[4 * y_last] + 1, S.h - 1);
     const int nrows = sy_max - sy_min + 1;
     int sxa; // source column held in LDS column 0
     if ((((uintptr_t)src | (unsigned)spitch) & 3) == 0) {
@@ -83,17 +83,19 @@ __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, in
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int x = min(x4 + i, D.w - 1);
-        const int sx0 = tx[x];
+        const short4 q = *reinterpret_cast<const short4 *>(tx + 4 * x); // (ofs, a0, a1, 0)
+        const int sx0 = q.x;
         o0[i] = sx0 - sxa;
         o1[i] = min(sx0 + 1, S.w - 1) - sxa;
-        a0[i] = tx[D.w + x];
-        a1[i] = tx[2 * D.w + x];
+        a0[i] = q.y;
+        a1[i] = q.z;
     }
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int y = y4 + j;
         if (y >= D.h) break;
-        const int sy0 = ty[y], b0 = ty[D.h + y], b1 = ty[2 * D.h + y];
+        const short4 qy = *reinterpret_cast<const short4 *>(ty + 4 * y);
+        const int sy0 = qy.x, b0 = qy.y, b1 = qy.z;
         const uint8_t *r0 = src_t + (sy0 - sy_min) * RS_PITCH;
         const uint8_t *r1 = src_t + (min(sy0 + 1, S.h - 1) - sy_min) * RS_PITCH;
         uint32_t out = 0;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void k_resize_direct(const Geom *__restrict__ 
     const uint8_t *src = orbx_level_ptr(pr, S, l - 1, b, &spitch);
     uint8_t *dst = pyr_w + (long long)b * pr.pyr_stride + D.pyr_off;
     const int16_t *tx = tabs + D.tab_x, *ty = tabs + D.tab_y;
-    const int sy0 = ty[y], b0 = ty[D.h + y], b1 = ty[2 * D.h + y];
+    const int sy0 = ty[4 * y], b0 = ty[4 * y + 1], b1 = ty[4 * y + 2];
     const int sy1 = sy0 + 1 < S.h ? sy0 + 1 : S.h - 1;
     const uint8_t *r0 = src + (long long)sy0 * spitch, *r1 = src + (long long)sy1 * spitch;
     uint32_t out = 0;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void k_resize_direct(const Geom *__restrict__ 
     for (int i = 0; i < 4; i++) {
         const int x = x4 + i;
         if (x < D.w) {
-            const int sx0 = tx[x], a0 = tx[D.w + x], a1 = tx[2 * D.w + x];
+            const int sx0 = tx[4 * x], a0 = tx[4 * x + 1], a1 = tx[4 * x + 2];
             const int sx1 = sx0 + 1 < S.w ? sx0 + 1 : S.w - 1;
             const int t0 = r0[sx0] * a0 + r0[sx1] * a1;
             const int t1 = r1[sx0] * a0 + r1[sx1] * a1;
@@ -834,7 +836,8 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // cv::resize coefficient tables, reference call site src/ORBextractor.cc:1366
-static void linear_tables(int ssize, int dsize, int16_t *ofs, int16_t *c0, int16_t *c1)
+// Stored interleaved, one (ofs, c0, c1, 0) quad of int16 per destination index: one 8-byte load per index on the device.
+static void linear_tables(int ssize, int dsize, int16_t *quads)
 {
     const double inv_scale = (double)dsize / ssize;
     const double scale = 1. / inv_scale;
@@ -845,9 +848,10 @@ static void linear_tables(int ssize, int dsize, int16_t *ofs, int16_t *c0, int16
         if (s < 0) { f = 0; s = 0; }
         if (s >= ssize - 1) { f = 0; s = ssize - 1; }
         int v0 = orbx_cv_round((1.f - f) * 2048), v1 = orbx_cv_round(f * 2048);
-        ofs[d] = (int16_t)s;
-        c0[d] = (int16_t)(v0 < -32768 ? -32768 : v0 > 32767 ? 32767 : v0);
-        c1[d] = (int16_t)(v1 < -32768 ? -32768 : v1 > 32767 ? 32767 : v1);
+        quads[4 * d] = (int16_t)s;
+        quads[4 * d + 1] = (int16_t)(v0 < -32768 ? -32768 : v0 > 32767 ? 32767 : v0);
+        quads[4 * d + 2] = (int16_t)(v1 < -32768 ? -32768 : v1 > 32767 ? 32767 : v1);
+        quads[4 * d + 3] = 0;
     }
 }
 
@@ -926,8 +930,8 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
             L.pitch = (int)align_up(L.w, 64);
             L.pyr_off = G.pyr_bytes;
             G.pyr_bytes += (long long)L.pitch * L.h;
-            L.tab_x = (int)tab_units; tab_units += 3 * (size_t)L.w;
-            L.tab_y = (int)tab_units; tab_units += 3 * (size_t)L.h;
+            L.tab_x = (int)tab_units; tab_units += 4 * (size_t)L.w;   // int16 units, multiples of 4: 8-byte aligned quads
+            L.tab_y = (int)tab_units; tab_units += 4 * (size_t)L.h;
         }
         if (L.n_cells > G.max_cells_level) G.max_cells_level = L.n_cells;
         if (L.node_cap > G.max_node_cap) G.max_node_cap = L.node_cap;
@@ -956,8 +960,8 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
     for (int l = 1; l < e->nlevels; l++) {
         LevelGeom &L = G.lv[l];
         const LevelGeom &S = G.lv[l - 1];
-        linear_tables(S.w, L.w, &tabs[L.tab_x], &tabs[L.tab_x + L.w], &tabs[L.tab_x + 2 * L.w]);
-        linear_tables(S.h, L.h, &tabs[L.tab_y], &tabs[L.tab_y + L.h], &tabs[L.tab_y + 2 * L.h]);
+        linear_tables(S.w, L.w, &tabs[L.tab_x]);
+        linear_tables(S.h, L.h, &tabs[L.tab_y]);
     }
     for (int l = 1; l < e->nlevels; l++) { // does every output tile's source rectangle fit k_resize's LDS tile?
         LevelGeom &L = G.lv[l];
@@ -966,13 +970,13 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         bool ok = true;
         for (int x0 = 0; x0 < L.w && ok; x0 += RS_TW) {
             const int xl = (x0 + RS_TW < L.w ? x0 + RS_TW : L.w) - 1;
-            const int smax = tx[xl] + 1 < S.w - 1 ? tx[xl] + 1 : S.w - 1;
-            if (((smax - (tx[x0] & ~3)) / 4 + 1) * 4 > RS_PITCH) ok = false;
+            const int smax = tx[4 * xl] + 1 < S.w - 1 ? tx[4 * xl] + 1 : S.w - 1;
+            if (((smax - (tx[4 * x0] & ~3)) / 4 + 1) * 4 > RS_PITCH) ok = false;
         }
         for (int y0 = 0; y0 < L.h && ok; y0 += RS_TH) {
             const int yl = (y0 + RS_TH < L.h ? y0 + RS_TH : L.h) - 1;
-            const int smax = ty[yl] + 1 < S.h - 1 ? ty[yl] + 1 : S.h - 1;
-            if (smax - ty[y0] + 1 > RS_ROWS) ok = false;
+            const int smax = ty[4 * yl] + 1 < S.h - 1 ? ty[4 * yl] + 1 : S.h - 1;
+            if (smax - ty[4 * y0] + 1 > RS_ROWS) ok = false;
         }
         L.resize_lds = ok ? 1 : 0;
     }
