@@ -225,6 +225,24 @@ int orbx_bow_transform(orbx_vocab *v, const uint8_t *desc, int n, int levelsup,
 
 /* the current Frame: undistorted keypoints, right coordinates, descriptors, image bounds (the 64x48 feature
  * grid of Frame::AssignFeaturesToGrid / GetFeaturesInArea, src/Frame.cc:261-279,:386-457, is rebuilt on device) */
+/* ---- batched, device-resident ComputeBoW + relocalisation search (BASELINE config 3 at throughput) ----
+ * orbx_bow_frames holds, in HBM, what Frame::ComputeBoW produces (mBowVec, mFeatVec) for a batch of frames whose
+ * keypoints / descriptors / counts are the device outputs of orbx_extract_batch_device (same cap).  Nothing crosses
+ * PCIe between extraction, transform and search; orbx_bow_frames_read copies one frame's vectors to the host.
+ * stream = NULL: the transform runs on the vocabulary's own stream, read / search on the stream of the last transform. */
+typedef struct orbx_bow_frames orbx_bow_frames;
+int orbx_bow_frames_create(int device, int max_batch, int cap, orbx_bow_frames **out);
+void orbx_bow_frames_destroy(orbx_bow_frames *f);
+int orbx_bow_transform_batch_device(orbx_vocab *v, orbx_bow_frames *f, const void *d_kps, const void *d_desc, const void *d_n,
+                                    int batch, int levelsup, void *stream);
+int orbx_bow_frames_read(orbx_bow_frames *f, int index, void *stream, uint32_t *bow_id, double *bow_val, int *nbow,
+                         uint32_t *fv_node_id, int32_t *fv_node_off, uint32_t *fv_feat, int *fv_nnodes);
+/* every keyframe of db against frames 0..batch-1 of f (SearchByBoW(KF, F), src/ORBmatcher.cc:171-303, in the loop of
+ * Tracking::Relocalization :1661-1682): d_match[batch][nkf][cap] (int32, KF feature per frame feature or -1) and
+ * d_nmatches[batch][nkf], both device memory; asynchronous on `stream`. */
+int orbx_bowdb_search_batch_device(orbx_bowdb *db, const orbx_bow_frames *f, int batch, float nnratio, int check_orientation,
+                                   void *d_match, void *d_nmatches, void *stream);
+
 typedef struct {
     int n;
     const float *x, *y;        /* mvKeysUn[i].pt */

@@ -12,17 +12,6 @@
 #include <string.h>
 #include <vector>
 
-struct DevFeat {
-    int n, nnodes;
-    const uint32_t *desc;     // [n][8]
-    const uint32_t *node_id;  // [nnodes]
-    const int32_t *node_off;  // [nnodes+1]
-    const uint32_t *feat;
-    const uint8_t *flag;
-    const float *angle, *x, *y, *u_right;
-    const int32_t *octave;
-};
-
 struct TriParams { float F[9]; float ex, ey; float sf2[ORBX_MAX_LEVELS]; float sig2[ORBX_MAX_LEVELS]; int only_stereo; };
 
 #define BOW_TH_LOW 50
@@ -105,13 +94,15 @@ __global__ __launch_bounds__(1024) void k_bow(const DevFeat *__restrict__ sides_
     __shared__ int hist[BOW_HISTO];
     __shared__ int keep3[3];
     __shared__ int s_cnt;
-    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // grid.y = query frame of a batched (KF set) x (frames) search (1 otherwise)
+    const int pair = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const DevFeat A = sides_a[pair];
-    const DevFeat B = sides_b[b_shared ? 0 : pair];
+    const DevFeat B = sides_b[b_shared ? frame : pair];
     const int nslots = MODE == 0 ? B.n : A.n;
     uint8_t *claimed = bow_smem;                 // [B.n]
     uint8_t *bins = bow_smem + ((B.n + 15) & ~15); // [nslots]
-    int32_t *match = match_out + (long long)pair * match_stride;
+    int32_t *match = match_out + ((long long)frame * gridDim.x + pair) * match_stride;
+    nmatches += (long long)frame * gridDim.x;
     const int nwaves = blockDim.x >> 6; // the shared vocabulary nodes are dealt over all waves of the workgroup
     for (int i = tid; i < B.n; i += blockDim.x) claimed[i] = 0;
     for (int i = tid; i < nslots; i += blockDim.x) { bins[i] = 255; match[i] = -1; }
@@ -500,6 +491,26 @@ extern "C" int orbx_bowdb_search(orbx_bowdb *db, const orbx_featset *f, float nn
     ORBX_HIP(hipStreamSynchronize(db->stream));
     if (f->n) memcpy(match_f, db->h_out, sizeof(int32_t) * (size_t)db->nkf * f->n);
     memcpy(nmatches, db->h_out + (size_t)db->nkf * stride, sizeof(int) * db->nkf);
+    return ORBX_OK;
+}
+
+// Batched, device-resident relocalisation search: every keyframe of the set against every frame of an
+// orbx_bow_frames batch (the output of orbx_bow_transform_batch_device) in one launch, nothing crosses PCIe.
+extern "C" int orbx_bowdb_search_batch_device(orbx_bowdb *db, const orbx_bow_frames *fr, int batch, float nnratio,
+                                              int check_orientation, void *d_match, void *d_nmatches, void *stream)
+{
+    if (!db || !fr || !d_match || !d_nmatches || batch < 1 || batch > fr->batch || fr->device != db->device) {
+        orbx_set_error("orbx_bowdb_search_batch_device: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    ORBX_HIP(hipSetDevice(db->device));
+    const size_t lds = (size_t)((fr->cap + 15) & ~15) * 2 + 16;
+    if (lds > 150 * 1024) { orbx_set_error("feature set too large for LDS"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_bow<0>, dim3(db->nkf, batch), dim3(1024), lds, stream ? (hipStream_t)stream : fr->last_stream,
+                       (const DevFeat *)db->d_blob, (const DevFeat *)fr->d_feats, 1, nnratio, check_orientation, (int32_t *)d_match,
+                       fr->cap, (int *)d_nmatches);
+    ORBX_HIP(hipGetLastError());
     return ORBX_OK;
 }
 

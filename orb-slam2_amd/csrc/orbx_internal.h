@@ -101,6 +101,31 @@ struct orbx_extractor {
     float prof_ms[ORBX_STAGE_COUNT]; int prof_n[ORBX_STAGE_COUNT];
 };
 
+// one side of a BoW search on the device (FeatureVector as CSR, see orbx_featset)
+struct DevFeat {
+    int n, nnodes;
+    const uint32_t *desc;     // [n][8]
+    const uint32_t *node_id;  // [nnodes]
+    const int32_t *node_off;  // [nnodes+1]
+    const uint32_t *feat;
+    const uint8_t *flag;
+    const float *angle, *x, *y, *u_right;
+    const int32_t *octave;
+};
+
+// device-resident BoW data of a batch of frames (orbx_bow_transform_batch_device -> orbx_bowdb_search_batch_device)
+struct orbx_bow_frames {
+    int device, batch, cap, npad;
+    uint8_t *d_buf;
+    uint32_t *word_id; double *word_w; uint32_t *node_id;      // [batch][cap]
+    uint32_t *bow_id; double *bow_val; int *counts;             // [batch][cap], [batch][cap], [batch][2] (nbow, nnodes)
+    uint32_t *fv_node_id; int32_t *fv_node_off; uint32_t *fv_feat; // [batch][cap], [batch][cap+1 -> stride cap+4], [batch][npad]
+    float *angle;                                               // [batch][cap]
+    DevFeat *d_feats;                                           // [batch]
+    uint8_t *h_buf; size_t h_cap;                               // pinned staging of orbx_bow_frames_read
+    hipStream_t last_stream;                                    // stream of the most recent transform: the default of read / search
+};
+
 void orbx_set_error(const char *fmt, ...);
 #define ORBX_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
     orbx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return ORBX_E_HIP; } } while (0)

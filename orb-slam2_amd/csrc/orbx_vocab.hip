@@ -30,8 +30,15 @@ __global__ __launch_bounds__(256) void k_vocab_descend(const int *__restrict__ c
                                                        const int *__restrict__ word_of, const uint32_t *__restrict__ ndesc,
                                                        const double *__restrict__ nweight, const uint32_t *__restrict__ feat,
                                                        int n, int nid_level, uint32_t *__restrict__ word_id,
-                                                       double *__restrict__ word_w, uint32_t *__restrict__ node_id)
+                                                       double *__restrict__ word_w, uint32_t *__restrict__ node_id,
+                                                       const int *__restrict__ n_dev, int stride)
 {
+    // batched form: grid.y = frame, n = n_dev[frame], arrays strided by `stride` features per frame
+    if (n_dev) {
+        const long long o = (long long)blockIdx.y * stride;
+        n = min(n_dev[blockIdx.y], stride);
+        feat += o * 8; word_id += o; word_w += o; node_id += o;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     uint32_t f[8];
@@ -85,8 +92,14 @@ __global__ __launch_bounds__(256) void k_bow_build(int n, int npad, const uint32
                                                    const double *__restrict__ word_w, const uint32_t *__restrict__ node_id,
                                                    uint32_t *__restrict__ bow_id, double *__restrict__ bow_val, int *__restrict__ counts,
                                                    uint32_t *__restrict__ fv_node_id, int32_t *__restrict__ fv_node_off,
-                                                   uint32_t *__restrict__ fv_feat)
+                                                   uint32_t *__restrict__ fv_feat, const int *__restrict__ n_dev, int stride)
 {
+    if (n_dev) { // batched form: one workgroup per frame (blockIdx.x)
+        const long long o = (long long)blockIdx.x * stride;
+        n = min(n_dev[blockIdx.x], stride);
+        word_id += o; word_w += o; node_id += o; bow_id += o; bow_val += o; counts += 2 * blockIdx.x;
+        fv_node_id += o; fv_node_off += (long long)blockIdx.x * (stride + 4); fv_feat += (long long)blockIdx.x * npad;
+    }
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(vocab_smem);
     int *flags = reinterpret_cast<int *>(keys + npad);
     __shared__ int s_w[4];
@@ -299,12 +312,12 @@ extern "C" int orbx_bow_transform(orbx_vocab *v, const uint8_t *desc, int n, int
     ORBX_HIP(hipMemcpyAsync(d, desc, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
     hipLaunchKernelGGL(k_vocab_descend, dim3((n + 255) / 256), dim3(256), 0, v->stream, v->d_child_off, v->d_child_ids, v->d_word_id,
                        v->d_desc, v->d_weight, (const uint32_t *)d, n, v->L - levelsup, (uint32_t *)(d + o_word), (double *)(d + o_w),
-                       (uint32_t *)(d + o_nid));
+                       (uint32_t *)(d + o_nid), nullptr, 0);
     const size_t lds = (size_t)npad * 12 + 64;
     ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_bow_build, dim3(1), dim3(256), lds, v->stream, n, npad, (const uint32_t *)(d + o_word), (const double *)(d + o_w),
                        (const uint32_t *)(d + o_nid), (uint32_t *)(d + o_bid), (double *)(d + o_bval), (int *)(d + o_cnt),
-                       (uint32_t *)(d + o_fid), (int32_t *)(d + o_foff), (uint32_t *)(d + o_ffeat));
+                       (uint32_t *)(d + o_fid), (int32_t *)(d + o_foff), (uint32_t *)(d + o_ffeat), nullptr, 0);
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipMemcpyAsync(v->h_out + o_word, d + o_word, total - o_word, hipMemcpyDeviceToHost, v->stream));
     ORBX_HIP(hipStreamSynchronize(v->stream));
@@ -320,5 +333,132 @@ extern "C" int orbx_bow_transform(orbx_vocab *v, const uint8_t *desc, int n, int
     memcpy(fv_node_off, h + o_foff, 4 * ((size_t)nn + 1));
     memcpy(fv_feat, h + o_ffeat, 4 * (size_t)fv_node_off[nn]);
     *nbow = nb; *fv_nnodes = nn;
+    return ORBX_OK;
+}
+
+// ---------------------------------------------------------------- batched, device-resident form (BASELINE config 3)
+// Frame::ComputeBoW for a whole batch of extracted frames without leaving the device: descriptors and counts are the
+// extractor's outputs, the FeatureVectors stay in HBM as the DevFeat records orbx_bowdb_search_batch_device consumes.
+
+__global__ __launch_bounds__(256) void k_frames_fill(DevFeat *__restrict__ feats, const orbx_keypoint *__restrict__ kps,
+                                                     const uint32_t *__restrict__ desc, const int *__restrict__ n_dev, int cap, int npad,
+                                                     const int *__restrict__ counts, const uint32_t *__restrict__ fv_node_id,
+                                                     const int32_t *__restrict__ fv_node_off, const uint32_t *__restrict__ fv_feat,
+                                                     float *__restrict__ angle)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(n_dev[b], cap);
+    for (int i = tid; i < n; i += 256) angle[(long long)b * cap + i] = kps[(long long)b * cap + i].angle;
+    if (tid == 0) {
+        DevFeat f;
+        f.n = n; f.nnodes = counts[2 * b + 1];
+        f.desc = desc + (long long)b * cap * 8;
+        f.node_id = fv_node_id + (long long)b * cap;
+        f.node_off = fv_node_off + (long long)b * (cap + 4);
+        f.feat = fv_feat + (long long)b * npad;
+        f.flag = nullptr;                       // the frame side of SearchByBoW(KF, F) has no flag test
+        f.angle = angle + (long long)b * cap;
+        f.x = f.y = f.u_right = nullptr; f.octave = nullptr;
+        feats[b] = f;
+    }
+}
+
+extern "C" int orbx_bow_frames_create(int device, int max_batch, int cap, orbx_bow_frames **out)
+{
+    if (!out || max_batch < 1 || cap < 1 || cap > 8192) { orbx_set_error("orbx_bow_frames_create: invalid argument (cap <= 8192)"); return ORBX_E_INVALID; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        orbx_set_error("no usable HIP device %d (liborbx has no CPU fallback)", device);
+        return ORBX_E_NO_DEVICE;
+    }
+    ORBX_HIP(hipSetDevice(device));
+    orbx_bow_frames *f = new orbx_bow_frames();
+    memset(f, 0, sizeof *f);
+    f->device = device; f->batch = max_batch; f->cap = cap;
+    f->npad = 64;
+    while (f->npad < cap) f->npad <<= 1;
+    const size_t B = (size_t)max_batch, c = (size_t)cap;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t r = o; o += a16v(bytes); return r; };
+    const size_t o_word = take(4 * B * c), o_w = take(8 * B * c), o_nid = take(4 * B * c), o_bid = take(4 * B * c), o_bval = take(8 * B * c),
+                 o_cnt = take(8 * B), o_fid = take(4 * B * c), o_foff = take(4 * B * (c + 4)), o_ffeat = take(4 * B * f->npad),
+                 o_ang = take(4 * B * c), o_feats = take(sizeof(DevFeat) * B);
+    if (hipMalloc((void **)&f->d_buf, o) != hipSuccess) { orbx_set_error("orbx_bow_frames_create: hipMalloc of %zu bytes failed", o); delete f; return ORBX_E_HIP; }
+    uint8_t *d = f->d_buf;
+    f->word_id = (uint32_t *)(d + o_word); f->word_w = (double *)(d + o_w); f->node_id = (uint32_t *)(d + o_nid);
+    f->bow_id = (uint32_t *)(d + o_bid); f->bow_val = (double *)(d + o_bval); f->counts = (int *)(d + o_cnt);
+    f->fv_node_id = (uint32_t *)(d + o_fid); f->fv_node_off = (int32_t *)(d + o_foff); f->fv_feat = (uint32_t *)(d + o_ffeat);
+    f->angle = (float *)(d + o_ang); f->d_feats = (DevFeat *)(d + o_feats);
+    *out = f;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_bow_frames_destroy(orbx_bow_frames *f)
+{
+    if (!f) return;
+    hipSetDevice(f->device);
+    if (f->d_buf) hipFree(f->d_buf);
+    if (f->h_buf) hipHostFree(f->h_buf);
+    delete f;
+}
+
+extern "C" int orbx_bow_transform_batch_device(orbx_vocab *v, orbx_bow_frames *f, const void *d_kps, const void *d_desc, const void *d_n,
+                                               int batch, int levelsup, void *stream)
+{
+    if (!v || !f || !d_kps || !d_desc || !d_n || batch < 1 || batch > f->batch || v->device != f->device) {
+        orbx_set_error("orbx_bow_transform_batch_device: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    ORBX_HIP(hipSetDevice(v->device));
+    hipStream_t s = stream ? (hipStream_t)stream : v->stream;
+    f->last_stream = s;
+    const int cap = f->cap, npad = f->npad;
+    hipLaunchKernelGGL(k_vocab_descend, dim3((cap + 255) / 256, batch), dim3(256), 0, s, v->d_child_off, v->d_child_ids, v->d_word_id,
+                       v->d_desc, v->d_weight, (const uint32_t *)d_desc, 0, v->L - levelsup, f->word_id, f->word_w, f->node_id,
+                       (const int *)d_n, cap);
+    const size_t lds = (size_t)npad * 12 + 64;
+    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_bow_build, dim3(batch), dim3(256), lds, s, 0, npad, f->word_id, f->word_w, f->node_id, f->bow_id, f->bow_val,
+                       f->counts, f->fv_node_id, f->fv_node_off, f->fv_feat, (const int *)d_n, cap);
+    hipLaunchKernelGGL(k_frames_fill, dim3(batch), dim3(256), 0, s, f->d_feats, (const orbx_keypoint *)d_kps, (const uint32_t *)d_desc,
+                       (const int *)d_n, cap, npad, f->counts, f->fv_node_id, f->fv_node_off, f->fv_feat, f->angle);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+// host copy of one frame's transform (tests, and the adaptor when it needs mBowVec / mFeatVec on the host);
+// synchronises `stream`.  Capacities: bow_id / bow_val / fv_node_id / fv_feat hold cap entries, fv_node_off cap + 1.
+extern "C" int orbx_bow_frames_read(orbx_bow_frames *f, int index, void *stream, uint32_t *bow_id, double *bow_val, int *nbow,
+                                    uint32_t *fv_node_id, int32_t *fv_node_off, uint32_t *fv_feat, int *fv_nnodes)
+{
+    if (!f || index < 0 || index >= f->batch || !nbow || !fv_nnodes) { orbx_set_error("orbx_bow_frames_read: invalid argument"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipSetDevice(f->device));
+    const size_t c = (size_t)f->cap;
+    const size_t o_bid = 16, o_bval = o_bid + a16v(4 * c), o_fid = o_bval + a16v(8 * c), o_foff = o_fid + a16v(4 * c),
+                 o_ffeat = o_foff + a16v(4 * (c + 4)), total = o_ffeat + a16v(4 * (size_t)f->npad);
+    if (total > f->h_cap) {
+        if (f->h_buf) ORBX_HIP(hipHostFree(f->h_buf));
+        f->h_buf = nullptr;
+        ORBX_HIP(hipHostMalloc((void **)&f->h_buf, total, hipHostMallocDefault));
+        f->h_cap = total;
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : f->last_stream;
+    uint8_t *h = f->h_buf;
+    const size_t i = (size_t)index;
+    ORBX_HIP(hipMemcpyAsync(h, f->counts + 2 * i, 8, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(h + o_bid, f->bow_id + i * c, 4 * c, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(h + o_bval, f->bow_val + i * c, 8 * c, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(h + o_fid, f->fv_node_id + i * c, 4 * c, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(h + o_foff, f->fv_node_off + i * (c + 4), 4 * (c + 1), hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(h + o_ffeat, f->fv_feat + i * f->npad, 4 * (size_t)f->npad, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    const int nb = ((const int *)h)[0], nn = ((const int *)h)[1];
+    *nbow = nb; *fv_nnodes = nn;
+    if (bow_id) memcpy(bow_id, h + o_bid, 4 * (size_t)nb);
+    if (bow_val) memcpy(bow_val, h + o_bval, 8 * (size_t)nb);
+    if (fv_node_id) memcpy(fv_node_id, h + o_fid, 4 * (size_t)nn);
+    if (fv_node_off) memcpy(fv_node_off, h + o_foff, 4 * ((size_t)nn + 1));
+    if (fv_feat && fv_node_off) memcpy(fv_feat, h + o_ffeat, 4 * (size_t)fv_node_off[nn]);
     return ORBX_OK;
 }

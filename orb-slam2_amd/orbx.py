@@ -96,6 +96,11 @@ def lib():
     L.orbx_search_by_projection_keyframe.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, i, f, i, i, vp, ip]
     L.orbx_search_by_projection_sim3.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, i, f, vp, ip]
     L.orbx_window_best.argtypes = [i, C.POINTER(FrameFeats), C.POINTER(ProjPoints), vp, vp, i, f, i, i, vp, vp, ip]
+    L.orbx_bow_frames_create.argtypes = [i, i, i, C.POINTER(vp)]
+    L.orbx_bow_frames_destroy.argtypes = [vp]; L.orbx_bow_frames_destroy.restype = None
+    L.orbx_bow_transform_batch_device.argtypes = [vp, vp, vp, vp, vp, i, i, vp]
+    L.orbx_bow_frames_read.argtypes = [vp, i, vp, vp, vp, ip, vp, vp, vp, ip]
+    L.orbx_bowdb_search_batch_device.argtypes = [vp, vp, i, f, i, vp, vp, vp]
     L.orbx_undistort_keypoints.argtypes = [i, vp, i, f, f, f, f, vp, i, vp]
     L.orbx_rectifier_create.argtypes = [i, i, i, i, i, vp, vp, C.POINTER(vp)]
     L.orbx_rectifier_destroy.argtypes = [vp]; L.orbx_rectifier_destroy.restype = None
@@ -362,6 +367,38 @@ class BowDatabase:
         out = np.full((self.nkf, b.n), -1, np.int32); n = np.zeros(self.nkf, np.int32)
         _check(self._L.orbx_bowdb_search(self._h, C.byref(b), nnratio, int(checkOri), _p(out), _p(n)))
         return out, n
+
+
+class BowFrames:
+    """Device-resident Frame::ComputeBoW results of a batch of frames (include/orbx.h: orbx_bow_frames_*)."""
+
+    def __init__(self, max_batch, cap, device=0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        _check(self._L.orbx_bow_frames_create(device, max_batch, cap, C.byref(self._h)))
+        self.batch, self.cap = max_batch, cap
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.orbx_bow_frames_destroy(h)
+            self._h = None
+
+    def transform(self, voc, d_kps, d_desc, d_n, batch, levelsup=4, stream=None):
+        """device pointers of orbx_extract_batch_device's outputs -> BowVector / FeatureVector in HBM (asynchronous)"""
+        _check(self._L.orbx_bow_transform_batch_device(voc._h, self._h, d_kps, d_desc, d_n, batch, levelsup, stream))
+
+    def read(self, index, stream=None):
+        cap = self.cap
+        bid = np.zeros(cap, np.uint32); bval = np.zeros(cap, np.float64); nb = C.c_int()
+        fid = np.zeros(cap, np.uint32); foff = np.zeros(cap + 1, np.int32); ffeat = np.zeros(cap, np.uint32); fn = C.c_int()
+        _check(self._L.orbx_bow_frames_read(self._h, index, stream, _p(bid), _p(bval), C.byref(nb), _p(fid), _p(foff), _p(ffeat), C.byref(fn)))
+        return dict(bow_id=bid[:nb.value].copy(), bow_val=bval[:nb.value].copy(), fv_node_id=fid[:fn.value].copy(),
+                    fv_node_off=foff[:fn.value + 1].copy(), fv_feat=ffeat[:foff[fn.value]].copy())
+
+    def search(self, db, batch, d_match, d_nmatches, nnratio=0.75, checkOri=True, stream=None):
+        """every keyframe of a BowDatabase against frames 0..batch-1: d_match[batch][nkf][cap], d_nmatches[batch][nkf] (device)"""
+        _check(self._L.orbx_bowdb_search_batch_device(db._h, self._h, batch, nnratio, int(checkOri), d_match, d_nmatches, stream))
 
 
 class ORBmatcher:

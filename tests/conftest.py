@@ -15,6 +15,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def pkg():
     import __graft_entry__ as ge
+    try:    # tests that share device buffers with torch: let torch initialise the GPU before liborbx does (seen on the
+        import torch   # GPU box: torch's lazy CUDA init failed with "No HIP GPUs are available" after liborbx had run)
+        torch.cuda.is_available()
+    except Exception:
+        pass
     return ge.load_pkg()
 
 

@@ -147,3 +147,64 @@ def test_hip_vocab_edge_cases(pkg, oracle):
         pkg.ORBVocabulary(25, 2, par, leaf, nd, w)  # k > 20 (reference loader limit)
     with pytest.raises(pkg.OrbxError):
         pkg.ORBVocabulary.loadFromTextFile("/nonexistent/ORBvoc.txt")
+
+
+@pytest.mark.gpu
+def test_hip_device_resident_bow_chain(pkg, oracle):
+    """BASELINE config 3 at throughput: extract_batch_device -> orbx_bow_transform_batch_device ->
+    orbx_bowdb_search_batch_device without leaving the device, against the oracle per frame / per pair"""
+    import torch
+    W, H, B = 752, 480, 5
+    imgs = [synth.image(40 + i, W, H) for i in range(B)]
+    imgs[3] = np.full((H, W), 90, np.uint8)          # a featureless frame inside the batch
+    pitch = 768
+    host = np.zeros((B, H, pitch), np.uint8)
+    for i in range(B): host[i, :, :W] = imgs[i]
+    d_img = torch.from_numpy(host).cuda()
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7, device=0, max_size=(W, H), max_batch=B)
+    cap = ex.max_keypoints(W, H)
+    d_kps = torch.zeros((B, cap, 7), device="cuda"); d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.Stream(); st = stream.cuda_stream
+    ex.extract_batch_device(d_img.data_ptr(), H * pitch, pitch, B, W, H, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), st)
+    stream.synchronize()
+    n = d_n.cpu().numpy(); desc = d_desc.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+    assert n[3] == 0 and n[0] > 500
+    par, leaf, nd, w = synth.vocab_tree(41, 10, 4, stop_frac=0.02, data=desc[0, :n[0]])
+    voc = pkg.ORBVocabulary(10, 4, par, leaf, nd, w); ovoc = oracle.Vocabulary(10, 4, par, leaf, nd, w)
+    fr = pkg.BowFrames(B, cap)
+    fr.transform(voc, d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), B, 2, st)
+    frames = []
+    for i in range(B):
+        got = fr.read(i, st)
+        exp = ovoc.transform(desc[i, :n[i]], 2)
+        for k_ in ("bow_id", "fv_node_id", "fv_node_off", "fv_feat"):
+            assert (got[k_] == exp[k_]).all(), (i, k_)
+        assert got["bow_val"].tobytes() == exp["bow_val"].tobytes(), i       # doubles, bit-exact
+        ang = np.frombuffer(kps[i, :n[i]].tobytes(), dtype=pkg.KP_DTYPE)["angle"].copy()
+        frames.append(dict(desc=desc[i, :n[i]], node_id=exp["fv_node_id"], node_off=exp["fv_node_off"], feat=exp["fv_feat"],
+                           flag=np.zeros(n[i], np.uint8), angle=ang))
+    # a small keyframe set made from frame 0 and frame 1
+    rng = np.random.Generator(np.random.PCG64(42))
+    kfs = []
+    for j in range(7):
+        base = frames[j % 2]
+        perm = rng.permutation(len(base["desc"])); dk = synth.flip_bits(rng, base["desc"], 0.07)[perm]
+        t = ovoc.transform(dk, 2)
+        kfs.append(dict(desc=dk, node_id=t["fv_node_id"], node_off=t["fv_node_off"], feat=t["fv_feat"],
+                        flag=(rng.random(len(dk)) < 0.7).astype(np.uint8), angle=base["angle"][perm]))
+    db = pkg.BowDatabase(kfs)
+    d_match = torch.full((B, len(kfs), cap), -7, dtype=torch.int32, device="cuda"); d_nm = torch.zeros((B, len(kfs)), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    fr.search(db, B, d_match.data_ptr(), d_nm.data_ptr(), 0.75, True, st)
+    stream.synchronize()
+    m = d_match.cpu().numpy(); nm = d_nm.cpu().numpy()
+    total = 0
+    for i in range(B):
+        for j, kf in enumerate(kfs):
+            exp, en = oracle.search_by_bow_kf_f(kf, frames[i], 0.75, True)
+            assert nm[i, j] == en, (i, j, nm[i, j], en)
+            assert (m[i, j, :n[i]] == exp).all(), (i, j)
+            total += en
+    assert total > 500 and (nm[3] == 0).all()
