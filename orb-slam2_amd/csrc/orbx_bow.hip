@@ -86,68 +86,260 @@ extern __shared__ __align__(16) unsigned char bow_smem[];
 
 // MODE 0: SearchByBoW(KF, F)  — match[nB] indexed by the F feature, value = KF feature
 // MODE 1: SearchByBoW(KF, KF) — match[nA] indexed by the KF1 feature, value = KF2 feature
+//
+// Work decomposition.  Inside one shared vocabulary node the reference is sequential (a feature of the second side
+// that an earlier first-side feature has taken is skipped, :222 / :622), across nodes it is independent, and a
+// typical node holds ~10 x 10 features.  Walking the first side of a node with one wave (64 lanes over ~10 candidates,
+// two wave reductions per step) left most lanes idle, so the kernel is split in two phases per batch of nodes:
+//   1. all Hamming distances of all shared nodes, one (node, a, b) triple per thread, into an LDS table (u16;
+//      0xFFFE = the first-side feature takes no part, 0xFFFF = the second-side feature takes no part);
+//   2. the greedy walk of a node by ONE thread on that table (pure LDS reads, no descriptor traffic), 64 nodes per
+//      wave side by side.
+// Nodes are packed into passes of at most BOW_MATCAP table entries; a single node larger than that is walked by a
+// wave straight from global memory (node_greedy_wave, the former kernel body).
+#define BOW_MATCAP 12288
+#define BOW_CHUNK 256
+
 template <int MODE>
-__global__ __launch_bounds__(1024) void k_bow(const DevFeat *__restrict__ sides_a, const DevFeat *__restrict__ sides_b,
-                                             int b_shared, float nnratio, int check_ori, int32_t *__restrict__ match_out,
-                                             int match_stride, int *__restrict__ nmatches)
+__device__ void node_greedy_wave(const DevFeat &A, const DevFeat &B, int a0, int a1, int b0, int b1, uint8_t *claimed,
+                                 uint8_t *bins, int32_t *match, float nnratio, int lane)
+{
+    for (int i1 = a0; i1 < a1; i1++) {
+        const int idx1 = (int)A.feat[i1];
+        if (!A.flag[idx1]) continue;
+        uint32_t da[8];
+        load_desc(A.desc, idx1, da);
+        unsigned k1 = 0xFFFFFFFFu; // dist<<20 | position: first index wins ties (strict <, :229-239)
+        int l1 = 256, l2 = 256;
+        for (int j = b0 + lane; j < b1; j += 64) {
+            const int idx2 = (int)B.feat[j];
+            if (claimed[idx2]) continue;
+            if (MODE == 1 && !B.flag[idx2]) continue;
+            uint32_t db[8];
+            load_desc(B.desc, idx2, db);
+            const int dist = hamming256(da, db);
+            if (dist < l1) { l2 = l1; l1 = dist; k1 = ((unsigned)dist << 20) | (unsigned)(j - b0); }
+            else if (dist < l2) l2 = dist;
+        }
+        const unsigned kbest = wave_min_u32(k1);
+        if (kbest == 0xFFFFFFFFu) continue;
+        const int best1 = (int)(kbest >> 20);
+        // second smallest of the multiset: the owner of the winner contributes its own runner-up
+        const unsigned second = wave_min_u32((unsigned)(k1 == kbest ? l2 : l1));
+        const int best2 = (int)second;
+        const bool ok_dist = MODE == 0 ? best1 <= BOW_TH_LOW : best1 < BOW_TH_LOW;
+        if (ok_dist && (float)best1 < nnratio * (float)best2) {
+            const int idx2 = (int)B.feat[b0 + (int)(kbest & 0xFFFFF)];
+            if (lane == 0) {
+                claimed[idx2] = 1;
+                const int bin = rot_bin(A.angle[idx1], B.angle[idx2]);
+                if (MODE == 0) { match[idx2] = idx1; bins[idx2] = (uint8_t)bin; }
+                else { match[idx1] = idx2; bins[idx1] = (uint8_t)bin; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
+    }
+}
+
+#define BOW_ROWCAP 4096
+
+#ifdef ORBX_DIAG
+__device__ unsigned long long g_bow_stat[8]; // diagnostic build: [0] table entries, [1] fixpoint rounds, [2] passes, [3] wave-fallback nodes, [4] workgroups, [5] rows
+extern "C" int orbx_diag_bow_stats(unsigned long long *out, int reset)
+{
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bow_stat), sizeof(unsigned long long) * 8));
+    if (reset) { unsigned long long z[8] = { 0 }; ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bow_stat), z, sizeof z)); }
+    return ORBX_OK;
+}
+#define BOW_STAT(i, v) do { if (tid == 0) atomicAdd(&g_bow_stat[i], (unsigned long long)(v)); } while (0)
+#else
+#define BOW_STAT(i, v) do { } while (0)
+#endif
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a, const DevFeat *__restrict__ sides_b,
+                                            int b_shared, float nnratio, int check_ori, int32_t *__restrict__ match_out,
+                                            int match_stride, int *__restrict__ nmatches)
 {
     __shared__ int hist[BOW_HISTO];
     __shared__ int keep3[3];
     __shared__ int s_cnt;
+    __shared__ int s_w[4];
+    __shared__ int s_npass, s_nfall;
+    // node tables of the current chunk (compacted: shared nodes only), filled in node order
+    __shared__ int c_aoff[BOW_CHUNK], c_boff[BOW_CHUNK], c_moff[BOW_CHUNK], c_roff[BOW_CHUNK];
+    __shared__ unsigned c_cnt[BOW_CHUNK];            // a_cnt | b_cnt << 16
+    __shared__ unsigned c_inv[BOW_CHUNK];            // ceil(2^32 / b_cnt)
+    __shared__ int pass_first[BOW_CHUNK + 1], pass_total[BOW_CHUNK], pass_rows[BOW_CHUNK];
+    __shared__ int fall_list[BOW_CHUNK];
+    __shared__ uint16_t choice[BOW_ROWCAP];          // per first-side row of the pass: chosen position in its node or 0xFFFF
     // grid.y = query frame of a batched (KF set) x (frames) search (1 otherwise)
     const int pair = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const DevFeat A = sides_a[pair];
     const DevFeat B = sides_b[b_shared ? frame : pair];
     const int nslots = MODE == 0 ? B.n : A.n;
-    uint8_t *claimed = bow_smem;                 // [B.n]
+    const int mB = B.nnodes ? B.node_off[B.nnodes] : 0; // length of the second side's feature list (<= B.n)
+    uint8_t *claimed = bow_smem;                 // [B.n]   (wave fallback only)
     uint8_t *bins = bow_smem + ((B.n + 15) & ~15); // [nslots]
+    unsigned *own = reinterpret_cast<unsigned *>(bins + ((nslots + 15) & ~15)); // [B.n] earliest row choosing a list position
+    uint16_t *mat = reinterpret_cast<uint16_t *>(own + ((B.n + 3) & ~3));        // [BOW_MATCAP]
     int32_t *match = match_out + ((long long)frame * gridDim.x + pair) * match_stride;
     nmatches += (long long)frame * gridDim.x;
-    const int nwaves = blockDim.x >> 6; // the shared vocabulary nodes are dealt over all waves of the workgroup
-    for (int i = tid; i < B.n; i += blockDim.x) claimed[i] = 0;
-    for (int i = tid; i < nslots; i += blockDim.x) { bins[i] = 255; match[i] = -1; }
+    for (int i = tid; i < B.n; i += 256) claimed[i] = 0;
+    for (int i = tid; i < nslots; i += 256) { bins[i] = 255; match[i] = -1; }
     __syncthreads();
-    for (int ia = wv; ia < A.nnodes; ia += nwaves) {
-        const int ib = find_node(B.node_id, B.nnodes, A.node_id[ia]);
-        if (ib < 0) continue;
-        const int b0 = B.node_off[ib], b1 = B.node_off[ib + 1];
-        for (int i1 = A.node_off[ia]; i1 < A.node_off[ia + 1]; i1++) {
-            const int idx1 = (int)A.feat[i1];
-            if (!A.flag[idx1]) continue;
-            uint32_t da[8];
-            load_desc(A.desc, idx1, da);
-            unsigned k1 = 0xFFFFFFFFu; // dist<<20 | position: first index wins ties (strict <, :229-239)
-            int l1 = 256, l2 = 256;
-            for (int j = b0 + lane; j < b1; j += 64) {
-                const int idx2 = (int)B.feat[j];
-                if (claimed[idx2]) continue;
-                if (MODE == 1 && !B.flag[idx2]) continue;
-                uint32_t db[8];
-                load_desc(B.desc, idx2, db);
-                const int dist = hamming256(da, db);
-                if (dist < l1) { l2 = l1; l1 = dist; k1 = ((unsigned)dist << 20) | (unsigned)(j - b0); }
-                else if (dist < l2) l2 = dist;
-            }
-            const unsigned kbest = wave_min_u32(k1);
-            if (kbest == 0xFFFFFFFFu) continue;
-            const int best1 = (int)(kbest >> 20);
-            // second smallest of the multiset: the owner of the winner contributes its own runner-up
-            const unsigned second = wave_min_u32((unsigned)(k1 == kbest ? l2 : l1));
-            const int best2 = (int)second;
-            const bool ok_dist = MODE == 0 ? best1 <= BOW_TH_LOW : best1 < BOW_TH_LOW;
-            if (ok_dist && (float)best1 < nnratio * (float)best2) {
-                const int idx2 = (int)B.feat[b0 + (int)(kbest & 0xFFFFF)];
-                if (lane == 0) {
-                    claimed[idx2] = 1;
-                    const int bin = rot_bin(A.angle[idx1], B.angle[idx2]);
-                    if (MODE == 0) { match[idx2] = idx1; bins[idx2] = (uint8_t)bin; }
-                    else { match[idx1] = idx2; bins[idx1] = (uint8_t)bin; }
-                }
-                __builtin_amdgcn_wave_barrier();
-                __threadfence_block();
+    for (int base = 0; base < A.nnodes; base += BOW_CHUNK) {
+        // ---- shared nodes of this chunk, compacted in node order
+        const int ia = base + tid;
+        int ao = 0, ac = 0, bo = 0, bc = 0;
+        if (ia < A.nnodes) {
+            const int ib = find_node(B.node_id, B.nnodes, A.node_id[ia]);
+            if (ib >= 0) {
+                ao = A.node_off[ia]; ac = A.node_off[ia + 1] - ao;
+                bo = B.node_off[ib]; bc = B.node_off[ib + 1] - bo;
             }
         }
+        const long long pcl = (long long)ac * bc;
+        const bool shared = pcl > 0;
+        const bool big = shared && (pcl > BOW_MATCAP || ac > BOW_ROWCAP || bc > 0xFFFF);
+        const bool tab = shared && !big;
+        int ncomp, nbig, tot, rows_tot;
+        const int k = block_excl_scan256(tab ? 1 : 0, &ncomp, s_w);
+        const int kb = block_excl_scan256(big ? 1 : 0, &nbig, s_w);
+        const int mo = block_excl_scan256(tab ? (int)pcl : 0, &tot, s_w);
+        const int ro = block_excl_scan256(tab ? ac : 0, &rows_tot, s_w);
+        if (tab) {
+            c_aoff[k] = ao; c_boff[k] = bo; c_cnt[k] = (unsigned)ac | ((unsigned)bc << 16);
+            c_inv[k] = (unsigned)((0x100000000ull + (unsigned)bc - 1) / (unsigned)bc);
+            c_moff[k] = mo; c_roff[k] = ro; // chunk-relative; made pass-relative below when the chunk needs several passes
+        }
+        if (big) fall_list[kb] = ia;
+        __syncthreads();
+        if (tot <= BOW_MATCAP && rows_tot <= BOW_ROWCAP) { // the usual case: one pass, offsets straight from the scans
+            if (tid == 0) {
+                s_npass = ncomp ? 1 : 0; pass_first[0] = 0; pass_first[1] = ncomp; pass_total[0] = tot; pass_rows[0] = rows_tot;
+                s_nfall = nbig;
+            }
+        } else if (tid == 0) {                    // pack the nodes, in order, into passes
+            int np = 0, off = 0, roff = 0;
+            pass_first[0] = 0;
+            for (int q = 0; q < ncomp; q++) {
+                const int an = (int)(c_cnt[q] & 0xFFFF), pc = an * (int)(c_cnt[q] >> 16);
+                if (off + pc > BOW_MATCAP || roff + an > BOW_ROWCAP) {
+                    pass_total[np] = off; pass_rows[np] = roff; np++; pass_first[np] = q; off = 0; roff = 0;
+                }
+                c_moff[q] = off; c_roff[q] = roff;
+                off += pc; roff += an;
+            }
+            pass_total[np] = off; pass_rows[np] = roff; np++; pass_first[np] = ncomp;
+            s_npass = np; s_nfall = nbig;
+        }
+        __syncthreads();
+        const int npass = s_npass, nfall = s_nfall;
+        BOW_STAT(2, npass); BOW_STAT(3, nfall); BOW_STAT(4, base == 0);
+        for (int ps = 0; ps < npass; ps++) {
+            const int q0 = pass_first[ps], q1 = pass_first[ps + 1], total = pass_total[ps], rows = pass_rows[ps];
+            // ---- phase 1: every distance of the pass (4 entries per thread in flight: idx -> flags/descriptors are
+            // two dependent global round trips per entry)
+            for (int e0 = tid; e0 < total; e0 += 4 * 256) {
+                int e[4], idx1[4], idx2[4];
+                bool live[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    e[u] = e0 + 256 * u;
+                    live[u] = e[u] < total;
+                    int lo = q0, hi = q1 - 1;      // last node with c_moff <= e
+                    const int ee = live[u] ? e[u] : 0;
+                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (c_moff[mid] <= ee) lo = mid; else hi = mid - 1; }
+                    const unsigned cnt = c_cnt[lo];
+                    const int r = ee - c_moff[lo], bcn = (int)(cnt >> 16);
+                    int i1 = (int)__umulhi((unsigned)r, c_inv[lo]);
+                    if (bcn == 1) i1 = r;       // 2^32 / 1 does not fit the magic
+                    const int j = r - i1 * bcn;
+                    idx1[u] = (int)A.feat[c_aoff[lo] + i1];
+                    idx2[u] = (int)B.feat[c_boff[lo] + j];
+                }
+                unsigned code[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    uint32_t da[8], db[8];
+                    load_desc(A.desc, idx1[u], da);
+                    load_desc(B.desc, idx2[u], db);
+                    const bool arow = A.flag[idx1[u]] != 0;
+                    const bool bcol = MODE == 1 ? B.flag[idx2[u]] != 0 : true;
+                    code[u] = !arow ? 0xFFFEu : !bcol ? 0xFFFFu : (unsigned)hamming256(da, db);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (live[u]) mat[e[u]] = (uint16_t)code[u];
+            }
+            for (int r = tid; r < rows; r += 256) choice[r] = 0xFFFF;
+            BOW_STAT(0, total); BOW_STAT(5, rows);
+            __syncthreads();
+            // ---- phase 2: the greedy walk as a fixpoint over rows.  choice(r) = best second-side position of row r that no
+            // EARLIER row of its node currently holds (with the runner-up taken over the same candidates), accepted by
+            // the distance / ratio tests.  Row r only depends on rows before it, so iterating all rows in parallel
+            // until nothing changes reproduces the sequential walk (a round per link of the longest conflict chain).
+            for (int round = 0; round <= rows; round++) {
+                for (int i = tid; i < mB; i += 256) own[i] = 0xFFFFFFFFu;
+                __syncthreads();
+                for (int r = tid; r < rows; r += 256) {
+                    const unsigned c = choice[r];
+                    if (c != 0xFFFF) {
+                        int lo = q0, hi = q1 - 1;
+                        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (c_roff[mid] <= r) lo = mid; else hi = mid - 1; }
+                        atomicMin(&own[c_boff[lo] + (int)c], (unsigned)r);
+                    }
+                }
+                __syncthreads();
+                int changed = 0;
+                for (int r = tid; r < rows; r += 256) {
+                    int lo = q0, hi = q1 - 1;
+                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (c_roff[mid] <= r) lo = mid; else hi = mid - 1; }
+                    const int bcn = (int)(c_cnt[lo] >> 16), boff = c_boff[lo];
+                    const uint16_t *row = mat + c_moff[lo] + (r - c_roff[lo]) * bcn;
+                    unsigned nc = 0xFFFF;
+                    if (row[0] != 0xFFFE) {          // A.flag (:205-210 / :606-613)
+                        int best1 = 256, best2 = 256, bj = -1;
+                        for (int j = 0; j < bcn; j++) {
+                            const int d = row[j];
+                            if (d == 0xFFFF || own[boff + j] < (unsigned)r) continue;
+                            if (d < best1) { best2 = best1; best1 = d; bj = j; } // first position wins ties (strict <)
+                            else if (d < best2) best2 = d;
+                        }
+                        const bool ok_dist = MODE == 0 ? best1 <= BOW_TH_LOW : best1 < BOW_TH_LOW;
+                        if (bj >= 0 && ok_dist && (float)best1 < nnratio * (float)best2) nc = (unsigned)bj;
+                    }
+                    if (nc != choice[r]) { choice[r] = (uint16_t)nc; changed = 1; }
+                }
+                BOW_STAT(1, 1);
+                if (!__syncthreads_or(changed)) break;
+            }
+            // ---- results of the pass
+            for (int r = tid; r < rows; r += 256) {
+                const unsigned c = choice[r];
+                if (c == 0xFFFF) continue;
+                int lo = q0, hi = q1 - 1;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (c_roff[mid] <= r) lo = mid; else hi = mid - 1; }
+                const int idx1 = (int)A.feat[c_aoff[lo] + (r - c_roff[lo])], idx2 = (int)B.feat[c_boff[lo] + (int)c];
+                const int bin = rot_bin(A.angle[idx1], B.angle[idx2]);
+                if (MODE == 0) { match[idx2] = idx1; bins[idx2] = (uint8_t)bin; }
+                else { match[idx1] = idx2; bins[idx1] = (uint8_t)bin; }
+            }
+            __syncthreads();
+        }
+        // ---- nodes too large for the table: one wave each, straight from global memory
+        for (int f = wv; f < nfall; f += 4) {
+            const int ja = fall_list[f];
+            const int ib = find_node(B.node_id, B.nnodes, A.node_id[ja]);
+            node_greedy_wave<MODE>(A, B, A.node_off[ja], A.node_off[ja + 1], B.node_off[ib], B.node_off[ib + 1], claimed, bins, match,
+                                   nnratio, lane);
+        }
+        __syncthreads();
     }
+    __threadfence_block();
     __syncthreads();
     histogram_filter(match, bins, nslots, check_ori, hist, keep3, &s_cnt, nmatches + pair);
 }
@@ -375,14 +567,14 @@ static int bow_run(int mode, int device, const orbx_featset *as, int na, const o
     const DevFeat *dA = (const DevFeat *)c->d_blob, *dB = dA + na;
     int32_t *d_match = c->d_out;
     int *d_n = c->d_out + (size_t)na * (stride > 0 ? stride : 1);
-    const size_t lds = (size_t)((max_b + 15) & ~15) + (size_t)((max_slots + 15) & ~15) + 16;
+    const size_t lds = (size_t)((max_b + 15) & ~15) + (size_t)((max_slots + 15) & ~15) + 4 * (size_t)((max_b + 3) & ~3) + 16 + 2 * BOW_MATCAP;
     if (lds > 150 * 1024) { orbx_set_error("feature sets too large for LDS"); return ORBX_E_INVALID; }
     if (mode == 0) {
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_bow<0>, dim3(na), dim3(1024), lds, c->stream, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
+        hipLaunchKernelGGL(k_bow<0>, dim3(na), dim3(256), lds, c->stream, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
     } else {
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_bow<1>, dim3(na), dim3(1024), lds, c->stream, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
+        hipLaunchKernelGGL(k_bow<1>, dim3(na), dim3(256), lds, c->stream, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
     }
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipMemcpyAsync(c->h_out, c->d_out, out_ints * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -479,12 +671,12 @@ extern "C" int orbx_bowdb_search(orbx_bowdb *db, const orbx_featset *f, float nn
     size_t off = a16(sizeof(DevFeat));
     feat_pack(f, 0, db->h_f, db->d_f, &off, hd);
     ORBX_HIP(hipMemcpyAsync(db->d_f, db->h_f, off, hipMemcpyHostToDevice, db->stream));
-    const size_t lds = (size_t)((f->n + 15) & ~15) * 2 + 16;
+    const size_t lds = (size_t)((f->n + 15) & ~15) * 2 + 4 * (size_t)((f->n + 3) & ~3) + 16 + 2 * BOW_MATCAP;
     if (lds > 150 * 1024) { orbx_set_error("feature set too large for LDS"); return ORBX_E_INVALID; }
     ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int32_t *d_match = db->d_out;
     int *d_n = db->d_out + (size_t)db->nkf * stride;
-    hipLaunchKernelGGL(k_bow<0>, dim3(db->nkf), dim3(1024), lds, db->stream, (const DevFeat *)db->d_blob, (const DevFeat *)db->d_f, 1,
+    hipLaunchKernelGGL(k_bow<0>, dim3(db->nkf), dim3(256), lds, db->stream, (const DevFeat *)db->d_blob, (const DevFeat *)db->d_f, 1,
                        nnratio, check_orientation, d_match, f->n, d_n);
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipMemcpyAsync(db->h_out, db->d_out, out_ints * sizeof(int32_t), hipMemcpyDeviceToHost, db->stream));
@@ -504,10 +696,10 @@ extern "C" int orbx_bowdb_search_batch_device(orbx_bowdb *db, const orbx_bow_fra
         return ORBX_E_INVALID;
     }
     ORBX_HIP(hipSetDevice(db->device));
-    const size_t lds = (size_t)((fr->cap + 15) & ~15) * 2 + 16;
+    const size_t lds = (size_t)((fr->cap + 15) & ~15) * 2 + 4 * (size_t)((fr->cap + 3) & ~3) + 16 + 2 * BOW_MATCAP;
     if (lds > 150 * 1024) { orbx_set_error("feature set too large for LDS"); return ORBX_E_INVALID; }
     ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_bow<0>, dim3(db->nkf, batch), dim3(1024), lds, stream ? (hipStream_t)stream : fr->last_stream,
+    hipLaunchKernelGGL(k_bow<0>, dim3(db->nkf, batch), dim3(256), lds, stream ? (hipStream_t)stream : fr->last_stream,
                        (const DevFeat *)db->d_blob, (const DevFeat *)fr->d_feats, 1, nnratio, check_orientation, (int32_t *)d_match,
                        fr->cap, (int *)d_nmatches);
     ORBX_HIP(hipGetLastError());
