@@ -9,6 +9,7 @@
 // wave min-reductions for best / second best.  Rotation histogram + ComputeThreeMaxima run once
 // per pair in LDS.
 #include "orbx_device.h"
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -140,6 +141,39 @@ __device__ void node_greedy_wave(const DevFeat &A, const DevFeat &B, int a0, int
             __threadfence_block();
         }
     }
+}
+
+// Latency form: one 1024-thread workgroup per pair, the shared nodes dealt over its 16 waves, each node walked by a
+// wave straight from global memory (node_greedy_wave).  Used when a call has too few pairs to fill the GPU (a single
+// query against a keyframe set: 123 us for 500 keyframes); the table kernel below is the throughput form.
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_bow_wave(const DevFeat *__restrict__ sides_a, const DevFeat *__restrict__ sides_b,
+                                                  int b_shared, float nnratio, int check_ori, int32_t *__restrict__ match_out,
+                                                  int match_stride, int *__restrict__ nmatches)
+{
+    __shared__ int hist[BOW_HISTO];
+    __shared__ int keep3[3];
+    __shared__ int s_cnt;
+    const int pair = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const DevFeat A = sides_a[pair];
+    const DevFeat B = sides_b[b_shared ? frame : pair];
+    const int nslots = MODE == 0 ? B.n : A.n;
+    uint8_t *claimed = bow_smem;                 // [B.n]
+    uint8_t *bins = bow_smem + ((B.n + 15) & ~15); // [nslots]
+    int32_t *match = match_out + ((long long)frame * gridDim.x + pair) * match_stride;
+    nmatches += (long long)frame * gridDim.x;
+    const int nwaves = blockDim.x >> 6;
+    for (int i = tid; i < B.n; i += blockDim.x) claimed[i] = 0;
+    for (int i = tid; i < nslots; i += blockDim.x) { bins[i] = 255; match[i] = -1; }
+    __syncthreads();
+    for (int ia = wv; ia < A.nnodes; ia += nwaves) {
+        const int ib = find_node(B.node_id, B.nnodes, A.node_id[ia]);
+        if (ib < 0) continue;
+        node_greedy_wave<MODE>(A, B, A.node_off[ia], A.node_off[ia + 1], B.node_off[ib], B.node_off[ib + 1], claimed, bins, match,
+                               nnratio, lane);
+    }
+    __syncthreads();
+    histogram_filter(match, bins, nslots, check_ori, hist, keep3, &s_cnt, nmatches + pair);
 }
 
 #define BOW_ROWCAP 4096
@@ -426,6 +460,29 @@ __global__ __launch_bounds__(256) void k_triangulation(const DevFeat *__restrict
     if (tid == 0) npairs[0] = total;
 }
 
+
+// pairs < BOW_TABLE_MIN_PAIRS: too few workgroups to fill 256 CUs, the 16-wave latency form is faster per call
+#define BOW_TABLE_MIN_PAIRS 4096
+template <int MODE>
+static int bow_launch(int npairs_x, int nframes_y, int max_b, int max_slots, hipStream_t st, const DevFeat *dA, const DevFeat *dB,
+                      int b_shared, float nnratio, int check_ori, int32_t *d_match, int stride, int *d_n)
+{
+    const size_t base = (size_t)((max_b + 15) & ~15) + (size_t)((max_slots + 15) & ~15) + 16;
+    bool table = (long long)npairs_x * nframes_y >= BOW_TABLE_MIN_PAIRS;
+    if (const char *f = getenv("ORBX_BOW_FORM")) table = f[0] == 't'; // "table" / "wave": lets the parity tests run both forms on small inputs
+    const size_t lds = table ? base + 4 * (size_t)((max_b + 3) & ~3) + 2 * BOW_MATCAP : base;
+    if (lds > 150 * 1024) { orbx_set_error("feature sets too large for LDS"); return ORBX_E_INVALID; }
+    if (table) {
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_bow<MODE>, dim3(npairs_x, nframes_y), dim3(256), lds, st, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
+    } else {
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow_wave<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_bow_wave<MODE>, dim3(npairs_x, nframes_y), dim3(1024), lds, st, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
+    }
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
 // ---------------------------------------------------------------- host side
 
 struct BowCtx {
@@ -567,16 +624,9 @@ static int bow_run(int mode, int device, const orbx_featset *as, int na, const o
     const DevFeat *dA = (const DevFeat *)c->d_blob, *dB = dA + na;
     int32_t *d_match = c->d_out;
     int *d_n = c->d_out + (size_t)na * (stride > 0 ? stride : 1);
-    const size_t lds = (size_t)((max_b + 15) & ~15) + (size_t)((max_slots + 15) & ~15) + 4 * (size_t)((max_b + 3) & ~3) + 16 + 2 * BOW_MATCAP;
-    if (lds > 150 * 1024) { orbx_set_error("feature sets too large for LDS"); return ORBX_E_INVALID; }
-    if (mode == 0) {
-        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_bow<0>, dim3(na), dim3(256), lds, c->stream, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
-    } else {
-        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_bow<1>, dim3(na), dim3(256), lds, c->stream, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
-    }
-    ORBX_HIP(hipGetLastError());
+    rc = mode == 0 ? bow_launch<0>(na, 1, max_b, max_slots, c->stream, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n)
+                   : bow_launch<1>(na, 1, max_b, max_slots, c->stream, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
+    if (rc) return rc;
     ORBX_HIP(hipMemcpyAsync(c->h_out, c->d_out, out_ints * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     ORBX_HIP(hipStreamSynchronize(c->stream));
     for (int i = 0; i < na; i++) {
@@ -671,14 +721,13 @@ extern "C" int orbx_bowdb_search(orbx_bowdb *db, const orbx_featset *f, float nn
     size_t off = a16(sizeof(DevFeat));
     feat_pack(f, 0, db->h_f, db->d_f, &off, hd);
     ORBX_HIP(hipMemcpyAsync(db->d_f, db->h_f, off, hipMemcpyHostToDevice, db->stream));
-    const size_t lds = (size_t)((f->n + 15) & ~15) * 2 + 4 * (size_t)((f->n + 3) & ~3) + 16 + 2 * BOW_MATCAP;
-    if (lds > 150 * 1024) { orbx_set_error("feature set too large for LDS"); return ORBX_E_INVALID; }
-    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int32_t *d_match = db->d_out;
     int *d_n = db->d_out + (size_t)db->nkf * stride;
-    hipLaunchKernelGGL(k_bow<0>, dim3(db->nkf), dim3(256), lds, db->stream, (const DevFeat *)db->d_blob, (const DevFeat *)db->d_f, 1,
-                       nnratio, check_orientation, d_match, f->n, d_n);
-    ORBX_HIP(hipGetLastError());
+    {
+        const int rc = bow_launch<0>(db->nkf, 1, f->n, f->n, db->stream, (const DevFeat *)db->d_blob, (const DevFeat *)db->d_f, 1, nnratio,
+                                     check_orientation, d_match, f->n, d_n);
+        if (rc) return rc;
+    }
     ORBX_HIP(hipMemcpyAsync(db->h_out, db->d_out, out_ints * sizeof(int32_t), hipMemcpyDeviceToHost, db->stream));
     ORBX_HIP(hipStreamSynchronize(db->stream));
     if (f->n) memcpy(match_f, db->h_out, sizeof(int32_t) * (size_t)db->nkf * f->n);
@@ -696,13 +745,9 @@ extern "C" int orbx_bowdb_search_batch_device(orbx_bowdb *db, const orbx_bow_fra
         return ORBX_E_INVALID;
     }
     ORBX_HIP(hipSetDevice(db->device));
-    const size_t lds = (size_t)((fr->cap + 15) & ~15) * 2 + 4 * (size_t)((fr->cap + 3) & ~3) + 16 + 2 * BOW_MATCAP;
-    if (lds > 150 * 1024) { orbx_set_error("feature set too large for LDS"); return ORBX_E_INVALID; }
-    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_bow<0>, dim3(db->nkf, batch), dim3(256), lds, stream ? (hipStream_t)stream : fr->last_stream,
-                       (const DevFeat *)db->d_blob, (const DevFeat *)fr->d_feats, 1, nnratio, check_orientation, (int32_t *)d_match,
-                       fr->cap, (int *)d_nmatches);
-    ORBX_HIP(hipGetLastError());
+    const int rc = bow_launch<0>(db->nkf, batch, fr->cap, fr->cap, stream ? (hipStream_t)stream : fr->last_stream, (const DevFeat *)db->d_blob,
+                                 (const DevFeat *)fr->d_feats, 1, nnratio, check_orientation, (int32_t *)d_match, fr->cap, (int *)d_nmatches);
+    if (rc) return rc;
     return ORBX_OK;
 }
 

@@ -399,3 +399,15 @@ def test_hamming_host(pkg, oracle):
     a = rng.integers(0, 256, (200, 32), dtype=np.uint8); b = rng.integers(0, 256, (200, 32), dtype=np.uint8)
     for i in range(200):
         assert pkg.ORBmatcher.DescriptorDistance(a[i], b[i]) == oracle.hamming(a[i], b[i]) == int(np.unpackbits(a[i] ^ b[i]).sum())
+
+
+@pytest.mark.gpu
+def test_bow_searches_table_form(pkg, oracle, monkeypatch):
+    """the same SearchByBoW parity cases through the throughput form of the kernel (LDS distance table + row fixpoint),
+    which a call only picks by itself from 4096 pairs up (orbx_bow.hip: bow_launch)"""
+    monkeypatch.setenv("ORBX_BOW_FORM", "table")
+    test_search_by_bow_kf_f(pkg, oracle, 0.75, True)
+    test_search_by_bow_kf_f(pkg, oracle, 0.9, False)
+    test_bow_database(pkg, oracle)
+    test_search_by_bow_kf_kf(pkg, oracle)
+    test_bow_edge_cases(pkg, oracle)

@@ -197,14 +197,23 @@ def test_hip_device_resident_bow_chain(pkg, oracle):
     db = pkg.BowDatabase(kfs)
     d_match = torch.full((B, len(kfs), cap), -7, dtype=torch.int32, device="cuda"); d_nm = torch.zeros((B, len(kfs)), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    fr.search(db, B, d_match.data_ptr(), d_nm.data_ptr(), 0.75, True, st)
-    stream.synchronize()
-    m = d_match.cpu().numpy(); nm = d_nm.cpu().numpy()
-    total = 0
-    for i in range(B):
-        for j, kf in enumerate(kfs):
-            exp, en = oracle.search_by_bow_kf_f(kf, frames[i], 0.75, True)
-            assert nm[i, j] == en, (i, j, nm[i, j], en)
-            assert (m[i, j, :n[i]] == exp).all(), (i, j)
-            total += en
-    assert total > 500 and (nm[3] == 0).all()
+    expect = [[oracle.search_by_bow_kf_f(kf, frames[i], 0.75, True) for kf in kfs] for i in range(B)]
+    import os
+    for form in ("table", "wave"):       # the throughput and the latency form of the search kernel (orbx_bow.hip: bow_launch)
+        os.environ["ORBX_BOW_FORM"] = form
+        try:
+            d_match.fill_(-7); d_nm.zero_()
+            torch.cuda.synchronize()
+            fr.search(db, B, d_match.data_ptr(), d_nm.data_ptr(), 0.75, True, st)
+            stream.synchronize()
+        finally:
+            del os.environ["ORBX_BOW_FORM"]
+        m = d_match.cpu().numpy(); nm = d_nm.cpu().numpy()
+        total = 0
+        for i in range(B):
+            for j in range(len(kfs)):
+                exp, en = expect[i][j]
+                assert nm[i, j] == en, (form, i, j, nm[i, j], en)
+                assert (m[i, j, :n[i]] == exp).all(), (form, i, j)
+                total += en
+        assert total > 500 and (nm[3] == 0).all()
