@@ -673,9 +673,9 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
                                              uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap,
                                              unsigned long long umax_packed)
 {
-    constexpr int RP = 48, HP = 40, BP = 40; // LDS pitches: raw bytes, row-pass u16, blurred bytes
+    constexpr int RP = 48, HR = 44, BP = 40; // LDS pitches: raw bytes, row-pass u16 (stored column-major, 44 rows per column), blurred bytes
     __shared__ __align__(16) uint8_t raw[43 * RP + 16];
-    __shared__ __align__(16) uint16_t hb[43 * HP];
+    __shared__ __align__(16) uint16_t hb[40 * HR];
     uint8_t *bl = raw; // the blurred patch overwrites the raw one (dead after the row pass): 5.5 KB per wave, 29 waves/CU
     const int slot = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     int l = 0;
@@ -773,24 +773,37 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
         for (int k = 1; k < 4; k++)
             o[k] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, k), T0,
                                           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, k), T1, 0u, false), false);
-        uint2 st;
-        st.x = o[0] | (o[1] << 16);
-        st.y = o[2] | (o[3] << 16);
-        *reinterpret_cast<uint2 *>(hb + r * HP + 4 * gq) = st;
+        // column-major: the column pass then reads vertically adjacent values as packed pairs
+#pragma unroll
+        for (int k = 0; k < 4; k++) hb[(4 * gq + k) * HR + r] = (uint16_t)o[k];
     }
     __syncthreads();
     DSTAMP(2);
-    // ---- column pass: lane = column, 43 row-pass values slide through registers
+    // ---- column pass: lane = column; its 44 row-pass values arrive as 22 packed pairs (a[2m], a[2m+1]); the pairs at odd
+    // offsets are one v_alignbit each; an output is four v_dot2_u32_u16 against the packed symmetric taps
+    // (g0,g1)(g2,g3)(g2,g1)(g0,0) with the rounding constant as the first accumulator.  Row 43 is padding: it only
+    // ever meets the zero tap.
     if (lane < 37) {
-        unsigned a[43];
+        typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
+        unsigned E[22], O[21];
+        const uint32_t *col = reinterpret_cast<const uint32_t *>(hb + lane * HR);
 #pragma unroll
-        for (int r = 0; r < 43; r++) a[r] = hb[r * HP + lane];
+        for (int m = 0; m < 22; m++) E[m] = col[m];
+#pragma unroll
+        for (int m = 0; m < 21; m++) O[m] = __builtin_amdgcn_alignbit(E[m + 1], E[m], 16);
         const unsigned g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];
+        const u16x2v G01 = __builtin_bit_cast(u16x2v, g0 | (g1 << 16)), G23 = __builtin_bit_cast(u16x2v, g2 | (g3 << 16)),
+                     G21 = __builtin_bit_cast(u16x2v, g2 | (g1 << 16)), G0 = __builtin_bit_cast(u16x2v, g0);
 #pragma unroll
         for (int r = 0; r < 37; r++) {
-            // taps are symmetric (c_gauss[k] == c_gauss[6-k]); sums stay below 2^25
-            const unsigned acc = (a[r] + a[r + 6]) * g0 + (a[r + 1] + a[r + 5]) * g1 + (a[r + 2] + a[r + 4]) * g2 + a[r + 3] * g3;
-            const unsigned v = (acc + (1u << 15)) >> 16;
+            const int m = r >> 1;
+            const unsigned p0 = (r & 1) ? O[m] : E[m], p1 = (r & 1) ? O[m + 1] : E[m + 1], p2 = (r & 1) ? O[m + 2] : E[m + 2],
+                           p3 = (r & 1) ? O[m + 3] : E[m + 3];
+            unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p0), G01, 1u << 15, false); // sums stay below 2^25
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p1), G23, acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p2), G21, acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p3), G0, acc, false);
+            const unsigned v = acc >> 16;
             bl[r * BP + lane] = (uint8_t)(v > 255u ? 255u : v);
         }
     }
