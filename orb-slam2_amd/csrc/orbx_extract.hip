@@ -14,6 +14,7 @@
 
 __constant__ uint32_t c_pat4[256];        // x0 | y0<<8 | x1<<16 | y1<<24, signed bytes (src/ORBextractor.cc:160-418, data)
 __constant__ int c_umax[16];              // src/ORBextractor.cc:510-533
+__constant__ uint4 c_omask[64];           // IC_Angle: per lane (row, half) the byte mask of its 16-pixel window inside the circular patch
 __constant__ int c_gauss[7];              // 8-bit fixed point 7-tap sigma=2 kernel
 
 // ================================================================ K1: pyramid level (E2)
@@ -670,8 +671,7 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
 // compared with one ballot per 64 pairs (computeOrbDescriptor, :116-157).
 __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef pr, const int *__restrict__ lvl_cnt,
                                              const uint32_t *__restrict__ lvl_kp, orbx_keypoint *__restrict__ out_kps,
-                                             uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap,
-                                             unsigned long long umax_packed)
+                                             uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap)
 {
     constexpr int RP = 48, HR = 44, BP = 40; // LDS pitches: raw bytes, row-pass u16 (stored column-major, 44 rows per column), blurred bytes
     __shared__ __align__(16) uint8_t raw[43 * RP + 16];
@@ -694,6 +694,7 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     uint32_t pat4[4];
 #pragma unroll
     for (int jj = 0; jj < 4; jj++) pat4[jj] = c_pat4[lane + 64 * jj];
+    const uint4 omask = c_omask[lane];
     int off = 0, total = 0;
     for (int i = 0; i < g->nlevels; i++) { const int c = lc[i]; if (i < l) off += c; total += c; }
     if (slot == 0 && lane == 0) out_n[b] = total < cap ? total : cap;
@@ -714,19 +715,18 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     if (x >= 21 && x + 21 < L.w && y >= 21 && y + 21 < L.h && x0a + 48 <= pitch && (((uintptr_t)img | (unsigned)pitch) & 3) == 0) {
         const uint8_t *src = img + (long long)(y - 21) * pitch + x0a;
         // all nine loads of a lane are issued before the first one is consumed: a rolled loop waits for every load
-        // before the next is issued (nine dependent global round trips per wave, 41 % of the wave's life)
+        // before the next is issued (nine dependent global round trips per wave, 41 % of the wave's life).
+        // Lane = (row lane/12, dword lane%12) of a 5-row band (60 lanes), band k covers rows 5k..5k+4: one division per
+        // lane instead of one per load, and the LDS offset of band k is an immediate (row pitch = 12 dwords).
+        const int lr = lane / 12, lc = lane - lr * 12;
+        const uint8_t *lsrc = src + (long long)lr * pitch + 4 * lc;
         uint32_t pv[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const int i = lane + 64 * k;
-            const int r = i / 12, c = i - r * 12;
-            if (i < 43 * 12) pv[k] = *reinterpret_cast<const uint32_t *>(src + (long long)r * pitch + 4 * c);
-        }
+        for (int k = 0; k < 9; k++)
+            if (lane < 60 && lr + 5 * k < 43) pv[k] = *reinterpret_cast<const uint32_t *>(lsrc + (long long)(5 * k) * pitch);
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const int i = lane + 64 * k;
-            if (i < 43 * 12) reinterpret_cast<uint32_t *>(raw)[i] = pv[k];
-        }
+        for (int k = 0; k < 9; k++)
+            if (lane < 60 && lr + 5 * k < 43) reinterpret_cast<uint32_t *>(raw)[lane + 60 * k] = pv[k];
     } else { // image edge (BORDER_REFLECT_101 of the cloned level, :1312-1314) or unaligned input
         xo = 0;
         for (int e = lane; e < 43 * 43; e += 64) {
@@ -740,19 +740,21 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     // ---- IC_Angle: lane = (row v+15, half); integer moments, order-independent
     int m10 = 0, m01 = 0;
     if (lane < 62) {
-        // umax (values <= 15) arrives packed in a kernel argument, 4 bits per row: a divergent index into a
-        // __constant__ array is a vector global load, i.e. one more memory round trip on every wave's critical path
-        const int v = (lane >> 1) - 15, dmax = (int)((umax_packed >> (4 * (v < 0 ? -v : v))) & 15);
-        const int u0 = (lane & 1) ? 0 : -dmax, u1 = (lane & 1) ? dmax : -1;
-        const uint8_t *row = raw + (21 + v) * RP + xo + 21 + u0;
-        const int n = u1 - u0 + 1; // <= 16
-        int rs = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) { // unrolled: the 16 LDS reads are in flight together instead of one latency each
-            const int I = k < n ? row[k] : 0;
-            rs += I; m10 += (u0 + k) * I;
-        }
-        m01 = v * rs;
+        // lane = (row v, half): its 16-pixel window (left half u = -16..-1, right half u = 0..15) is five aligned LDS
+        // dwords realigned with v_alignbyte and masked to the circular patch (mask fetched with the first round trip);
+        // sum(I) by v_sad_u8 against 0 and sum(k*I), k = 0..15, by v_dot4_u32_u8 against constant weights
+        const int v = (lane >> 1) - 15, half = lane & 1;
+        const int off = xo + (half ? 21 : 5);     // byte offset of the window in the staged row
+        const uint32_t *d = reinterpret_cast<const uint32_t *>(raw + (21 + v) * RP) + (off >> 2);
+        const unsigned D0 = d[0], D1 = d[1], D2 = d[2], D3 = d[3], D4 = d[4];
+        const int sh = off & 3;
+        const unsigned W0 = __builtin_amdgcn_alignbyte(D1, D0, sh) & omask.x, W1 = __builtin_amdgcn_alignbyte(D2, D1, sh) & omask.y,
+                       W2 = __builtin_amdgcn_alignbyte(D3, D2, sh) & omask.z, W3 = __builtin_amdgcn_alignbyte(D4, D3, sh) & omask.w;
+        const unsigned rs = __builtin_amdgcn_sad_u8(W0, 0u, __builtin_amdgcn_sad_u8(W1, 0u, __builtin_amdgcn_sad_u8(W2, 0u, __builtin_amdgcn_sad_u8(W3, 0u, 0u))));
+        const unsigned pk = __builtin_amdgcn_udot4(W0, 0x03020100u, __builtin_amdgcn_udot4(W1, 0x07060504u,
+                            __builtin_amdgcn_udot4(W2, 0x0B0A0908u, __builtin_amdgcn_udot4(W3, 0x0F0E0D0Cu, 0u, false), false), false), false);
+        m10 = (int)pk - (half ? 0 : 16 * (int)rs);   // u = k - 16 in the left half
+        m01 = v * (int)rs;
     }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
@@ -816,7 +818,6 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     unsigned long long words[4];
 #pragma unroll
     for (int jj = 0; jj < 4; jj++) {
-        const int pi = lane + 64 * jj;
         const uint32_t pw = pat4[jj];
         const float x0 = (float)(signed char)(pw & 0xFF), y0 = (float)(signed char)((pw >> 8) & 0xFF),
                     x1 = (float)(signed char)((pw >> 16) & 0xFF), y1 = (float)(signed char)(pw >> 24);
@@ -1053,6 +1054,19 @@ static int upload_constants(orbx_extractor *e)
                  ((uint32_t)(uint8_t)ORB_PAT_Y1[i] << 24);
     ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pat4), pat, sizeof pat));
     ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), e->umax, sizeof(int) * 16));
+    {   // k_desc's orientation lanes: lane = (row v = lane/2 - 15, half = lane & 1); the left half covers u = -16..-1 and
+        // keeps u >= -umax[|v|], the right half covers u = 0..15 and keeps u <= umax[|v|] (src/ORBextractor.cc:91-108)
+        uint8_t m[64][16];
+        memset(m, 0, sizeof m);
+        for (int lane = 0; lane < 62; lane++) {
+            const int v = (lane >> 1) - 15, d = e->umax[v < 0 ? -v : v];
+            for (int k = 0; k < 16; k++) {
+                const int u = (lane & 1) ? k : k - 16;
+                m[lane][k] = (u >= -d && u <= d) ? 0xFF : 0;
+            }
+        }
+        ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_omask), m, sizeof m));
+    }
     // cv::getGaussianKernel(7, 2, CV_32F) -> 8-bit fixed point
     float cf[7]; double sum = 0; const double scale2x = -0.5 / (2.0 * 2.0);
     for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)exp(scale2x * x * x); sum += cf[i]; }
@@ -1214,10 +1228,8 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
                        e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, lds_pts_cap(G), err_flag);
     orbx_prof_end(e, s);
     orbx_prof_begin(e, ORBX_STAGE_DESC, s);
-    unsigned long long umax_packed = 0;
-    for (int v = 0; v < 16; v++) umax_packed |= (unsigned long long)(e->umax[v] & 15) << (4 * v);
     hipLaunchKernelGGL(k_desc, dim3(G.kp_total, batch), dim3(64), 0, s, e->d_geom, pr, e->d_lvl_cnt, e->d_lvl_kp,
-                       (orbx_keypoint *)d_kps, (uint8_t *)d_desc, (int *)d_n_out, cap, umax_packed);
+                       (orbx_keypoint *)d_kps, (uint8_t *)d_desc, (int *)d_n_out, cap);
     orbx_prof_end(e, s);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;

@@ -75,7 +75,6 @@ __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrR
     const int n_l = nL[p];
     if (il >= n_l) return; // wave-uniform
     const long long ol = (long long)p * cap + il;
-    const orbx_keypoint *kr = kR + (long long)p * cap;
     const uint32_t *dr = dR + (long long)p * cap * 8;
     const orbx_keypoint kp = kL[ol];
     const int level_l = min(max(kp.octave, 0), g->nlevels - 1); // never index the level tables out of range
