@@ -821,8 +821,13 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
         const uint32_t pw = pat4[jj];
         const float x0 = (float)(signed char)(pw & 0xFF), y0 = (float)(signed char)((pw >> 8) & 0xFF),
                     x1 = (float)(signed char)((pw >> 16) & 0xFF), y1 = (float)(signed char)(pw >> 24);
-        const int r0 = dev_cv_round(x0 * bb + y0 * a), q0 = dev_cv_round(x0 * a - y0 * bb);
-        const int r1 = dev_cv_round(x1 * bb + y1 * a), q1 = dev_cv_round(x1 * a - y1 * bb);
+        // (x*b + y*a, x*a - y*b) as two packed fp32 multiplies and one packed add (v_pk_mul_f32 / v_pk_add_f32 round each
+        // component like the scalar forms; y*(-b) == -(y*b) exactly, so the subtraction is unchanged)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 BA = { bb, a }, AnB = { a, -bb };
+        const f32x2 R0 = f32x2{ x0, x0 } * BA + f32x2{ y0, y0 } * AnB, R1 = f32x2{ x1, x1 } * BA + f32x2{ y1, y1 } * AnB;
+        const int r0 = dev_cv_round(R0.x), q0 = dev_cv_round(R0.y);
+        const int r1 = dev_cv_round(R1.x), q1 = dev_cv_round(R1.y);
         const int t0 = bl[(18 + r0) * BP + 18 + q0], t1 = bl[(18 + r1) * BP + 18 + q1];
         words[jj] = __ballot(t0 < t1);
     }
