@@ -253,9 +253,13 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
     const int pitch = rec.level == 0 ? pr.img0_pitch : rec.pitch;
     const uint8_t *img = rec.level == 0 ? pr.img0 + (long long)b * pr.img0_stride
                                         : pr.pyr + (long long)b * pr.pyr_stride + rec.pyr_off;
-    int xo; // tile column of image column ini_x
-    if ((((uintptr_t)img | (unsigned)pitch) & 3) == 0) {
-        xo = ini_x & 3;
+    // The tile is fetched with dword loads that start one byte left of the cell (gfx950 global loads need no alignment),
+    // so the first detectable pixel always sits at tile column 4: every pretest group of four pixels is a whole LDS
+    // dword whatever the cell's position or the caller's pitch, and a 30-px cell is 8 groups per row (4 wave iterations;
+    // with source-aligned loads it was 9 groups = 5 iterations for three alignments out of four).
+    constexpr int xo = 1; // tile column of image column ini_x
+    {
+        struct __attribute__((packed)) U32 { uint32_t v; };
         const int ndw = (tw + xo + 3) >> 2; // <= 17 dwords per row
         const FastDiv fd(ndw);
         const uint8_t *src = img + (long long)ini_y * pitch + (ini_x - xo);
@@ -271,19 +275,13 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 tr[k] = r; tc[k] = c;
-                if (i0 + 64 * k + lane < total) tv[k] = *reinterpret_cast<const uint32_t *>(src + (unsigned)(r * pitch + 4 * c));
+                if (i0 + 64 * k + lane < total) tv[k] = reinterpret_cast<const U32 *>(src + (long long)r * pitch + 4 * c)->v;
                 r += dr; c += dc;
                 if (c >= ndw) { c -= ndw; r++; }
             }
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 if (i0 + 64 * k + lane < total) reinterpret_cast<uint32_t *>(tile + tr[k] * P)[tc[k]] = tv[k];
-        }
-    } else {
-        xo = 0;
-        for (int r = 0; r < th; r++) {
-            const uint8_t *row = img + (long long)(ini_y + r) * pitch + ini_x;
-            for (int c = lane; c < tw; c += 64) tile[r * P + c] = row[c];
         }
     }
     {
@@ -325,11 +323,10 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
                 const unsigned t = __builtin_bit_cast(unsigned, thv - r); // negative halves <=> r > th
                 bits |= (((t >> 15) & 1u) | ((t >> 30) & 2u)) << (2 * h);
             }
-            // keep only pixels inside the detectable columns of a real item
+            // keep only pixels inside the detectable columns of a real item (tc_lo == 4: only the last group is partial)
             const int tc = 4 * gcol;
             unsigned valid = 0xFu;
-            if (tc < tc_lo) valid &= 0xFu << (tc_lo - tc);
-            if (tc + 3 > tc_hi) valid &= 0xFu >> (tc + 3 - tc_hi);
+            if (tc + 3 > tc_hi) valid = 0xFu >> (tc + 3 - tc_hi);
             bits &= (i < nitems) ? valid : 0u;
             const int cnt = __popc(bits);
             // exclusive prefix of cnt (0..4) over the wave from three ballots
