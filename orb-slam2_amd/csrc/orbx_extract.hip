@@ -706,10 +706,12 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     asm volatile("" :: "v"(x), "s"(pitch));
     DSTAMP(5); // prologue: level search, level counts, packed keypoint
 #endif
-    // ---- stage the 43x43 patch; xo = LDS column of patch column 0
-    int xo = (x - 21) & 3;
-    const int x0a = x - 21 - xo;
-    if (x >= 21 && x + 21 < L.w && y >= 21 && y + 21 < L.h && x0a + 48 <= pitch && (((uintptr_t)img | (unsigned)pitch) & 3) == 0) {
+    // ---- stage the 43x43 patch at LDS column 0 of every row (unaligned dword loads: the window phase is a constant,
+    // so the realignment shifts below are immediates and the row pass reads three dwords per item instead of four)
+    constexpr int xo = 0;
+    const int x0a = x - 21;
+    if (x >= 21 && x + 21 < L.w && y >= 21 && y + 21 < L.h && x0a + 48 <= pitch) {
+        struct __attribute__((packed)) U32 { uint32_t v; };
         const uint8_t *src = img + (long long)(y - 21) * pitch + x0a;
         // all nine loads of a lane are issued before the first one is consumed: a rolled loop waits for every load
         // before the next is issued (nine dependent global round trips per wave, 41 % of the wave's life).
@@ -720,12 +722,11 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
         uint32_t pv[9];
 #pragma unroll
         for (int k = 0; k < 9; k++)
-            if (lane < 60 && lr + 5 * k < 43) pv[k] = *reinterpret_cast<const uint32_t *>(lsrc + (long long)(5 * k) * pitch);
+            if (lane < 60 && lr + 5 * k < 43) pv[k] = reinterpret_cast<const U32 *>(lsrc + (long long)(5 * k) * pitch)->v;
 #pragma unroll
         for (int k = 0; k < 9; k++)
             if (lane < 60 && lr + 5 * k < 43) reinterpret_cast<uint32_t *>(raw)[lane + 60 * k] = pv[k];
-    } else { // image edge (BORDER_REFLECT_101 of the cloned level, :1312-1314) or unaligned input
-        xo = 0;
+    } else { // image edge (BORDER_REFLECT_101 of the cloned level, :1312-1314)
         for (int e = lane; e < 43 * 43; e += 64) {
             const int r = e / 43, c = e - r * 43;
             raw[r * RP + c] = img[(long long)reflect101(y - 21 + r, L.h) * pitch + reflect101(x - 21 + c, L.w)];
@@ -763,9 +764,7 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     for (int i = lane; i < 43 * 10; i += 64) {
         const int r = i / 10, gq = i - r * 10;
         const uint32_t *d = reinterpret_cast<const uint32_t *>(raw + r * RP) + gq;
-        const unsigned D0 = d[0], D1 = d[1], D2 = d[2], D3 = d[3];
-        const unsigned W0 = __builtin_amdgcn_alignbyte(D1, D0, xo), W1 = __builtin_amdgcn_alignbyte(D2, D1, xo),
-                       W2 = __builtin_amdgcn_alignbyte(D3, D2, xo);
+        const unsigned W0 = d[0], W1 = d[1], W2 = d[2]; // the 10 bytes an item needs (4 outputs + 6 taps) start dword-aligned
         unsigned o[4];
         o[0] = __builtin_amdgcn_udot4(W0, T0, __builtin_amdgcn_udot4(W1, T1, 0u, false), false);
 #pragma unroll
