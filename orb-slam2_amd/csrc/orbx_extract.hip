@@ -10,7 +10,6 @@
 
 #include <math.h>
 #include <stdio.h>
-#include <stdlib.h>
 #include <string.h>
 
 __constant__ uint32_t c_pat4[256];        // x0 | y0<<8 | x1<<16 | y1<<24, signed bytes (src/ORBextractor.cc:160-418, data)
@@ -224,14 +223,13 @@ __device__ unsigned long long g_desc_stamp[4096 * 8]; // same for k_desc
 // P / SP = LDS pitches of the pixel tile and the score tile: (48, 40) when every cell of the pyramid fits
 // (cells up to 38 px wide), else (72, 64); smaller tiles = more resident waves per CU.
 template <int P, int SP>
-__global__ __launch_bounds__(64, 8) void k_fast(const Geom *__restrict__ g, const CellRec *__restrict__ cells, PyrRef pr,
+__global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const CellRec *__restrict__ cells, PyrRef pr,
                                              int *__restrict__ cell_cnt, uint32_t *__restrict__ cand, int ini_th, int min_th)
 {
     uint8_t *tile = fast_smem;
     uint8_t *sc = fast_smem + g->fast_lds_sc;
     uint16_t *list = reinterpret_cast<uint16_t *>(fast_smem + g->fast_lds_list);
-    unsigned long long *masks = reinterpret_cast<unsigned long long *>(fast_smem); // aliases the tile: it is dead once the scores exist
-    const int list_cap = g->fast_list_cap;
+    unsigned long long *masks = reinterpret_cast<unsigned long long *>(fast_smem + g->fast_lds_mask);
     const int b = blockIdx.y, lane = threadIdx.x;
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8, speed only): remap so that FAST_XG
     // horizontally adjacent cells land on the same XCD (their halos share cache lines in that XCD's L2) while each
@@ -337,31 +335,17 @@ __global__ __launch_bounds__(64, 8) void k_fast(const Geom *__restrict__ g, cons
                       2 * __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0)) +
                       4 * __builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0));
             const int e0 = (py << 6) + (tc - tc_lo); // tc - tc_lo may be negative for the first group
-            const int n_it = __popcll(m0) + 2 * __popcll(m1) + 4 * __popcll(m2);
-            if (nlist + n_it <= list_cap) { // wave-uniform: once the list is full nothing more is stored (dense form below)
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (bits & (1u << j)) list[pos++] = (uint16_t)(e0 + j);
-            }
-            nlist += n_it;
+            for (int j = 0; j < 4; j++)
+                if (bits & (1u << j)) list[pos++] = (uint16_t)(e0 + j);
+            nlist += __popcll(m0) + 2 * __popcll(m1) + 4 * __popcll(m2);
         }
     }
     __syncthreads();
     STAMP(1);
-    // The list holds fast_list_cap entries (sized so that 32 waves fit a CU: the typical cell lists 20 % of its pixels).
-    // A cell whose pretest passes more than that switches to the dense form: every detectable pixel is an entry (the
-    // pretest is only a necessary condition, the full score of a pixel that failed it is 0), same row-major order.
-    const bool dense = nlist > list_cap;
-    const FastDiv fdw(dw);
-    if (dense) nlist = dh * dw;
-    auto entry = [&](int i) -> int {
-        if (!dense) return list[i];
-        const int py = fdw.div(i);
-        return (py << 6) | (i - py * dw);
-    };
     // ---- full score on the compacted pixels (dense lanes); list entries are (py<<6 | px), ascending
     for (int i = lane; i < nlist; i += 64) {
-        const int e = entry(i), py = e >> 6, px = e & 63;
+        const int e = list[i], py = e >> 6, px = e & 63;
         sc[(py + 1) * SP + px + 1] = (uint8_t)fast_score_full<P>(t0 + py * P + px, min_th);
     }
     __syncthreads();
@@ -371,7 +355,7 @@ __global__ __launch_bounds__(64, 8) void k_fast(const Geom *__restrict__ g, cons
     unsigned long long any_ini = 0;
     for (int ch = 0; ch < nchunk; ch++) {
         const int i = ch * 64 + lane;
-        const int e = entry(min(i, nlist - 1)), py = e >> 6, px = e & 63;
+        const int e = list[min(i, nlist - 1)], py = e >> 6, px = e & 63;
         const uint8_t *c = sc + (py + 1) * SP + px + 1;
         const int s = c[0];
         const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)c[-SP - 1], (int)c[-SP])),
@@ -390,7 +374,7 @@ __global__ __launch_bounds__(64, 8) void k_fast(const Geom *__restrict__ g, cons
         const unsigned long long sel = masks[2 * ch + pick];
         if (sel == 0) continue;
         if ((sel >> lane) & 1ull) {
-            const int e = entry(ch * 64 + lane), py = e >> 6, px = e & 63;
+            const int e = list[ch * 64 + lane], py = e >> 6, px = e & 63;
             const int s = sc[(py + 1) * SP + px + 1];
             const int X = ini_x + 3 + px - ORBX_MIN_BORDER, Y = ini_y + 3 + py - ORBX_MIN_BORDER;
             const int o = off + __builtin_amdgcn_mbcnt_hi((unsigned)(sel >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sel, 0));
@@ -983,26 +967,8 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         const int tp = G.fast_small ? 48 : ORBX_TILE_PITCH, sp = G.fast_small ? 40 : ORBX_SCORE_PITCH;
         G.fast_lds_sc = (int)align_up((size_t)max_th * tp + 8, 16);
         G.fast_lds_list = G.fast_lds_sc + (int)align_up((size_t)(max_dh + 2) * sp, 16);
-        // the tile region must also hold the NMS masks (16 B per 64 pixels of the largest cell) that alias it later
-        {
-            const int mask_bytes = 16 * ((max_npx + 63) / 64) + 16;
-            if (G.fast_lds_sc < mask_bytes) {
-                const int grow = (int)align_up((size_t)(mask_bytes - G.fast_lds_sc), 16);
-                G.fast_lds_sc += grow; G.fast_lds_list += grow;
-            }
-        }
-        // candidate list: as many entries as keep a wave's LDS within 5 KB (32 waves per CU), at least a third of the
-        // largest cell; cells that list more switch to the dense form inside the kernel
-        {
-            const int budget = (5 * 1024 - G.fast_lds_list - 16) / 2;
-            int cap_e = budget > max_npx / 3 ? budget : max_npx / 3;
-            if (cap_e > max_npx) cap_e = max_npx;
-            if (cap_e < 64) cap_e = 64;
-            if (const char *ev = getenv("ORBX_FAST_LIST_CAP")) { const int v = atoi(ev); if (v >= 1) cap_e = v < max_npx ? v : max_npx; } // tests: force the dense form
-            G.fast_list_cap = cap_e;
-        }
-        G.fast_lds_mask = 0;
-        G.fast_lds_bytes = G.fast_lds_list + (int)align_up((size_t)G.fast_list_cap * 2 + 16, 16);
+        G.fast_lds_mask = G.fast_lds_list + (int)align_up((size_t)max_npx * 2 + 16, 16);
+        G.fast_lds_bytes = G.fast_lds_mask + 16 * ((max_npx + 63) / 64) + 16;
     }
     // resize tables
     std::vector<int16_t> tabs(tab_units ? tab_units : 1);

@@ -42,7 +42,6 @@ struct Geom {
     int max_cells_level;    // max n_cells over levels
     int max_node_cap;
     int fast_lds_sc, fast_lds_list, fast_lds_mask, fast_lds_bytes; // LDS carve of k_fast
-    int fast_list_cap;      // entries of k_fast's candidate list (cells that list more use the dense form)
     int fast_small;         // 1: k_fast<48,40> (every cell <= 35 px wide), 0: k_fast<72,64>
     LevelGeom lv[ORBX_MAX_LEVELS];
 };

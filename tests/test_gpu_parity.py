@@ -411,13 +411,3 @@ def test_bow_searches_table_form(pkg, oracle, monkeypatch):
     test_bow_database(pkg, oracle)
     test_search_by_bow_kf_kf(pkg, oracle)
     test_bow_edge_cases(pkg, oracle)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("cap", [1, 64, 200])
-def test_extract_fast_dense_form(pkg, oracle, monkeypatch, cap):
-    """k_fast's candidate list is sized for the typical cell; cells that list more pixels switch to the dense form (every
-    detectable pixel is an entry).  A tiny list capacity sends (nearly) every cell down that path: same results."""
-    monkeypatch.setenv("ORBX_FAST_LIST_CAP", str(cap))
-    test_extract_stage_parity(pkg, oracle, 640, 480, 1000, 3)
-    test_extract_stage_parity(pkg, oracle, 1241, 376, 2000, 4)
