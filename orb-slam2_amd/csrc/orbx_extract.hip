@@ -13,7 +13,6 @@
 #include <string.h>
 
 __constant__ uint32_t c_pat4[256];        // x0 | y0<<8 | x1<<16 | y1<<24, signed bytes (src/ORBextractor.cc:160-418, data)
-__constant__ int c_umax[16];              // src/ORBextractor.cc:510-533
 __constant__ uint4 c_omask[64];           // IC_Angle: per lane (row, half) the byte mask of its 16-pixel window inside the circular patch
 __constant__ int c_gauss[7];              // 8-bit fixed point 7-tap sigma=2 kernel
 
@@ -1054,7 +1053,6 @@ static int upload_constants(orbx_extractor *e)
         pat[i] = (uint32_t)(uint8_t)ORB_PAT_X0[i] | ((uint32_t)(uint8_t)ORB_PAT_Y0[i] << 8) | ((uint32_t)(uint8_t)ORB_PAT_X1[i] << 16) |
                  ((uint32_t)(uint8_t)ORB_PAT_Y1[i] << 24);
     ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pat4), pat, sizeof pat));
-    ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), e->umax, sizeof(int) * 16));
     {   // k_desc's orientation lanes: lane = (row v = lane/2 - 15, half = lane & 1); the left half covers u = -16..-1 and
         // keeps u >= -umax[|v|], the right half covers u = 0..15 and keeps u <= umax[|v|] (src/ORBextractor.cc:91-108)
         uint8_t m[64][16];

@@ -411,3 +411,29 @@ def test_bow_searches_table_form(pkg, oracle, monkeypatch):
     test_bow_database(pkg, oracle)
     test_search_by_bow_kf_kf(pkg, oracle)
     test_bow_edge_cases(pkg, oracle)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,off", [(1241, 376, 1), (640, 480, 3), (401, 301, 2)])
+def test_extract_device_unaligned_pitch_and_base(pkg, oracle, w, h, off):
+    """device-resident input with pitch == width (odd) and a base pointer that is not 4-byte aligned: the kernels fetch
+    with unaligned dword loads, so this is the same code path as the aligned case"""
+    import torch
+    B = 2
+    imgs = [synth.image(90 + i, w, h) for i in range(B)]
+    flat = np.zeros(off + B * w * h + 8, np.uint8)
+    for i in range(B):
+        flat[off + i * w * h: off + (i + 1) * w * h] = imgs[i].reshape(-1)
+    d = torch.from_numpy(flat).cuda()
+    ex = pkg.ORBextractor(800, 1.2, 8, 20, 7, device=0, max_size=(w, h), max_batch=B)
+    cap = ex.max_keypoints(w, h)
+    kps = torch.zeros((B, cap, 7), device="cuda"); desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d.data_ptr() + off, w * h, w, B, w, h, kps.data_ptr(), desc.data_ptr(), cap, n.data_ptr(), None)
+    ex.sync()
+    nn = n.cpu().numpy(); kk = kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28); dd = desc.cpu().numpy()
+    orc = oracle.Oracle(800, 1.2, 8, 20, 7)
+    for i in range(B):
+        okps, odesc = orc.extract(imgs[i])
+        assert nn[i] == len(okps) > 100
+        assert kk[i, :nn[i]].tobytes() == okps.tobytes() and dd[i, :nn[i]].tobytes() == odesc.tobytes()
