@@ -10,6 +10,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 __constant__ uint32_t c_pat4[256];        // x0 | y0<<8 | x1<<16 | y1<<24, signed bytes (src/ORBextractor.cc:160-418, data)
@@ -885,13 +886,13 @@ static size_t tree_lds_bytes(const Geom &G, int lds_pts_cap)
     return cap * (4 + 4 + 8 + 8 + 16 + 16 + 4 * 5) + (size_t)((G.max_cells_level + 4) & ~3) * 4 + (size_t)lds_pts_cap * 6 + 64;
 }
 static const size_t kTreeLdsLimit = 150 * 1024;
-// LDS point capacity of k_tree: enough for a level's typical candidate count (P_0/96), bounded so that
+// LDS point capacity of k_tree: about a level's typical candidate count, bounded so that
 // several (level, image) workgroups fit one CU and so that the node tables (76 B per leaf) still fit;
 // levels with more candidates keep their points in the HBM scratch.  < 0: the node tables alone do not fit.
 static int lds_pts_cap(const Geom &G)
 {
-    int c = (G.lv[0].w * G.lv[0].h / 96 + 1023) & ~1023;
-    c = c < 4096 ? 4096 : c > 12288 ? 12288 : c;
+    int c = (G.lv[0].w * G.lv[0].h / 160 + 1023) & ~1023; // P_0/160: measured best at 512 images per launch (1241x376: 3072)
+    c = c < 3072 ? 3072 : c > 12288 ? 12288 : c;
     while (c > 0 && tree_lds_bytes(G, c) > kTreeLdsLimit) c -= 1024;
     if (tree_lds_bytes(G, c) > kTreeLdsLimit) return -1;
     return c;
