@@ -77,3 +77,33 @@ def test_invalid_arguments_rejected(pkg):
         rc = L.orbx_extractor_create(C.byref(h), args[0], args[1], args[2], args[3], args[4], 0, 640, 480, 1)
         assert rc == -1, args
         assert b"invalid" in L.orbx_last_error()
+
+
+def test_no_silent_cpu_fallback_next_rows(pkg):
+    """the rows either side of the path fail the same way without a GPU"""
+    if pkg.lib().orbx_device_count() > 0:
+        pytest.skip("a GPU is present")
+    f32 = np.float32
+    n = 8
+    frame = dict(x=np.linspace(10, 300, n).astype(f32), y=np.linspace(10, 200, n).astype(f32), octave=np.zeros(n, np.int32),
+                 angle=np.zeros(n, f32), u_right=np.full(n, -1, f32), desc=np.zeros((n, 32), np.uint8), occupied=np.zeros(n, np.uint8),
+                 bounds=(0.0, 0.0, 320.0, 240.0))
+    pts = dict(u=frame["x"], v=frame["y"], aux=np.ones(n, f32), level=np.zeros(n, np.int32), angle=np.zeros(n, f32),
+               view_cos=np.ones(n, f32), desc=frame["desc"], valid=np.ones(n, np.uint8), has_obs=np.ones(n, np.uint8))
+    sf = np.array([1.0, 1.2], f32)
+    m = pkg.ORBmatcher(0.75, True)
+    calls = [lambda: m.SearchByProjectionLastFrame(frame, pts, sf, 7.0),
+             lambda: m.SearchByProjectionMapPoints(frame, pts, sf, 3.0),
+             lambda: m.SearchByProjectionKeyFrame(frame, pts, sf, 10.0, 100),
+             lambda: m.SearchByProjectionSim3(frame, pts, sf, 10.0),
+             lambda: m.Fuse(frame, pts, sf, None, 3.0),
+             lambda: m.SearchBySim3(frame, frame, pts, pts, sf, sf, 7.5),
+             lambda: m.SearchForInitialization(frame, frame, np.stack([frame["x"], frame["y"]], 1), 100),
+             lambda: pkg.UndistortKeyPoints(np.zeros((4, 2), f32), 500.0, 500.0, 320.0, 240.0, [0.1, 0.0, 0.0, 0.0]),
+             lambda: pkg.Rectifier((320, 240), np.zeros((240, 320), f32), np.zeros((240, 320), f32)),
+             lambda: pkg.BowFrames(2, 100),
+             lambda: pkg.ComputeDistinctiveDescriptors([np.zeros((3, 32), np.uint8)])]
+    for i, c in enumerate(calls):
+        with pytest.raises(pkg.OrbxError) as ei:
+            c()
+        assert ei.value.code == -4, i
