@@ -96,6 +96,14 @@ int orbx_remap_batch_device(const orbx_rectifier *r, const void *d_src, size_t s
 int orbx_extract_rectified(orbx_extractor *e, const orbx_rectifier *r, const uint8_t *img, int w, int h, size_t stride,
                            orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out, uint8_t *rect_out, size_t rect_stride);
 
+/* One stereo frame in one call (host pointers): both ORBextractor::operator() calls of Frame::Frame(imLeft, imRight, ...)
+ * (src/Frame.cc:82-85, two threads in the reference) and Frame::ComputeStereoMatches (:97, :577-751).  e must have been
+ * created with max_batch >= 2.  kps[2*cap] / desc[2*cap*32]: left eye at index 0, right eye at index cap; n_out[2];
+ * u_right[cap], depth[cap] = mvuRight, mvDepth of the left keypoints.  bf = mbf, min_z = mb (see orbx_stereo_match). */
+int orbx_extract_stereo(orbx_extractor *e, const uint8_t *img_left, const uint8_t *img_right, int w, int h, size_t stride,
+                        float bf, float min_z, orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out,
+                        float *u_right, float *depth);
+
 /* B images of one size in one pass (host pointers). kps[B*cap], desc[B*cap*32], n_out[B]. */
 int orbx_extract_batch(orbx_extractor *e, const uint8_t *const *imgs, int batch, int w, int h, size_t stride,
                        orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out);

@@ -1431,6 +1431,65 @@ extern "C" int orbx_extract_rectified(orbx_extractor *e, const orbx_rectifier *r
     return ORBX_OK;
 }
 
+// One stereo frame through host pointers in one call: what Frame::Frame(imLeft, imRight, ...) does with two ExtractORB
+// threads and ComputeStereoMatches (src/Frame.cc:82-97): both eyes in one H2D copy and one batch-of-2 extraction, the
+// stereo matcher on the still device-resident keypoints, everything back in one group of copies behind ONE
+// synchronisation (the separate calls cost three synchronisations and an extra round trip of both eyes' features).
+extern "C" int orbx_extract_stereo(orbx_extractor *e, const uint8_t *img_left, const uint8_t *img_right, int w, int h, size_t stride,
+                                   float bf, float min_z, orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out,
+                                   float *u_right, float *depth)
+{
+    if (!e || !img_left || !img_right || !kps || !desc || !n_out || !u_right || !depth || w < 1 || h < 1 || stride < (size_t)w ||
+        !(min_z > 0)) {
+        orbx_set_error("orbx_extract_stereo: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    if (e->max_batch < 2) { orbx_set_error("orbx_extract_stereo needs an extractor created with max_batch >= 2"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipSetDevice(e->device));
+    int rc = orbx_prepare_geometry(e, w, h);
+    if (rc) return rc;
+    const int need = e->geom.kp_total;
+    if (cap < need) { orbx_set_error("keypoint capacity %d < orbx_max_keypoints() = %d", cap, need); return ORBX_E_CAPACITY; }
+    const size_t pitch = align_up(w, 64), img_bytes = pitch * h;
+    if ((rc = ensure(&e->d_stage_in, &e->stage_in_cap, img_bytes * e->max_batch))) return rc;
+    if ((rc = ensure_pinned(&e->h_stage_in, &e->h_stage_in_cap, img_bytes * e->max_batch))) return rc;
+    if ((rc = orbx_ensure_out_staging(e, e->max_batch, need))) return rc;
+    const size_t o_kps = 64, o_desc = o_kps + align_up(sizeof(orbx_keypoint) * (size_t)need * 2, 64), o_ur = o_desc + (size_t)64 * need,
+                 o_z = o_ur + align_up(4 * (size_t)need, 64), out_bytes = o_z + align_up(4 * (size_t)need, 64);
+    if ((rc = ensure_pinned(&e->h_out, &e->h_out_cap, out_bytes))) return rc;
+    const uint8_t *eyes[2] = { img_left, img_right };
+    for (int i = 0; i < 2; i++) {
+        uint8_t *dst = e->h_stage_in + img_bytes * i;
+        for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * pitch, eyes[i] + (size_t)y * stride, (size_t)w);
+    }
+    ORBX_HIP(hipMemcpyAsync(e->d_stage_in, e->h_stage_in, img_bytes * 2, hipMemcpyHostToDevice, e->stream));
+    e->prof_chain = false;
+    rc = orbx_extract_batch_device(e, e->d_stage_in, img_bytes, pitch, 2, w, h, e->d_out_kps, e->d_out_desc, need, e->d_out_n, nullptr);
+    if (rc) return rc;
+    orbx_keypoint *dk = (orbx_keypoint *)e->d_out_kps;
+    uint8_t *dd = (uint8_t *)e->d_out_desc;
+    int *dn = (int *)e->d_out_n;
+    rc = orbx_stereo_match_batch_device(e, 0, e, 1, 1, dk, dd, dn, dk + need, dd + (size_t)32 * need, dn + 1, need, bf, min_z,
+                                        e->d_out_ur, e->d_out_depth, nullptr);
+    if (rc) return rc;
+    ORBX_HIP(hipMemcpyAsync(e->h_out, dn, sizeof(int) * 2, hipMemcpyDeviceToHost, e->stream));
+    ORBX_HIP(hipMemcpyAsync(e->h_out + o_kps, dk, sizeof(orbx_keypoint) * (size_t)need * 2, hipMemcpyDeviceToHost, e->stream));
+    ORBX_HIP(hipMemcpyAsync(e->h_out + o_desc, dd, (size_t)64 * need, hipMemcpyDeviceToHost, e->stream));
+    ORBX_HIP(hipMemcpyAsync(e->h_out + o_ur, e->d_out_ur, 4 * (size_t)need, hipMemcpyDeviceToHost, e->stream));
+    ORBX_HIP(hipMemcpyAsync(e->h_out + o_z, e->d_out_depth, 4 * (size_t)need, hipMemcpyDeviceToHost, e->stream));
+    rc = orbx_sync(e, nullptr);
+    if (rc) return rc;
+    const int *hn = reinterpret_cast<const int *>(e->h_out);
+    for (int i = 0; i < 2; i++) {
+        n_out[i] = hn[i];
+        memcpy(kps + (size_t)i * cap, e->h_out + o_kps + sizeof(orbx_keypoint) * (size_t)need * i, sizeof(orbx_keypoint) * (size_t)hn[i]);
+        memcpy(desc + (size_t)i * cap * 32, e->h_out + o_desc + (size_t)32 * need * i, (size_t)32 * hn[i]);
+    }
+    memcpy(u_right, e->h_out + o_ur, 4 * (size_t)hn[0]);
+    memcpy(depth, e->h_out + o_z, 4 * (size_t)hn[0]);
+    return ORBX_OK;
+}
+
 extern "C" int orbx_extract(orbx_extractor *e, const uint8_t *img, int w, int h, size_t stride,
                             orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out)
 {

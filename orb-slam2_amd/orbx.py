@@ -67,6 +67,7 @@ def lib():
     L.orbx_get_features_per_level.argtypes = [vp, vp]
     L.orbx_max_keypoints.argtypes = [vp, i, i]
     L.orbx_extract.argtypes = [vp, vp, i, i, sz, vp, vp, i, ip]
+    L.orbx_extract_stereo.argtypes = [vp, vp, vp, i, i, sz, f, f, vp, vp, i, vp, vp, vp]
     L.orbx_extract_color.argtypes = [vp, vp, i, i, sz, i, i, vp, vp, i, ip, vp, sz]
     L.orbx_extract_batch.argtypes = [vp, vp, i, i, i, sz, vp, vp, i, vp]
     L.orbx_extract_batch_device.argtypes = [vp, vp, sz, sz, i, i, i, vp, vp, i, vp, vp]
@@ -210,6 +211,19 @@ class ORBextractor:
         kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int()
         _check(self._L.orbx_extract(self._h, _p(image), w, h, image.strides[0], _p(kps), _p(desc), cap, C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_stereo(self, imLeft, imRight, bf, min_z):
+        """one stereo frame in one call: both eyes' operator() + Frame::ComputeStereoMatches (reference src/Frame.cc:82-97)
+        -> (kpsL, descL, kpsR, descR, uRight, depth); the extractor needs max_batch >= 2"""
+        L_ = np.ascontiguousarray(imLeft, np.uint8); R_ = np.ascontiguousarray(imRight, np.uint8)
+        if L_.shape != R_.shape or L_.ndim != 2:
+            raise OrbxError(-1, "left and right image must be equal 2-D uint8 arrays")
+        h, w = L_.shape
+        cap = self.max_keypoints(w, h)
+        kps = np.zeros((2, cap), KP_DTYPE); desc = np.zeros((2, cap, 32), np.uint8); n = np.zeros(2, np.int32)
+        ur = np.zeros(cap, np.float32); z = np.zeros(cap, np.float32)
+        _check(self._L.orbx_extract_stereo(self._h, _p(L_), _p(R_), w, h, L_.strides[0], bf, min_z, _p(kps), _p(desc), cap, _p(n), _p(ur), _p(z)))
+        return (kps[0, :n[0]].copy(), desc[0, :n[0]].copy(), kps[1, :n[1]].copy(), desc[1, :n[1]].copy(), ur[:n[0]].copy(), z[:n[0]].copy())
 
     def extract_color(self, image, rgb=True, want_gray=False):
         """colour frame (H x W x 3|4 uint8): cvtColor to grey on device (Tracking::GrabImage*, src/Tracking.cc:177-202), then operator()"""

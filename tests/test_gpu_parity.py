@@ -437,3 +437,20 @@ def test_extract_device_unaligned_pitch_and_base(pkg, oracle, w, h, off):
         okps, odesc = orc.extract(imgs[i])
         assert nn[i] == len(okps) > 100
         assert kk[i, :nn[i]].tobytes() == okps.tobytes() and dd[i, :nn[i]].tobytes() == odesc.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,w,h,nf", [(63, 1241, 376, 1000), (64, 752, 480, 1200)])
+def test_extract_stereo_single_call(pkg, oracle, seed, w, h, nf):
+    """orbx_extract_stereo = both eyes' operator() + ComputeStereoMatches of Frame::Frame (src/Frame.cc:82-97) in one call"""
+    left, right, _ = synth.stereo_pair(seed, w, h)
+    bf, b = 386.1448, 386.1448 / 718.856
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7, device=0, max_size=(w, h), max_batch=2)
+    kL, dL, kR, dR, ur, dp = ex.extract_stereo(left, right, bf, b)
+    oL, oR = oracle.Oracle(nf, 1.2, 8, 20, 7), oracle.Oracle(nf, 1.2, 8, 20, 7)
+    okL, odL = oL.extract(left); okR, odR = oR.extract(right)
+    assert kL.tobytes() == okL.tobytes() and kR.tobytes() == okR.tobytes() and dL.tobytes() == odL.tobytes() and dR.tobytes() == odR.tobytes()
+    our, odp = oracle.stereo_match(oL, oR, okL, odL, okR, odR, bf, b)
+    assert ur.tobytes() == our.tobytes() and dp.tobytes() == odp.tobytes() and (ur >= 0).sum() > 50
+    with pytest.raises(pkg.OrbxError):
+        pkg.ORBextractor(nf, 1.2, 8, 20, 7, device=0, max_size=(w, h), max_batch=1).extract_stereo(left, right, bf, b)

@@ -32,3 +32,15 @@ for _ in range(200):
     t=time.perf_counter(); st(); ts.append(time.perf_counter()-t)
 ts=np.array(ts)*1e6
 print("orbx_stereo_match host API: median %.1f us  p95 %.1f us  matches %d" % (np.median(ts), np.percentile(ts,95), (ur>=0).sum()))
+# one-call stereo frame
+ex2 = pkg.ORBextractor(1000,1.2,8,20,7,device=0,max_size=(W,H),max_batch=2)
+cap2 = ex2.max_keypoints(W,H)
+k2 = np.zeros((2,cap2), pkg.KP_DTYPE); d2 = np.zeros((2,cap2,32),np.uint8); n2 = np.zeros(2,np.int32); u2 = np.zeros(cap2,np.float32); z2 = np.zeros(cap2,np.float32)
+def st1():
+    rc = L.orbx_extract_stereo(ex2._h, L_.ctypes.data, R_.ctypes.data, W, H, L_.strides[0], C.c_float(386.1448), C.c_float(0.5372), k2.ctypes.data, d2.ctypes.data, cap2, n2.ctypes.data, u2.ctypes.data, z2.ctypes.data); assert rc == 0
+for _ in range(20): st1()
+ts=[]
+for _ in range(300):
+    t=time.perf_counter(); st1(); ts.append(time.perf_counter()-t)
+ts=np.array(ts)*1e6
+print("orbx_extract_stereo (one call per stereo frame): median %.1f us  p95 %.1f us  kpL %d kpR %d matches %d" % (np.median(ts), np.percentile(ts,95), n2[0], n2[1], (u2[:n2[0]]>=0).sum()))
