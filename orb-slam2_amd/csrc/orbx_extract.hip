@@ -262,26 +262,24 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
         struct __attribute__((packed)) U32 { uint32_t v; };
         const int ndw = (tw + xo + 3) >> 2; // <= 17 dwords per row
         const FastDiv fd(ndw);
-        const uint8_t *src = img + (long long)ini_y * pitch + (ini_x - xo);
-        // (r, c) of element i = lane + 64k advances by (64 / ndw, 64 % ndw) with carry: no per-element division
-        int r = fd.div(lane), c = lane - r * ndw;
-        const int dr = fd.div(64), dc = 64 - dr * ndw;
-        // loads go out in batches of eight before any is consumed (a rolled load/store loop is one global round trip
-        // per iteration); a 30-px cell needs one batch, the largest cells of the (72, 64) variant three
-        const int total = th * ndw;
-        for (int i0 = 0; i0 < total; i0 += 8 * 64) {
+        // Lane = (row lr, dword lc) of a band of rpb = 64 / ndw whole rows; band k covers rows k*rpb .. k*rpb + rpb - 1.
+        // The lane part of every address is computed once, a band adds a wave-uniform row offset (scalar): the former
+        // element-wise (r, c) walk cost ~25 VALU instructions per load/store pair.  Loads go out in batches of eight
+        // before any is consumed (a rolled load/store loop is one global round trip per iteration).
+        const int lr = fd.div(lane), lc = lane - lr * ndw;
+        const int rpb = fd.div(64);
+        const bool lane_on = lr < rpb;
+        const uint8_t *lsrc = img + (long long)(ini_y + lr) * pitch + (ini_x - xo) + 4 * lc;
+        uint32_t *ldst = reinterpret_cast<uint32_t *>(tile + lr * P) + lc;
+        const int band_bytes = rpb * pitch, band_dw = rpb * (P / 4);
+        for (int b0 = 0; b0 * rpb < th; b0 += 8) {
             uint32_t tv[8];
-            int tr[8], tc[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                tr[k] = r; tc[k] = c;
-                if (i0 + 64 * k + lane < total) tv[k] = reinterpret_cast<const U32 *>(src + (long long)r * pitch + 4 * c)->v;
-                r += dr; c += dc;
-                if (c >= ndw) { c -= ndw; r++; }
-            }
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                if (i0 + 64 * k + lane < total) reinterpret_cast<uint32_t *>(tile + tr[k] * P)[tc[k]] = tv[k];
+                if (lane_on && (b0 + k) * rpb + lr < th) tv[k] = reinterpret_cast<const U32 *>(lsrc + (long long)(b0 + k) * band_bytes)->v;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (lane_on && (b0 + k) * rpb + lr < th) ldst[(b0 + k) * band_dw] = tv[k];
         }
     }
     {
