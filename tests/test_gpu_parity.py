@@ -454,3 +454,34 @@ def test_extract_stereo_single_call(pkg, oracle, seed, w, h, nf):
     assert ur.tobytes() == our.tobytes() and dp.tobytes() == odp.tobytes() and (ur >= 0).sum() > 50
     with pytest.raises(pkg.OrbxError):
         pkg.ORBextractor(nf, 1.2, 8, 20, 7, device=0, max_size=(w, h), max_batch=1).extract_stereo(left, right, bf, b)
+
+
+@pytest.mark.gpu
+def test_stereo_border_windows(pkg, oracle):
+    """keypoints placed by hand right at the image border: their 11x11 SAD windows leave the level, so k_stereo takes
+    the reflect-101 byte path instead of the dword/LDS path every extractor keypoint takes; same answers as the oracle"""
+    w, h, nf = 752, 480, 800
+    left, right, _ = synth.stereo_pair(66, w, h)
+    exL, exR = _extractor(pkg, nf, w, h), _extractor(pkg, nf, w, h)
+    kL, dL = exL(left); kR, dR = exR(right)
+    oL, oR = oracle.Oracle(nf, 1.2, 8, 20, 7), oracle.Oracle(nf, 1.2, 8, 20, 7)
+    oL.extract(left); oR.extract(right)          # the oracle's SAD stage reads its own pyramids
+    rng = np.random.Generator(np.random.PCG64(67))
+    m = 120
+    kL2, dL2, kR2, dR2 = kL.copy(), dL.copy(), kR.copy(), dR.copy()
+    idx = rng.choice(min(len(kL), len(kR)), m, replace=False)
+    for t, i in enumerate(idx):
+        lvl = int(rng.integers(0, 4)); s = np.float32(1.2) ** lvl
+        lw, lh = int(round(w / float(s))), int(round(h / float(s)))
+        edge = t % 4
+        x = [rng.uniform(13, 17), rng.uniform(lw - 9, lw - 6.5), rng.uniform(40, lw - 40), rng.uniform(40, lw - 40)][edge]
+        y = [rng.uniform(30, lh - 30), rng.uniform(30, lh - 30), rng.uniform(1, 5), rng.uniform(lh - 6, lh - 2)][edge]
+        d = rng.uniform(0.5, 6.0)
+        kL2["x"][i] = np.float32(x * s); kL2["y"][i] = np.float32(y * s); kL2["octave"][i] = lvl
+        kR2["x"][i] = np.float32((x - d) * s); kR2["y"][i] = kL2["y"][i]; kR2["octave"][i] = lvl
+        dR2[i] = dL2[i]                           # identical descriptors: the coarse stage pairs them
+    bf, b = 386.1448, 386.1448 / 718.856
+    ur, dp = pkg.ComputeStereoMatches(exL, exR, kL2, dL2, kR2, dR2, bf, b)
+    our, odp = oracle.stereo_match(oL, oR, kL2, dL2, kR2, dR2, bf, b)
+    assert ur.tobytes() == our.tobytes() and dp.tobytes() == odp.tobytes()
+    assert (our[idx] >= 0).sum() >= 5 or (our >= 0).sum() > 50
