@@ -1012,7 +1012,9 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         }
     }
     if (lds_pts_cap(G) < 0) {
-        orbx_set_error("per-level feature quota %d too large for the quadtree kernel's LDS node tables (limit about 2000 per level)", G.max_node_cap);
+        orbx_set_error("the quadtree kernel's LDS tables do not fit: %d leaves per level x 76 B + %d FAST cells per level x 4 B exceed %zu KB "
+                       "(about 2000 features per level on small images, fewer on very large ones)", G.max_node_cap, G.max_cells_level,
+                       kTreeLdsLimit / 1024);
         return ORBX_E_INVALID;
     }
     ORBX_HIP(hipSetDevice(e->device));
