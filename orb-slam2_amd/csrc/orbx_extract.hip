@@ -756,9 +756,14 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     m01 = wave_sum(m01);
     const float angle = dev_fast_atan2((float)m01, (float)m10);
     DSTAMP(1);
+    // the steering sine / cosine (a long dependent fp64 chain) is computed here, where it can overlap the LDS traffic of the blur
+    const float factor_pi = (float)(3.14159265358979323846 / 180.f);
+    float sn, cs;
+    dev_sincos(angle * factor_pi, &sn, &cs);
     // ---- row pass: 4 outputs per item from 4 aligned dwords, v_dot4_u32_u8 against the packed taps
     const unsigned T0 = (unsigned)c_gauss[0] | ((unsigned)c_gauss[1] << 8) | ((unsigned)c_gauss[2] << 16) | ((unsigned)c_gauss[3] << 24);
     const unsigned T1 = (unsigned)c_gauss[4] | ((unsigned)c_gauss[5] << 8) | ((unsigned)c_gauss[6] << 16);
+#pragma unroll
     for (int i = lane; i < 43 * 10; i += 64) {
         const int r = i / 10, gq = i - r * 10;
         const uint32_t *d = reinterpret_cast<const uint32_t *>(raw + r * RP) + gq;
@@ -805,9 +810,6 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     }
     __syncthreads();
     DSTAMP(3);
-    const float factor_pi = (float)(3.14159265358979323846 / 180.f);
-    float sn, cs;
-    dev_sincos(angle * factor_pi, &sn, &cs);
     const float a = cs, bb = sn;
     unsigned long long words[4];
 #pragma unroll
