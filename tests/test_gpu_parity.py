@@ -103,7 +103,7 @@ def test_random_geometry_sweep(pkg, oracle):
         if orc.features_per_level().max() > 1900:
             # documented limit (Limits): the quadtree's node tables live in LDS (76 B per leaf, ~2000 leaves)
             if orc.features_per_level().max() > 2050:
-                with pytest.raises(pkg.OrbxError, match="too large for the quadtree"):
+                with pytest.raises(pkg.OrbxError, match="quadtree kernel.s LDS tables do not fit"):
                     ex(img)
             continue
         kps, desc = ex(img)
