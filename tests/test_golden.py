@@ -24,7 +24,7 @@ def _featset(z, pre, flag=None):
 
 def test_fixtures_present():
     assert len(EXTRACT) == 3
-    for f in ("stereo_640x480_s104.npz", "bow_s105.npz"):
+    for f in ("stereo_640x480_s104.npz", "bow_s105.npz", "projection_s201.npz", "frontend_s204.npz"):
         assert os.path.exists(os.path.join(GOLD, f))
 
 
@@ -128,3 +128,91 @@ def test_hip_reproduces_stereo_and_bow_fixtures(pkg):
     p = pkg.ORBmatcher(0.6, False).SearchForTriangulation(_featset(b, "kf", b["tri_flag_kf"]), _featset(b, "fr", b["tri_flag_fr"]),
                                                          b["F12"], 300.0, 200.0, b["sf"], b["sig2"])
     assert (p == b["tri_pairs"]).all()
+
+
+# ---------------------------------------------------------------- fixtures of the next rows (f1-f4)
+
+def _group(z, pre):
+    d = {k[len(pre) + 1:]: z[k] for k in z.files if k.startswith(pre + "_")}
+    if "bounds" in d:
+        d["bounds"] = tuple(float(v) for v in d["bounds"])
+    return d
+
+
+def _projection_cases(z, api):
+    """(name, got) pairs; api = the oracle module or a dict of GPU callables with the same signatures"""
+    cur, pts, sf, inv = _group(z, "cur"), _group(z, "pts"), z["sf"], z["inv_s2"]
+    f32 = np.float32
+    for d in (0, 1, 2):
+        yield f"last_{d}", api["last"](cur, pts, sf, 7.0, d, 40.0)
+    p2 = dict(pts); p2["aux"] = (pts["u"] - 5).astype(f32)
+    yield "points", api["points"](cur, p2, sf, 3.0, 0.8)
+    yield "kf", api["kf"](cur, pts, sf, 10.0, 100)
+    yield "sim3p", api["sim3p"](cur, pts, sf, 10.0)
+    yield "sim3", api["sim3"](_group(z, "s1"), _group(z, "s2"), _group(z, "p12"), _group(z, "p21"), sf, 7.5)
+    yield "init", api["init"](_group(z, "i1"), _group(z, "i2"), z["init_prev"], 100, 0.9)
+
+
+def _check_projection(z, api, best):
+    for name, (m, n) in _projection_cases(z, api):
+        assert n == int(z[name + "_n"]) and (np.asarray(m) == z[name + "_m"]).all(), name
+    cur, pts, sf, inv = _group(z, "cur"), _group(z, "pts"), z["sf"], z["inv_s2"]
+    p3 = dict(pts); p3["aux"] = (pts["u"] - 8).astype(np.float32)
+    for chi2 in (0, 1):
+        bi, bd, n = best(cur, p3, sf, inv, 4.0, chi2, 50)
+        assert n == int(z[f"best_{chi2}_n"]) and (bi == z[f"best_{chi2}_idx"]).all() and (bd == z[f"best_{chi2}_dist"]).all(), chi2
+
+
+def test_oracle_reproduces_next_row_fixtures(oracle):
+    z = _load(os.path.join(GOLD, "projection_s201.npz"))
+    O = oracle
+    api = dict(last=lambda c, p, sf, th, d, mbf: O.search_by_projection_last(c, p, sf, th, d, mbf, True),
+               points=lambda c, p, sf, th, r: O.search_by_projection_points(c, p, sf, th, r),
+               kf=lambda c, p, sf, th, od: O.search_by_projection_keyframe(c, p, sf, th, od, True),
+               sim3p=lambda c, p, sf, th: O.search_by_projection_sim3(c, p, sf, th),
+               sim3=lambda a, b, p, q, sf, th: O.search_by_sim3(a, b, p, q, sf, sf, th),
+               init=lambda a, b, prev, win, r: O.search_for_initialization(a, b, prev, win, r, True))
+    _check_projection(z, api, O.window_best)
+    f = _load(os.path.join(GOLD, "frontend_s204.npz"))
+    t = O.Vocabulary(10, 3, f["voc_parent"], f["voc_leaf"], f["voc_desc"], f["voc_weight"]).transform(f["desc"], 1)
+    for k in ("word_id", "node_id", "bow_id", "fv_node_id", "fv_node_off", "fv_feat"):
+        assert (t[k] == f["bow_" + k]).all(), k
+    assert t["bow_val"].tobytes() == f["bow_bow_val"].tobytes() and t["word_weight"].tobytes() == f["bow_word_weight"].tobytes()
+    off = f["obs_off"]
+    assert [O.distinctive_descriptor(f["obs_flat"][off[i]:off[i + 1]]) for i in range(len(off) - 1)] == f["obs_best"].tolist()
+    assert (O.cvt_gray(f["rgb"], 1) == f["gray_rgb"]).all() and (O.cvt_gray(f["rgb"], 0) == f["gray_bgr"]).all()
+    assert (O.remap_bilinear(f["img"], f["map_x"], f["map_y"]) == f["remapped"]).all()
+    c = f["und_cam"]
+    assert O.undistort_points(f["und_xy"], float(c[0]), float(c[1]), float(c[2]), float(c[3]), f["und_dist"]).tobytes() == f["und_out"].tobytes()
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_next_row_fixtures(pkg):
+    """the HIP paths of rows f1-f4 against the committed fixtures: nothing under oracle/ runs in this test"""
+    z = _load(os.path.join(GOLD, "projection_s201.npz"))
+    m = pkg.ORBmatcher(0.8, True); m9 = pkg.ORBmatcher(0.9, True)
+    api = dict(last=lambda c, p, sf, th, d, mbf: m.SearchByProjectionLastFrame(c, p, sf, th, d, mbf),
+               points=lambda c, p, sf, th, r: pkg.ORBmatcher(r, True).SearchByProjectionMapPoints(c, p, sf, th),
+               kf=lambda c, p, sf, th, od: m.SearchByProjectionKeyFrame(c, p, sf, th, od),
+               sim3p=lambda c, p, sf, th: m.SearchByProjectionSim3(c, p, sf, th),
+               sim3=lambda a, b, p, q, sf, th: m.SearchBySim3(a, b, p, q, sf, sf, th),
+               init=lambda a, b, prev, win, r: pkg.ORBmatcher(r, True).SearchForInitialization(a, b, prev, win)[:2])
+    _check_projection(z, api, lambda c, p, sf, inv, th, chi2, md: m.Fuse(c, p, sf, inv if chi2 else None, th, md))
+    f = _load(os.path.join(GOLD, "frontend_s204.npz"))
+    t = pkg.ORBVocabulary(10, 3, f["voc_parent"], f["voc_leaf"], f["voc_desc"], f["voc_weight"]).transform(f["desc"], 1)
+    for k in ("word_id", "node_id", "bow_id", "fv_node_id", "fv_node_off", "fv_feat"):
+        assert (t[k] == f["bow_" + k]).all(), k
+    assert t["bow_val"].tobytes() == f["bow_bow_val"].tobytes()
+    off = f["obs_off"]
+    best = pkg.ComputeDistinctiveDescriptors([f["obs_flat"][off[i]:off[i + 1]] for i in range(len(off) - 1)])
+    assert (best == f["obs_best"]).all()
+    h, w = f["img"].shape
+    ex = pkg.ORBextractor(300, 1.2, 4, 20, 7, device=0, max_size=(w, h))
+    assert (ex.extract_color(f["rgb"], rgb=True, want_gray=True)[2] == f["gray_rgb"]).all()
+    assert (ex.extract_color(f["rgb"], rgb=False, want_gray=True)[2] == f["gray_bgr"]).all()
+    rect = pkg.Rectifier((w, h), f["map_x"], f["map_y"])
+    rh, rw = f["map_x"].shape
+    ex2 = pkg.ORBextractor(300, 1.2, 4, 20, 7, device=0, max_size=(rw, rh))
+    assert (ex2.extract_rectified(rect, f["img"], want_rect=True)[2] == f["remapped"]).all()
+    c = f["und_cam"]
+    assert pkg.UndistortKeyPoints(f["und_xy"], float(c[0]), float(c[1]), float(c[2]), float(c[3]), f["und_dist"]).tobytes() == f["und_out"].tobytes()

@@ -33,6 +33,64 @@ def extract_case(name, img, nf, nlevels=8):
     return o, k, d
 
 
+def next_rows():
+    """the projection-type searches (f1), vocabulary transform (f2), distinctive descriptor (f3),
+    colour / rectification / undistortion front end (f4, f2) on small seeded inputs"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_projection as TP
+    import test_remap as TR
+    f32 = np.float32
+    out = {}
+    cur, pts, sf = TP._scene(201, 600, 500, dense=True)
+    inv_s2 = (1.0 / (sf * sf)).astype(f32)
+    for k_, v in cur.items():
+        out["cur_" + k_] = np.asarray(v)
+    for k_, v in pts.items():
+        out["pts_" + k_] = np.asarray(v)
+    out["sf"] = sf; out["inv_s2"] = inv_s2
+    for d in (0, 1, 2):
+        m, n = O.search_by_projection_last(cur, pts, sf, 7.0, d, 40.0, True)
+        out[f"last_{d}_m"] = m; out[f"last_{d}_n"] = n
+    p2 = dict(pts); p2["aux"] = (pts["u"] - 5).astype(f32)
+    m, n = O.search_by_projection_points(cur, p2, sf, 3.0, 0.8); out["points_m"] = m; out["points_n"] = n
+    m, n = O.search_by_projection_keyframe(cur, pts, sf, 10.0, 100, True); out["kf_m"] = m; out["kf_n"] = n
+    m, n = O.search_by_projection_sim3(cur, pts, sf, 10.0); out["sim3p_m"] = m; out["sim3p_n"] = n
+    p3 = dict(pts); p3["aux"] = (pts["u"] - 8).astype(f32)
+    for chi2 in (0, 1):
+        bi, bd, n = O.window_best(cur, p3, sf, inv_s2, 4.0, chi2, 50)
+        out[f"best_{chi2}_idx"] = bi; out[f"best_{chi2}_dist"] = bd; out[f"best_{chi2}_n"] = n
+    c1, c2, p12, p21, sf2 = TP._sim3_scene(202, 400)
+    for nm, dct in (("s1", c1), ("s2", c2), ("p12", p12), ("p21", p21)):
+        for k_, v in dct.items():
+            out[f"{nm}_{k_}"] = np.asarray(v)
+    m, n = O.search_by_sim3(c1, c2, p12, p21, sf2, sf2, 7.5); out["sim3_m"] = m; out["sim3_n"] = n
+    f1, f2, prev = TP._init_scene(203, 500)
+    for nm, dct in (("i1", f1), ("i2", f2)):
+        for k_, v in dct.items():
+            out[f"{nm}_{k_}"] = np.asarray(v)
+    out["init_prev"] = prev
+    m, n = O.search_for_initialization(f1, f2, prev, 100, 0.9, True); out["init_m"] = m; out["init_n"] = n
+    np.savez_compressed(os.path.join(OUT, "projection_s201.npz"), **out)
+    # f2 / f3 / f4
+    rng = np.random.Generator(np.random.PCG64(204))
+    desc = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    par, leaf, nd, w = synth.vocab_tree(205, 10, 3, stop_frac=0.05, data=desc)
+    t = O.Vocabulary(10, 3, par, leaf, nd, w).transform(desc, 1)
+    obs = [synth.flip_bits(rng, np.repeat(desc[i:i + 1], 3 + i % 9, axis=0), 0.08) for i in range(40)]
+    img = synth.image(206, 200, 150, nshapes=200)
+    rgb = np.stack([img, np.roll(img, 3, 1), np.roll(img, 5, 0)], 2)
+    mx, my = TR._maps(207, 200, 150, 192, 144)
+    xy = np.stack([rng.uniform(0, 640, 200), rng.uniform(0, 480, 200)], 1).astype(f32)
+    cam = (517.306408, 516.469215, 318.643040, 255.313989, np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], f32))
+    np.savez_compressed(os.path.join(OUT, "frontend_s204.npz"), voc_parent=par, voc_leaf=leaf, voc_desc=nd, voc_weight=w, desc=desc,
+                        **{"bow_" + k_: v for k_, v in t.items()},
+                        obs_flat=np.concatenate(obs), obs_off=np.cumsum([0] + [len(o) for o in obs]).astype(np.int32),
+                        obs_best=np.array([O.distinctive_descriptor(o) for o in obs], np.int32),
+                        rgb=rgb, gray_rgb=O.cvt_gray(rgb, 1), gray_bgr=O.cvt_gray(rgb, 0),
+                        img=img, map_x=mx, map_y=my, remapped=O.remap_bilinear(img, mx, my),
+                        und_xy=xy, und_cam=np.array(cam[:4], f32), und_dist=cam[4], und_out=O.undistort_points(xy, *cam[:4], cam[4]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     extract_case("extract_320x240_s101", synth.image(101, 320, 240, nshapes=500), 500)
@@ -69,6 +127,7 @@ def main():
             flat[f"{nm}_{k_}"] = v
     np.savez_compressed(os.path.join(OUT, "bow_s105.npz"), **flat, tri_flag_kf=kf_t["flag"], tri_flag_fr=fr_t["flag"], F12=F12,
                         sf=oL.scale_factors(), sig2=oL.level_sigma2(), m_kf_f=m_kf_f, n_kf_f=n1, m_kf_kf=m_kf_kf, n_kf_kf=n2, tri_pairs=pairs)
+    next_rows()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
