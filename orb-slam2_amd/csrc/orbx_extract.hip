@@ -104,8 +104,9 @@ __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, in
         for (int i = 0; i < 4; i++) {
             const int t0 = r0[o0[i]] * a0[i] + r0[o1[i]] * a1[i];
             const int t1 = r1[o0[i]] * a0[i] + r1[o1[i]] * a1[i];
-            int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
-            v = v < 0 ? 0 : v > 255 ? 255 : v;
+            // the weights are non-negative and each pair sums to 2048 (+-1 by rounding), so v stays inside [0, 255]:
+            // ((2049 * (255 * 2049 >> 4)) >> 16) + 2 >> 2 == 255 -- cv::resize's saturate_cast never fires for INTER_LINEAR
+            const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
             out |= (uint32_t)v << (8 * i);
         }
         *reinterpret_cast<uint32_t *>(dst + (long long)y * D.pitch + x4) = out;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
         const int g_lo = tc_lo >> 2, gpr = (tc_hi >> 2) - g_lo + 1;
         const int nitems = dh * gpr;
         const FastDiv fg(gpr);
-        const i16x2 thv = { (short)min_th, (short)min_th }, zero = { 0, 0 };
+        const i16x2 thv = { (short)min_th, (short)min_th };
         for (int i0 = 0; i0 < nitems; i0 += 64) {
             const int i = i0 + lane, ic = min(i, nitems - 1);
             const int py = fg.div(ic), gcol = g_lo + (ic - py * gpr);
@@ -311,13 +312,13 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
             for (int h = 0; h < 2; h++) {
                 const unsigned sel = h ? 0x0c030c02u : 0x0c010c00u; // bytes (2h, 2h+1) -> two u16
                 const i16x2 c = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, C, sel));
-                const i16x2 dn = c - __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, N, sel));
-                const i16x2 ds = c - __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, S, sel));
-                const i16x2 de = c - __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, Ev, sel));
-                const i16x2 dwv = c - __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, Wv, sel));
-                const i16x2 dk = __builtin_elementwise_min(__builtin_elementwise_max(dn, ds), __builtin_elementwise_max(de, dwv));
-                const i16x2 br = __builtin_elementwise_max(__builtin_elementwise_min(dn, ds), __builtin_elementwise_min(de, dwv));
-                const i16x2 r = __builtin_elementwise_max(dk, zero - br);
+                // with d = c - x: min(max(dN,dS), max(dE,dW)) = c - A, A = max(min(N,S), min(E,W)), and
+                //                 max(min(dN,dS), min(dE,dW)) = c - B, B = min(max(N,S), max(E,W)); r = max(c - A, B - c)
+                const i16x2 n = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, N, sel)), s_ = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, S, sel));
+                const i16x2 e = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, Ev, sel)), w_ = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, Wv, sel));
+                const i16x2 A = __builtin_elementwise_max(__builtin_elementwise_min(n, s_), __builtin_elementwise_min(e, w_));
+                const i16x2 B = __builtin_elementwise_min(__builtin_elementwise_max(n, s_), __builtin_elementwise_max(e, w_));
+                const i16x2 r = __builtin_elementwise_max(c - A, B - c);
                 const unsigned t = __builtin_bit_cast(unsigned, thv - r); // negative halves <=> r > th
                 bits |= (((t >> 15) & 1u) | ((t >> 30) & 2u)) << (2 * h);
             }
