@@ -1,0 +1,53 @@
+"""Long randomized parity soak (not part of the test suite): extraction over random geometries / thresholds / textures,
+stereo on random pairs, against the CPU oracle.  Run on the GPU box: python tools/soak.py [seconds] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import __graft_entry__ as ge
+from tools import synth
+from oracle import oracle_py as O
+pkg = ge.load_pkg()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 else 777))
+t0 = time.time(); n_ok = n_rej = n_st = 0
+trial = 0
+while time.time() - t0 < budget:
+    trial += 1
+    w = int(rng.integers(100, 2000)); h = int(rng.integers(80, 1200))
+    nlevels = int(rng.integers(1, 11)); sf = float(rng.choice([1.05, 1.1, 1.2, 1.2, 1.2, 1.3, 1.5, 1.9]))
+    nf = int(rng.integers(20, 5000)); ini = int(rng.integers(8, 60)); mn = int(rng.integers(2, ini + 1))
+    kind = trial % 5
+    if kind == 0: img = rng.integers(0, 256, (h, w), dtype=np.uint8)                       # white noise: every cell saturates
+    elif kind == 1: img = np.full((h, w), int(rng.integers(0, 256)), np.uint8)            # flat
+    elif kind == 2: img = (np.add.outer(np.arange(h), np.arange(w)) % 256).astype(np.uint8)  # ramps
+    else: img = synth.image(5000 + trial, w, h, nshapes=int(w * h / int(rng.integers(150, 900))) + 20)
+    tag = f"trial {trial}: {w}x{h} nf={nf} L={nlevels} sf={sf} th={ini}/{mn} kind={kind}"
+    try:
+        orc = O.Oracle(nf, sf, nlevels, ini, mn)
+        ok_, od_ = orc.extract(img)
+    except RuntimeError:
+        n_rej += 1; continue
+    try:
+        ex = pkg.ORBextractor(nf, sf, nlevels, ini, mn, device=0, max_size=(w, h), max_batch=2)
+        k, d = ex(img)
+    except pkg.OrbxError as e:
+        # documented limits / deviations: LDS table limit; zero quadtree roots are rejected up front
+        # (the reference only survives them when the level has no FAST candidate at all)
+        if "LDS tables do not fit" in str(e) or "zero quadtree roots" in str(e): n_rej += 1; continue
+        print("GPU rejected", tag, e, flush=True); raise
+    assert len(k) == len(ok_) and k.tobytes() == ok_.tobytes() and d.tobytes() == od_.tobytes(), tag
+    n_ok += 1
+    if kind >= 3 and w >= 200 and h >= 150 and trial % 2 == 0:   # a stereo frame through the one-call API
+        left, right, _ = synth.stereo_pair(7000 + trial, w, h)
+        bf = float(rng.uniform(50, 500)); b = float(rng.uniform(0.05, 1.0))
+        try:
+            oL, oR = O.Oracle(nf, sf, nlevels, ini, mn), O.Oracle(nf, sf, nlevels, ini, mn)
+            okL, odL = oL.extract(left); okR, odR = oR.extract(right)
+        except RuntimeError:
+            continue
+        kL, dL, kR, dR, ur, dp = ex.extract_stereo(left, right, bf, b)
+        our, odp = O.stereo_match(oL, oR, okL, odL, okR, odR, bf, b)
+        assert kL.tobytes() == okL.tobytes() and dR.tobytes() == odR.tobytes() and ur.tobytes() == our.tobytes() and dp.tobytes() == odp.tobytes(), "stereo " + tag
+        n_st += 1
+    if trial % 20 == 0: print(f"{time.time() - t0:6.1f}s trials {trial} ok {n_ok} rejected {n_rej} stereo {n_st}", flush=True)
+print(f"soak done: {trial} trials, {n_ok} bit-exact extractions, {n_st} bit-exact stereo frames, {n_rej} rejected by both sides")
