@@ -98,7 +98,9 @@ extern __shared__ __align__(16) unsigned char bow_smem[];
 //      wave side by side.
 // Nodes are packed into passes of at most BOW_MATCAP table entries; a single node larger than that is walked by a
 // wave straight from global memory (node_greedy_wave, the former kernel body).
-#define BOW_MATCAP 12288
+#ifndef BOW_MATCAP
+#define BOW_MATCAP 4096
+#endif
 #define BOW_CHUNK 256
 
 template <int MODE>
@@ -106,18 +108,18 @@ __device__ void node_greedy_wave(const DevFeat &A, const DevFeat &B, int a0, int
                                  uint8_t *bins, int32_t *match, float nnratio, int lane)
 {
     for (int i1 = a0; i1 < a1; i1++) {
+        if (!A.sflag[i1]) continue;
         const int idx1 = (int)A.feat[i1];
-        if (!A.flag[idx1]) continue;
         uint32_t da[8];
-        load_desc(A.desc, idx1, da);
+        load_desc(A.sdesc, i1, da);
         unsigned k1 = 0xFFFFFFFFu; // dist<<20 | position: first index wins ties (strict <, :229-239)
         int l1 = 256, l2 = 256;
         for (int j = b0 + lane; j < b1; j += 64) {
             const int idx2 = (int)B.feat[j];
             if (claimed[idx2]) continue;
-            if (MODE == 1 && !B.flag[idx2]) continue;
+            if (MODE == 1 && !B.sflag[j]) continue;
             uint32_t db[8];
-            load_desc(B.desc, idx2, db);
+            load_desc(B.sdesc, j, db);
             const int dist = hamming256(da, db);
             if (dist < l1) { l2 = l1; l1 = dist; k1 = ((unsigned)dist << 20) | (unsigned)(j - b0); }
             else if (dist < l2) l2 = dist;
@@ -176,10 +178,12 @@ __global__ __launch_bounds__(1024) void k_bow_wave(const DevFeat *__restrict__ s
     histogram_filter(match, bins, nslots, check_ori, hist, keep3, &s_cnt, nmatches + pair);
 }
 
-#define BOW_ROWCAP 4096
+#ifndef BOW_ROWCAP
+#define BOW_ROWCAP 512
+#endif
 
 #ifdef ORBX_DIAG
-__device__ unsigned long long g_bow_stat[8]; // diagnostic build: [0] table entries, [1] fixpoint rounds, [2] passes, [3] wave-fallback nodes, [4] workgroups, [5] rows
+__device__ unsigned long long g_bow_stat[8]; // diagnostic build: [0] table entries, [1] fixpoint rounds, [2] passes, [3] wave-fallback nodes, [4] workgroups, [5] rows, [6] phase-1 cycles, [7] phase-2 cycles (thread 0)
 extern "C" int orbx_diag_bow_stats(unsigned long long *out, int reset)
 {
     ORBX_HIP(hipDeviceSynchronize());
@@ -206,9 +210,10 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
     __shared__ int c_aoff[BOW_CHUNK], c_boff[BOW_CHUNK], c_moff[BOW_CHUNK], c_roff[BOW_CHUNK];
     __shared__ unsigned c_cnt[BOW_CHUNK];            // a_cnt | b_cnt << 16
     __shared__ unsigned c_inv[BOW_CHUNK];            // ceil(2^32 / b_cnt)
-    __shared__ int pass_first[BOW_CHUNK + 1], pass_total[BOW_CHUNK], pass_rows[BOW_CHUNK];
-    __shared__ int fall_list[BOW_CHUNK];
+    __shared__ uint16_t pass_first[BOW_CHUNK + 1], pass_total[BOW_CHUNK], pass_rows[BOW_CHUNK];
+    __shared__ uint16_t fall_list[BOW_CHUNK];
     __shared__ uint16_t choice[BOW_ROWCAP];          // per first-side row of the pass: chosen position in its node or 0xFFFF
+    __shared__ uint8_t row_node[BOW_ROWCAP];         // per row: its (compacted) node, 0..255 inside the chunk
     // grid.y = query frame of a batched (KF set) x (frames) search (1 otherwise)
     const int pair = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const DevFeat A = sides_a[pair];
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
             c_inv[k] = (unsigned)((0x100000000ull + (unsigned)bc - 1) / (unsigned)bc);
             c_moff[k] = mo; c_roff[k] = ro; // chunk-relative; made pass-relative below when the chunk needs several passes
         }
-        if (big) fall_list[kb] = ia;
+        if (big) fall_list[kb] = (uint16_t)tid; // node index inside the chunk
         __syncthreads();
         if (tot <= BOW_MATCAP && rows_tot <= BOW_ROWCAP) { // the usual case: one pass, offsets straight from the scans
             if (tid == 0) {
@@ -275,10 +280,19 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
         BOW_STAT(2, npass); BOW_STAT(3, nfall); BOW_STAT(4, base == 0);
         for (int ps = 0; ps < npass; ps++) {
             const int q0 = pass_first[ps], q1 = pass_first[ps + 1], total = pass_total[ps], rows = pass_rows[ps];
-            // ---- phase 1: every distance of the pass (4 entries per thread in flight: idx -> flags/descriptors are
-            // two dependent global round trips per entry)
+            // ---- phase 1: every distance of the pass, one (node, a, b) triple per thread, four in flight.  Descriptors and
+            // flags are read from the copies stored in LIST order (sdesc / sflag): the triples of neighbouring lanes touch
+            // neighbouring 32-byte records (4 per cache line) instead of 64 unrelated lines per load instruction, and no
+            // feature index has to be fetched first.
+#ifdef ORBX_DIAG
+            unsigned long long _tb0 = __builtin_amdgcn_s_memtime();
+#endif
+            for (int q = q0 + wv; q < q1; q += 4) { // the node of every row, for phase 2
+                const int acn = (int)(c_cnt[q] & 0xFFFF), rb = c_roff[q];
+                for (int i1 = lane; i1 < acn; i1 += 64) row_node[rb + i1] = (uint8_t)q;
+            }
             for (int e0 = tid; e0 < total; e0 += 4 * 256) {
-                int e[4], idx1[4], idx2[4];
+                int e[4], pa[4], pb[4];
                 bool live[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -291,18 +305,17 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
                     const int r = ee - c_moff[lo], bcn = (int)(cnt >> 16);
                     int i1 = (int)__umulhi((unsigned)r, c_inv[lo]);
                     if (bcn == 1) i1 = r;       // 2^32 / 1 does not fit the magic
-                    const int j = r - i1 * bcn;
-                    idx1[u] = (int)A.feat[c_aoff[lo] + i1];
-                    idx2[u] = (int)B.feat[c_boff[lo] + j];
+                    pa[u] = c_aoff[lo] + i1;
+                    pb[u] = c_boff[lo] + (r - i1 * bcn);
                 }
                 unsigned code[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     uint32_t da[8], db[8];
-                    load_desc(A.desc, idx1[u], da);
-                    load_desc(B.desc, idx2[u], db);
-                    const bool arow = A.flag[idx1[u]] != 0;
-                    const bool bcol = MODE == 1 ? B.flag[idx2[u]] != 0 : true;
+                    load_desc(A.sdesc, pa[u], da);
+                    load_desc(B.sdesc, pb[u], db);
+                    const bool arow = A.sflag[pa[u]] != 0;
+                    const bool bcol = MODE == 1 ? B.sflag[pb[u]] != 0 : true;
                     code[u] = !arow ? 0xFFFEu : !bcol ? 0xFFFFu : (unsigned)hamming256(da, db);
                 }
 #pragma unroll
@@ -312,6 +325,10 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
             for (int r = tid; r < rows; r += 256) choice[r] = 0xFFFF;
             BOW_STAT(0, total); BOW_STAT(5, rows);
             __syncthreads();
+#ifdef ORBX_DIAG
+            unsigned long long _tb1 = __builtin_amdgcn_s_memtime();
+            BOW_STAT(6, _tb1 - _tb0);
+#endif
             // ---- phase 2: the greedy walk as a fixpoint over rows.  choice(r) = best second-side position of row r that no
             // EARLIER row of its node currently holds (with the runner-up taken over the same candidates), accepted by
             // the distance / ratio tests.  Row r only depends on rows before it, so iterating all rows in parallel
@@ -321,17 +338,12 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
                 __syncthreads();
                 for (int r = tid; r < rows; r += 256) {
                     const unsigned c = choice[r];
-                    if (c != 0xFFFF) {
-                        int lo = q0, hi = q1 - 1;
-                        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (c_roff[mid] <= r) lo = mid; else hi = mid - 1; }
-                        atomicMin(&own[c_boff[lo] + (int)c], (unsigned)r);
-                    }
+                    if (c != 0xFFFF) atomicMin(&own[c_boff[row_node[r]] + (int)c], (unsigned)r);
                 }
                 __syncthreads();
                 int changed = 0;
                 for (int r = tid; r < rows; r += 256) {
-                    int lo = q0, hi = q1 - 1;
-                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (c_roff[mid] <= r) lo = mid; else hi = mid - 1; }
+                    const int lo = row_node[r];
                     const int bcn = (int)(c_cnt[lo] >> 16), boff = c_boff[lo];
                     const uint16_t *row = mat + c_moff[lo] + (r - c_roff[lo]) * bcn;
                     unsigned nc = 0xFFFF;
@@ -351,12 +363,14 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
                 BOW_STAT(1, 1);
                 if (!__syncthreads_or(changed)) break;
             }
+#ifdef ORBX_DIAG
+            BOW_STAT(7, __builtin_amdgcn_s_memtime() - _tb1);
+#endif
             // ---- results of the pass
             for (int r = tid; r < rows; r += 256) {
                 const unsigned c = choice[r];
                 if (c == 0xFFFF) continue;
-                int lo = q0, hi = q1 - 1;
-                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (c_roff[mid] <= r) lo = mid; else hi = mid - 1; }
+                const int lo = row_node[r];
                 const int idx1 = (int)A.feat[c_aoff[lo] + (r - c_roff[lo])], idx2 = (int)B.feat[c_boff[lo] + (int)c];
                 const int bin = rot_bin(A.angle[idx1], B.angle[idx2]);
                 if (MODE == 0) { match[idx2] = idx1; bins[idx2] = (uint8_t)bin; }
@@ -366,7 +380,7 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
         }
         // ---- nodes too large for the table: one wave each, straight from global memory
         for (int f = wv; f < nfall; f += 4) {
-            const int ja = fall_list[f];
+            const int ja = base + fall_list[f];
             const int ib = find_node(B.node_id, B.nnodes, A.node_id[ja]);
             node_greedy_wave<MODE>(A, B, A.node_off[ja], A.node_off[ja + 1], B.node_off[ib], B.node_off[ib + 1], claimed, bins, match,
                                    nnratio, lane);
@@ -563,7 +577,7 @@ static size_t feat_bytes(const orbx_featset *f, int geom)
 {
     const size_t m = f->nnodes ? (size_t)f->node_off[f->nnodes] : 0;
     size_t s = a16((size_t)f->n * 32) + a16((size_t)f->nnodes * 4) + a16(((size_t)f->nnodes + 1) * 4) + a16(m * 4) +
-               a16((size_t)f->n) + a16((size_t)f->n * 4);
+               a16((size_t)f->n) + a16((size_t)f->n * 4) + a16(m * 32) + a16(m);
     if (geom) s += 4 * a16((size_t)f->n * 4);
     return s;
 }
@@ -604,6 +618,19 @@ static void feat_pack(const orbx_featset *f, int geom, uint8_t *h, const uint8_t
     }
     d->flag = (const uint8_t *)put(f->flag, (size_t)f->n);
     d->angle = (const float *)put(f->angle, (size_t)f->n * 4);
+    {   // descriptors and flags once more, in list order (see k_bow phase 1)
+        const uint32_t *list = (const uint32_t *)(h + ((const uint8_t *)d->feat - dbase));
+        const int32_t *noff = (const int32_t *)(h + ((const uint8_t *)d->node_off - dbase));
+        const size_t ml = f->nnodes ? (size_t)noff[f->nnodes] : 0;
+        uint8_t *sd = h + *off;
+        d->sdesc = (const uint32_t *)put(nullptr, m * 32);
+        uint8_t *sf = h + *off;
+        d->sflag = (const uint8_t *)put(nullptr, m);
+        for (size_t k = 0; k < ml; k++) {
+            memcpy(sd + 32 * k, f->desc + 32 * (size_t)list[k], 32);
+            sf[k] = f->flag[list[k]];
+        }
+    }
     d->x = d->y = d->u_right = nullptr; d->octave = nullptr;
     if (geom) {
         d->x = (const float *)put(f->x, (size_t)f->n * 4);

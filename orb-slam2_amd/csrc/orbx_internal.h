@@ -111,6 +111,8 @@ struct DevFeat {
     const uint8_t *flag;
     const float *angle, *x, *y, *u_right;
     const int32_t *octave;
+    const uint32_t *sdesc;    // [len(feat)][8] descriptors in list order (desc[feat[k]])
+    const uint8_t *sflag;     // [len(feat)] flags in list order
 };
 
 // device-resident BoW data of a batch of frames (orbx_bow_transform_batch_device -> orbx_bowdb_search_batch_device)
@@ -121,6 +123,7 @@ struct orbx_bow_frames {
     uint32_t *bow_id; double *bow_val; int *counts;             // [batch][cap], [batch][cap], [batch][2] (nbow, nnodes)
     uint32_t *fv_node_id; int32_t *fv_node_off; uint32_t *fv_feat; // [batch][cap], [batch][cap+1 -> stride cap+4], [batch][npad]
     float *angle;                                               // [batch][cap]
+    uint32_t *sdesc; uint8_t *sflag;                            // [batch][npad][8], [batch][npad]: list-order copies
     DevFeat *d_feats;                                           // [batch]
     uint8_t *h_buf; size_t h_cap;                               // pinned staging of orbx_bow_frames_read
     hipStream_t last_stream;                                    // stream of the most recent transform: the default of read / search

@@ -344,11 +344,20 @@ __global__ __launch_bounds__(256) void k_frames_fill(DevFeat *__restrict__ feats
                                                      const uint32_t *__restrict__ desc, const int *__restrict__ n_dev, int cap, int npad,
                                                      const int *__restrict__ counts, const uint32_t *__restrict__ fv_node_id,
                                                      const int32_t *__restrict__ fv_node_off, const uint32_t *__restrict__ fv_feat,
-                                                     float *__restrict__ angle)
+                                                     float *__restrict__ angle, uint32_t *__restrict__ sdesc, uint8_t *__restrict__ sflag)
 {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = min(n_dev[b], cap);
     for (int i = tid; i < n; i += 256) angle[(long long)b * cap + i] = kps[(long long)b * cap + i].angle;
+    {   // descriptors once more in FeatureVector list order (what the search kernel streams through)
+        const int nn = counts[2 * b + 1];
+        const int m = fv_node_off[(long long)b * (cap + 4) + nn];
+        const uint32_t *list = fv_feat + (long long)b * npad;
+        const uint4 *src = reinterpret_cast<const uint4 *>(desc + (long long)b * cap * 8);
+        uint4 *dst = reinterpret_cast<uint4 *>(sdesc + (long long)b * npad * 8);
+        for (int i = tid; i < 2 * m; i += 256) dst[i] = src[2 * (long long)list[i >> 1] + (i & 1)];
+        for (int i = tid; i < m; i += 256) sflag[(long long)b * npad + i] = 1;
+    }
     if (tid == 0) {
         DevFeat f;
         f.n = n; f.nnodes = counts[2 * b + 1];
@@ -358,6 +367,7 @@ __global__ __launch_bounds__(256) void k_frames_fill(DevFeat *__restrict__ feats
         f.feat = fv_feat + (long long)b * npad;
         f.flag = nullptr;                       // the frame side of SearchByBoW(KF, F) has no flag test
         f.angle = angle + (long long)b * cap;
+        f.sdesc = sdesc + (long long)b * npad * 8; f.sflag = sflag + (long long)b * npad;
         f.x = f.y = f.u_right = nullptr; f.octave = nullptr;
         feats[b] = f;
     }
@@ -383,13 +393,14 @@ extern "C" int orbx_bow_frames_create(int device, int max_batch, int cap, orbx_b
     auto take = [&](size_t bytes) { const size_t r = o; o += a16v(bytes); return r; };
     const size_t o_word = take(4 * B * c), o_w = take(8 * B * c), o_nid = take(4 * B * c), o_bid = take(4 * B * c), o_bval = take(8 * B * c),
                  o_cnt = take(8 * B), o_fid = take(4 * B * c), o_foff = take(4 * B * (c + 4)), o_ffeat = take(4 * B * f->npad),
-                 o_ang = take(4 * B * c), o_feats = take(sizeof(DevFeat) * B);
+                 o_ang = take(4 * B * c), o_feats = take(sizeof(DevFeat) * B), o_sd = take(32 * B * f->npad), o_sf = take(B * f->npad);
     if (hipMalloc((void **)&f->d_buf, o) != hipSuccess) { orbx_set_error("orbx_bow_frames_create: hipMalloc of %zu bytes failed", o); delete f; return ORBX_E_HIP; }
     uint8_t *d = f->d_buf;
     f->word_id = (uint32_t *)(d + o_word); f->word_w = (double *)(d + o_w); f->node_id = (uint32_t *)(d + o_nid);
     f->bow_id = (uint32_t *)(d + o_bid); f->bow_val = (double *)(d + o_bval); f->counts = (int *)(d + o_cnt);
     f->fv_node_id = (uint32_t *)(d + o_fid); f->fv_node_off = (int32_t *)(d + o_foff); f->fv_feat = (uint32_t *)(d + o_ffeat);
     f->angle = (float *)(d + o_ang); f->d_feats = (DevFeat *)(d + o_feats);
+    f->sdesc = (uint32_t *)(d + o_sd); f->sflag = d + o_sf;
     *out = f;
     return ORBX_OK;
 }
@@ -422,7 +433,7 @@ extern "C" int orbx_bow_transform_batch_device(orbx_vocab *v, orbx_bow_frames *f
     hipLaunchKernelGGL(k_bow_build, dim3(batch), dim3(256), lds, s, 0, npad, f->word_id, f->word_w, f->node_id, f->bow_id, f->bow_val,
                        f->counts, f->fv_node_id, f->fv_node_off, f->fv_feat, (const int *)d_n, cap);
     hipLaunchKernelGGL(k_frames_fill, dim3(batch), dim3(256), 0, s, f->d_feats, (const orbx_keypoint *)d_kps, (const uint32_t *)d_desc,
-                       (const int *)d_n, cap, npad, f->counts, f->fv_node_id, f->fv_node_off, f->fv_feat, f->angle);
+                       (const int *)d_n, cap, npad, f->counts, f->fv_node_id, f->fv_node_off, f->fv_feat, f->angle, f->sdesc, f->sflag);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
 }

@@ -12,4 +12,5 @@ bench.main()
 out = (C.c_ulonglong * 8)()
 L.orbx_diag_bow_stats(out, 1)
 wg = max(out[4], 1)
+print("phase-1 cycles/wg", out[6] / max(out[4], 1), "phase-2 cycles/wg", out[7] / max(out[4], 1))
 print("workgroups", out[4], "entries/wg", out[0] / wg, "rows/wg", out[5] / wg, "rounds/wg", out[1] / wg, "passes/wg", out[2] / wg, "fallback nodes/wg", out[3] / wg)
