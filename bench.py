@@ -109,10 +109,14 @@ def main():
 
     pkg = ge.load_pkg()
     st = pkg.streams
+    # ORBX_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    rank, world = st.init("nccl", device_id=dev)   # "nccl" is RCCL on ROCm; no-op for a single process
+    rank, world = st.init(backend, device_id=dev if backend == "nccl" else None)   # "nccl" is RCCL on ROCm; no-op for a single process
     assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
 
     pkg.lib()  # fails loudly if liborbx.so is missing: there is no fallback path
@@ -233,7 +237,7 @@ def main():
     ex.profile_read(reset=True)
     prof_on[0] = True
     ex.profile_enable(True)           # HIP events on the launch stream, around every kernel of the timed steps
-    elapsed = st.timed_steps(step, args.steps, local_sync, world, device=dev)   # barrier + sync both sides, MAX over ranks
+    elapsed = st.timed_steps(step, args.steps, local_sync, world, device=dev if backend == "nccl" else None)   # barrier + sync both sides, MAX over ranks
     ex.profile_enable(False)
     prof = ex.profile_read(reset=True)
     ex.sync(sp)
