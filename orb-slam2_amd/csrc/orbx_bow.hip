@@ -568,6 +568,7 @@ static int feat_validate(const orbx_featset *f, int need_geom)
             if (i && f->node_id[i] <= f->node_id[i - 1]) return 0;
         }
         const int m = f->node_off[f->nnodes];
+        if (m > f->n) return 0; // a FeatureVector lists every feature at most once (the kernels size per-position tables by n)
         for (int i = 0; i < m; i++) if (f->feat[i] >= (uint32_t)f->n) return 0; // indices must be in range: the kernel trusts them
     }
     return 1;
