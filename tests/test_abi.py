@@ -107,3 +107,27 @@ def test_no_silent_cpu_fallback_next_rows(pkg):
         with pytest.raises(pkg.OrbxError) as ei:
             c()
         assert ei.value.code == -4, i
+
+
+def _build_c_example(tmpdir):
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    exe = os.path.join(tmpdir, "stereo_frame")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "stereo_frame.c"),
+                           "-L", os.path.join(ROOT, "orb-slam2_amd"), "-lorbx", "-Wl,-rpath," + os.path.join(ROOT, "orb-slam2_amd"), "-o", exe])
+    return exe
+
+
+def test_c_example_compiles_and_links(tmp_path):
+    """a plain C client links against liborbx.so through include/orbx.h alone (no torch, no Python)"""
+    _build_c_example(str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_c_example_runs(tmp_path):
+    import subprocess
+    exe = _build_c_example(str(tmp_path))
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "stereo matches" in out.stdout
