@@ -48,6 +48,24 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// reductions inside each 16-lane row (a quarter wave), result in every lane of the row: butterfly of row rotations
+__device__ __forceinline__ unsigned row16_min_u32(unsigned v)
+{
+    v = min(v, (unsigned)ORBX_DPP(v, v, 0x128, 0xf, 0xf)); // row_ror:8
+    v = min(v, (unsigned)ORBX_DPP(v, v, 0x124, 0xf, 0xf)); // row_ror:4
+    v = min(v, (unsigned)ORBX_DPP(v, v, 0x122, 0xf, 0xf)); // row_ror:2
+    v = min(v, (unsigned)ORBX_DPP(v, v, 0x121, 0xf, 0xf)); // row_ror:1
+    return v;
+}
+__device__ __forceinline__ unsigned row16_or_u32(unsigned v)
+{
+    v |= (unsigned)ORBX_DPP(v, v, 0x128, 0xf, 0xf);
+    v |= (unsigned)ORBX_DPP(v, v, 0x124, 0xf, 0xf);
+    v |= (unsigned)ORBX_DPP(v, v, 0x122, 0xf, 0xf);
+    v |= (unsigned)ORBX_DPP(v, v, 0x121, 0xf, 0xf);
+    return v;
+}
+
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 {
     v = max(v, (unsigned)ORBX_DPP(v, 0, 0x111, 0xf, 0xf));

@@ -68,13 +68,20 @@ __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrR
                                                 float *__restrict__ depth, int *__restrict__ st_dist,
                                                 const int *__restrict__ row_off, const uint2 *__restrict__ entries, int ent_cap)
 {
+    // A wave takes FOUR left keypoints.  Coarse stage: one keypoint per 16-lane row (a row of the table holds ~25
+    // candidates, so a whole wave per keypoint left most lanes idle and paid the dependent load chain
+    // keypoint -> row offsets -> entries -> descriptors once per keypoint); the four chains run side by side and the
+    // minimum / its owner are found with row-local DPP butterflies.  Fine stage: the wave then walks its matched
+    // keypoints (0..4) one at a time with all 64 lanes on the 11x11x11 SAD.
     constexpr int SW_BYTES = 11 * 16 + 11 * 28 + 4; // per wave: left window rows (16 B) + right window rows (28 B)
     __shared__ __align__(16) uint8_t s_win[4 * ((SW_BYTES + 15) & ~15)];
-    const int p = blockIdx.y, lane = threadIdx.x & 63;
-    const int il = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int p = blockIdx.y, lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
+    const int il_base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
     const int n_l = nL[p];
-    if (il >= n_l) return; // wave-uniform
-    const long long ol = (long long)p * cap + il;
+    if (il_base >= n_l) return; // wave-uniform
+    const int il = il_base + sub;
+    const bool have = il < n_l;
+    const long long ol = (long long)p * cap + (have ? il : il_base);
     const uint32_t *dr = dR + (long long)p * cap * 8;
     const orbx_keypoint kp = kL[ol];
     const int level_l = min(max(kp.octave, 0), g->nlevels - 1); // never index the level tables out of range
@@ -82,22 +89,21 @@ __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrR
     const int n_rows = g->lv[0].h;
     const int row = (int)vl;
     const float min_u = ul - max_d, max_u = ul; // minD = 0
-    float out_u = -1.0f, out_z = -1.0f;
-    int out_sad = -1;
-    unsigned best = 0xFFFFFFFFu;
-    float best_x = 0.f; // x of the best right keypoint (uniform after the reduction)
-    if (row >= 0 && row < n_rows && !(max_u < 0)) {
+    const bool active = have && row >= 0 && row < n_rows && !(max_u < 0);
+    unsigned mine = 0xFFFFFFFFu;
+    float mine_x = 0.f;
+    {
         uint32_t a[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) a[i] = dL[ol * 8 + i];
         const int *ro = row_off + (long long)p * (n_rows + 1);
         const uint2 *en = entries + (long long)p * ent_cap;
-        const int e1 = ro[row + 1];
-        unsigned mine = 0xFFFFFFFFu;
-        float mine_x = 0.f;
-        for (int base = ro[row]; base < e1; base += 64) { // right keypoints whose row band holds this row (:622)
-            if (base + lane < e1) {
-                const uint2 ent = en[base + lane];
+        const int rr = active ? row : 0;
+        const int b0 = active ? ro[rr] : 0, e1 = active ? ro[rr + 1] : 0;
+        for (int base = b0; __any(base < e1); base += 16) { // right keypoints whose row band holds this row (:622)
+            const int j = base + sl;
+            if (j < e1) {
+                const uint2 ent = en[j];
                 const int ir = (int)(ent.x & 0xFFFFu), oct = (int)(short)(ent.x >> 16);
                 const float qx = __uint_as_float(ent.y);
                 if (oct >= level_l - 1 && oct <= level_l + 1 && qx >= min_u && qx <= max_u) {
@@ -114,23 +120,32 @@ __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrR
                 }
             }
         }
-        best = wave_min_u32(mine);
-        if (best != 0xFFFFFFFFu) { // the key holds iR, so exactly one lane owns the minimum
-            const unsigned long long own = __ballot(mine == best);
-            best_x = __shfl(mine_x, (int)__builtin_ctzll(own), WAVE);
-        }
     }
-    const int best_dist = best == 0xFFFFFFFFu ? 100 : (int)(best >> 16);
-    if (best_dist < 75) { // thOrbDist = (TH_HIGH+TH_LOW)/2
-        const float ur0 = best_x;
-        const float sfac = tabs.isf[level_l];
-        const float sul = roundf(kp.x * sfac), svl = roundf(kp.y * sfac), sur0 = roundf(ur0 * sfac);
-        const LevelGeom &LV = g->lv[level_l];
+    const unsigned best_row = row16_min_u32(mine);                                   // per 16-lane row
+    const unsigned bx_row = row16_or_u32(mine == best_row && mine != 0xFFFFFFFFu ? __float_as_uint(mine_x) : 0u); // the key holds iR: one owner
+    for (int gk = 0; gk < 4; gk++) { // fine stage, one keypoint at a time (all values wave-uniform from here)
+        if (il_base + gk >= n_l) break;
+        const unsigned best = (unsigned)__builtin_amdgcn_readlane((int)best_row, gk * 16);
+        const int best_dist = best == 0xFFFFFFFFu ? 100 : (int)(best >> 16);
+        const float ur0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)bx_row, gk * 16));
+        const float kx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(kp.x), gk * 16));
+        const float ky = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(kp.y), gk * 16));
+        const int lvl = __builtin_amdgcn_readlane(level_l, gk * 16);
+        const long long og = (long long)p * cap + il_base + gk;
+        if (!(best_dist < 75)) { // thOrbDist = (TH_HIGH+TH_LOW)/2: no coarse match
+            if (lane == 0) { u_right[og] = -1.0f; depth[og] = -1.0f; st_dist[og] = -1; }
+            continue;
+        }
+        float out_u = -1.0f, out_z = -1.0f;
+        int out_sad = -1;
+        const float sfac = tabs.isf[lvl];
+        const float sul = roundf(kx * sfac), svl = roundf(ky * sfac), sur0 = roundf(ur0 * sfac);
+        const LevelGeom &LV = g->lv[lvl];
         const float iniu = sur0 + 5 - 5, endu = sur0 + 5 + 5 + 1;
         if (!(iniu < 0 || endu >= (float)LV.w)) {
             int pl, prr;
-            const uint8_t *imL = orbx_level_ptr(prL, LV, level_l, img_l0 + p, &pl);
-            const uint8_t *imR = orbx_level_ptr(prR, LV, level_l, img_r0 + p, &prr);
+            const uint8_t *imL = orbx_level_ptr(prL, LV, lvl, img_l0 + p, &pl);
+            const uint8_t *imR = orbx_level_ptr(prR, LV, lvl, img_r0 + p, &prr);
             const int cy = (int)svl, cxl = (int)sul;
             // each lane owns window pixels e = lane and lane+64 (< 121)
             const int e0 = lane, e1 = lane + 64;
@@ -149,7 +164,7 @@ __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrR
                 uint8_t *wl = s_win + (threadIdx.x >> 6) * ((SW_BYTES + 15) & ~15), *wr = wl + 11 * 16;
                 const int xla = (cxl - 5) & ~3, xra = (cx0 - 10) & ~3;
                 // right: 77 dwords (clamped at the row end: the extra bytes of a clamped dword are never read)
-                uint32_t vr0, vr1 = 0, vl = 0;
+                uint32_t vr0, vr1 = 0, vlw = 0;
                 {
                     const int rr = lane / 7, cc = lane - rr * 7;
                     const int xo_ = min(xra + 4 * cc, (prr - 4));
@@ -160,11 +175,12 @@ __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrR
                     }
                     if (lane < 44) {
                         const int r3 = lane >> 2, c3 = lane & 3;
-                        vl = *reinterpret_cast<const uint32_t *>(imL + (long long)(cy - 5 + r3) * pl + min(xla + 4 * c3, pl - 4));
+                        vlw = *reinterpret_cast<const uint32_t *>(imL + (long long)(cy - 5 + r3) * pl + min(xla + 4 * c3, pl - 4));
                     }
+                    __builtin_amdgcn_wave_barrier();                      // the previous keypoint's reads are done (in-order LDS)
                     reinterpret_cast<uint32_t *>(wr)[lane] = vr0;        // row pitch 28 bytes = 7 dwords: index = r*7 + c
                     if (lane < 13) reinterpret_cast<uint32_t *>(wr)[lane + 64] = vr1;
-                    if (lane < 44) reinterpret_cast<uint32_t *>(wl)[lane] = vl; // row pitch 16 bytes
+                    if (lane < 44) reinterpret_cast<uint32_t *>(wl)[lane] = vlw; // row pitch 16 bytes
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -216,10 +232,10 @@ __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrR
                     if (k == best_inc + 5) { d1 = (float)dists[k - 1]; d2 = (float)dists[k]; d3 = (float)dists[k + 1]; }
                 const float delta = (d1 - d3) / (2.0f * (d1 + d3 - 2.0f * d2));
                 if (!(delta < -1 || delta > 1)) {
-                    float best_ur = tabs.sf[level_l] * ((float)sur0 + (float)best_inc + delta);
-                    float disparity = ul - best_ur;
+                    float best_ur = tabs.sf[lvl] * ((float)sur0 + (float)best_inc + delta);
+                    float disparity = kx - best_ur;
                     if (disparity >= 0 && disparity < max_d) {
-                        if (disparity <= 0) { disparity = 0.01f; best_ur = (float)((double)ul - 0.01); }
+                        if (disparity <= 0) { disparity = 0.01f; best_ur = (float)((double)kx - 0.01); }
                         out_z = bf / disparity;
                         out_u = best_ur;
                         out_sad = best_sad;
@@ -227,8 +243,8 @@ __global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrR
                 }
             }
         }
+        if (lane == 0) { u_right[og] = out_u; depth[og] = out_z; st_dist[og] = out_sad; }
     }
-    if (lane == 0) { u_right[ol] = out_u; depth[ol] = out_z; st_dist[ol] = out_sad; }
 }
 
 // one 256-thread workgroup per stereo pair
@@ -342,7 +358,7 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
     orbx_prof_begin(L, ORBX_STAGE_STEREO, s);
     hipLaunchKernelGGL(k_stereo_prep, dim3(batch), dim3(256), (size_t)2 * ((rows + 4) & ~3) * sizeof(int), s, L->d_geom,
                        (const orbx_keypoint *)d_kR, (const int *)d_nR, cap, tabs, (int *)d_row_off, (uint2 *)d_entries, ent_cap);
-    hipLaunchKernelGGL(k_stereo, dim3((cap + 3) / 4, batch), dim3(256), 0, s, L->d_geom, pl, pr, img_l0, img_r0,
+    hipLaunchKernelGGL(k_stereo, dim3((cap + 15) / 16, batch), dim3(256), 0, s, L->d_geom, pl, pr, img_l0, img_r0,
                        (const orbx_keypoint *)d_kL, (const uint32_t *)d_dL, (const int *)d_nL,
                        (const orbx_keypoint *)d_kR, (const uint32_t *)d_dR, (const int *)d_nR, cap, bf, max_d, tabs,
                        (float *)d_u_right, (float *)d_depth, L->d_st_dist, (const int *)d_row_off, (const uint2 *)d_entries, ent_cap);
