@@ -114,6 +114,8 @@ def lib():
         L.oracle_vocab_nodes.argtypes = [C.c_void_p]
         L.oracle_vocab_words.argtypes = [C.c_void_p]
         L.oracle_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.POINTER(C.c_int)] + [C.c_void_p] * 3 + [C.POINTER(C.c_int)]
+        L.oracle_bow_accumulate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.oracle_distinctive_descriptor.argtypes = [C.c_void_p, C.c_int]
         L.oracle_search_by_projection_last.argtypes = [C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.oracle_search_by_projection_points.argtypes = [C.POINTER(FrameFeats), C.POINTER(ProjPoints), C.c_void_p, C.c_float, C.c_float, C.c_void_p]
@@ -278,6 +280,18 @@ class Vocabulary:
         assert rc == 0
         return dict(word_id=wid, word_weight=ww, node_id=nid, bow_id=bid[:nb.value].copy(), bow_val=bval[:nb.value].copy(),
                     fv_node_id=fid[:fn.value].copy(), fv_node_off=foff[:fn.value + 1].copy(), fv_feat=ffeat[:foff[fn.value]].copy())
+
+
+def bow_accumulate(word_id, word_weight, node_id):
+    """the accumulation half of TemplatedVocabulary::transform (BowVector::addWeight / normalize(L1), FeatureVector::addFeature)"""
+    wid = np.ascontiguousarray(word_id, np.uint32); ww = np.ascontiguousarray(word_weight, np.float64)
+    nid = np.ascontiguousarray(node_id, np.uint32); n = len(wid)
+    bid = np.zeros(max(n, 1), np.uint32); bval = np.zeros(max(n, 1), np.float64); nb = C.c_int()
+    fid = np.zeros(max(n, 1), np.uint32); foff = np.zeros(n + 1, np.int32); ffeat = np.zeros(max(n, 1), np.uint32); fn = C.c_int()
+    rc = lib().oracle_bow_accumulate(_p(wid), _p(ww), _p(nid), n, _p(bid), _p(bval), C.byref(nb), _p(fid), _p(foff), _p(ffeat), C.byref(fn))
+    assert rc == 0
+    return dict(bow_id=bid[:nb.value].copy(), bow_val=bval[:nb.value].copy(), fv_node_id=fid[:fn.value].copy(),
+                fv_node_off=foff[:fn.value + 1].copy(), fv_feat=ffeat[:foff[fn.value]].copy())
 
 
 def distinctive_descriptor(desc):

@@ -1089,49 +1089,30 @@ static int kf_cmp(const void *a, const void *b)
     return p->feat < q->feat ? -1 : p->feat > q->feat ? 1 : 0;
 }
 
-int oracle_bow_transform(const oracle_vocab *v, const uint8_t *desc, int n, int levelsup,
-                         uint32_t *word_id, double *word_weight, uint32_t *node_id,
-                         uint32_t *bow_id, double *bow_val, int *nbow,
-                         uint32_t *fv_node_id, int32_t *fv_node_off, uint32_t *fv_feat, int *fv_nnodes)
+/* The accumulation half of TemplatedVocabulary::transform (:1147-1165): for every feature i in order whose word
+ * weight is > 0 (:1157), v.addWeight(word_id[i], weight[i]) (BowVector.cpp:33-45: the map value is incremented in
+ * FEATURE order, which fixes the fp64 summation order) and fv.addFeature(node_id[i], i) (FeatureVector.cpp:31-45),
+ * then v.normalize(L1) (BowVector.cpp:58-77).  Pinned against the reference's own BowVector.cpp / FeatureVector.cpp
+ * compiled into oracle/_ref (tests/test_dbow2_ref.py). */
+int oracle_bow_accumulate(const uint32_t *word_id, const double *word_weight, const uint32_t *node_id, int n,
+                          uint32_t *bow_id, double *bow_val, int *nbow,
+                          uint32_t *fv_node_id, int32_t *fv_node_off, uint32_t *fv_feat, int *fv_nnodes)
 {
     kf_pair *words = malloc(sizeof(kf_pair) * (n ? n : 1)), *nodes = malloc(sizeof(kf_pair) * (n ? n : 1));
-    double *wts = malloc(sizeof(double) * (n ? n : 1));
     int m = 0;
-    const int nid_level = v->L - levelsup;
-    for (int i = 0; i < n; i++) {
-        /* transform(feature, word_id, weight, nid, levelsup), :1218-1259 */
-        const uint8_t *f = desc + (size_t)i * 32;
-        int nid = 0, final_id = 0, level = 0;
-        do {
-            ++level;
-            const int c0 = v->child_off[final_id], c1 = v->child_off[final_id + 1];
-            final_id = v->child_ids[c0];
-            double best_d = oracle_hamming(f, v->desc + (size_t)final_id * 32);
-            for (int c = c0 + 1; c < c1; c++) {
-                const int id = v->child_ids[c];
-                const double d = oracle_hamming(f, v->desc + (size_t)id * 32);
-                if (d < best_d) { best_d = d; final_id = id; }
-            }
-            if (level == nid_level) nid = final_id;
-        } while (v->child_off[final_id + 1] > v->child_off[final_id]);
-        const int wid = v->word_id[final_id];
-        const double w = v->weight[final_id];
-        if (word_id) word_id[i] = (uint32_t)wid;
-        if (word_weight) word_weight[i] = w;
-        if (node_id) node_id[i] = (uint32_t)nid;
-        if (w > 0) { /* not stopped, :1157 */
-            words[m].key = (uint32_t)wid; words[m].feat = i; wts[i] = w;
-            nodes[m].key = (uint32_t)nid; nodes[m].feat = i;
+    for (int i = 0; i < n; i++)
+        if (word_weight[i] > 0) { /* not stopped, :1157 */
+            words[m].key = word_id[i]; words[m].feat = i;
+            nodes[m].key = node_id[i]; nodes[m].feat = i;
             m++;
         }
-    }
     /* BowVector: std::map<WordId, WordValue> with addWeight in feature order (BowVector.cpp:33-45) */
     qsort(words, m, sizeof(kf_pair), kf_cmp);
     int nb = 0;
     for (int i = 0; i < m;) {
         int j = i;
-        double acc = wts[words[i].feat];
-        for (j = i + 1; j < m && words[j].key == words[i].key; j++) acc += wts[words[j].feat];
+        double acc = word_weight[words[i].feat];
+        for (j = i + 1; j < m && words[j].key == words[i].key; j++) acc += word_weight[words[j].feat];
         bow_id[nb] = words[i].key; bow_val[nb] = acc; nb++;
         i = j;
     }
@@ -1149,8 +1130,44 @@ int oracle_bow_transform(const oracle_vocab *v, const uint8_t *desc, int n, int 
     }
     fv_node_off[nn] = m;
     *fv_nnodes = nn;
-    free(words); free(nodes); free(wts);
+    free(words); free(nodes);
     return 0;
+}
+
+int oracle_bow_transform(const oracle_vocab *v, const uint8_t *desc, int n, int levelsup,
+                         uint32_t *word_id, double *word_weight, uint32_t *node_id,
+                         uint32_t *bow_id, double *bow_val, int *nbow,
+                         uint32_t *fv_node_id, int32_t *fv_node_off, uint32_t *fv_feat, int *fv_nnodes)
+{
+    uint32_t *wid_all = malloc(sizeof(uint32_t) * (n ? n : 1)), *nid_all = malloc(sizeof(uint32_t) * (n ? n : 1));
+    double *wts = malloc(sizeof(double) * (n ? n : 1));
+    const int nid_level = v->L - levelsup;
+    for (int i = 0; i < n; i++) {
+        /* transform(feature, word_id, weight, nid, levelsup), :1218-1259 */
+        const uint8_t *f = desc + (size_t)i * 32;
+        int nid = 0, final_id = 0, level = 0;
+        do {
+            ++level;
+            const int c0 = v->child_off[final_id], c1 = v->child_off[final_id + 1];
+            final_id = v->child_ids[c0];
+            double best_d = oracle_hamming(f, v->desc + (size_t)final_id * 32);
+            for (int c = c0 + 1; c < c1; c++) {
+                const int id = v->child_ids[c];
+                const double d = oracle_hamming(f, v->desc + (size_t)id * 32);
+                if (d < best_d) { best_d = d; final_id = id; }
+            }
+            if (level == nid_level) nid = final_id;
+        } while (v->child_off[final_id + 1] > v->child_off[final_id]);
+        wid_all[i] = (uint32_t)v->word_id[final_id];
+        wts[i] = v->weight[final_id];
+        nid_all[i] = (uint32_t)nid;
+        if (word_id) word_id[i] = wid_all[i];
+        if (word_weight) word_weight[i] = wts[i];
+        if (node_id) node_id[i] = nid_all[i];
+    }
+    const int rc = oracle_bow_accumulate(wid_all, wts, nid_all, n, bow_id, bow_val, nbow, fv_node_id, fv_node_off, fv_feat, fv_nnodes);
+    free(wid_all); free(nid_all); free(wts);
+    return rc;
 }
 
 /* ------------------------------------------------------------------ MapPoint::ComputeDistinctiveDescriptors (f3) */

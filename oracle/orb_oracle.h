@@ -132,6 +132,12 @@ int oracle_bow_transform(const oracle_vocab *v, const uint8_t *desc, int n, int 
                          uint32_t *bow_id, double *bow_val, int *nbow,
                          uint32_t *fv_node_id, int32_t *fv_node_off, uint32_t *fv_feat, int *fv_nnodes);
 
+/* accumulation half of transform (BowVector::addWeight in feature order + normalize(L1), FeatureVector::addFeature);
+ * features with word_weight[i] <= 0 are skipped (TemplatedVocabulary.h:1157).  Same output contract as above. */
+int oracle_bow_accumulate(const uint32_t *word_id, const double *word_weight, const uint32_t *node_id, int n,
+                          uint32_t *bow_id, double *bow_val, int *nbow,
+                          uint32_t *fv_node_id, int32_t *fv_node_off, uint32_t *fv_feat, int *fv_nnodes);
+
 /* MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:266-340, for one map point: desc[n][32] are the
  * descriptors of its (non-bad) observations in std::map iteration order; returns BestIdx (-1 if n == 0). */
 int oracle_distinctive_descriptor(const uint8_t *desc, int n);
