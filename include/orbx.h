@@ -16,6 +16,14 @@
  *
  * Threading (as the reference): one extractor handle is used by one thread
  * at a time; distinct handles may be used concurrently.
+ *
+ * Streams: a handle remembers the stream of its most recent "*_device" launches.  Whenever a call
+ * has to rebuild the per-image-size tables (first call / a new image size) or to grow a workspace,
+ * it first waits for that stream and for the handle's own stream, so tables and buffers are never
+ * rewritten or freed under running kernels.  A caller stream must therefore stay valid until the
+ * handle has been used with another stream or destroyed.  Steady state (same size, same batch)
+ * never synchronises.  A kernel-side error (ORBX_E_CAPACITY from orbx_sync) belongs to the work
+ * that orbx_sync has just waited for; the flag is cleared when it is reported.
  */
 #ifndef ORBX_H
 #define ORBX_H
@@ -357,6 +365,10 @@ int orbx_profile_read(orbx_extractor *e, float *ms, int *launches, int reset);
  * x,y are relative to (16,16) like the reference's vToDistributeKeys. */
 int orbx_debug_candidates(orbx_extractor *e, int image_index, int level, int32_t *x, int32_t *y, int32_t *resp, int cap, int *n);
 int orbx_debug_level_counts(orbx_extractor *e, int image_index, int32_t *counts /*[nlevels]*/);
+/* test hook: the SearchByBoW kernels exist in a latency form (one 16-wave workgroup per pair) and a throughput form
+ * (LDS distance table + row fixpoint); a call picks by problem size.  form = 1 / 2 forces the wave / table form for
+ * every later call of the process, 0 restores the automatic choice.  Both forms return identical matches. */
+int orbx_debug_set_bow_form(int form);
 
 #ifdef __cplusplus
 }

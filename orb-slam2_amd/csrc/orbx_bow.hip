@@ -9,6 +9,7 @@
 // wave min-reductions for best / second best.  Rotation histogram + ComputeThreeMaxima run once
 // per pair in LDS.
 #include "orbx_device.h"
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -475,6 +476,15 @@ __global__ __launch_bounds__(256) void k_triangulation(const DevFeat *__restrict
 }
 
 
+// 0 = choose by size, 1 = always the wave form, 2 = always the table form (explicit debug entry point, no environment lookup)
+static std::atomic<int> g_bow_form{0};
+extern "C" int orbx_debug_set_bow_form(int form)
+{
+    if (form < 0 || form > 2) { orbx_set_error("orbx_debug_set_bow_form: 0 (auto), 1 (wave) or 2 (table)"); return ORBX_E_INVALID; }
+    g_bow_form.store(form, std::memory_order_relaxed);
+    return ORBX_OK;
+}
+
 // pairs < BOW_TABLE_MIN_PAIRS: too few workgroups to fill 256 CUs, the 16-wave latency form is faster per call
 #define BOW_TABLE_MIN_PAIRS 4096
 template <int MODE>
@@ -483,7 +493,8 @@ static int bow_launch(int npairs_x, int nframes_y, int max_b, int max_slots, hip
 {
     const size_t base = (size_t)((max_b + 15) & ~15) + (size_t)((max_slots + 15) & ~15) + 16;
     bool table = (long long)npairs_x * nframes_y >= BOW_TABLE_MIN_PAIRS;
-    if (const char *f = getenv("ORBX_BOW_FORM")) table = f[0] == 't'; // "table" / "wave": lets the parity tests run both forms on small inputs
+    const int forced = g_bow_form.load(std::memory_order_relaxed); // orbx_debug_set_bow_form: the parity tests run both forms on small inputs
+    if (forced) table = forced == 2;
     const size_t lds = table ? base + 4 * (size_t)((max_b + 3) & ~3) + 2 * BOW_MATCAP : base;
     if (lds > 150 * 1024) { orbx_set_error("feature sets too large for LDS"); return ORBX_E_INVALID; }
     if (table) {

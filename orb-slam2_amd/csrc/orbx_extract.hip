@@ -1021,7 +1021,10 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         return ORBX_E_INVALID;
     }
     ORBX_HIP(hipSetDevice(e->device));
-    ORBX_HIP(hipStreamSynchronize(e->stream));
+    {   // earlier launches (possibly on a caller's non-blocking stream) still read d_geom / d_tabs / d_cells and the workspaces
+        const int qrc = orbx_quiesce(e);
+        if (qrc) return qrc;
+    }
     const size_t B = e->max_batch;
     int rc;
     if ((rc = ensure(&e->d_tabs, &e->tabs_cap, tabs.size() * 2))) return rc;
@@ -1201,6 +1204,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
         return ORBX_E_CAPACITY;
     }
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    e->last_launch_stream = s;
     PyrRef pr;
     pr.img0 = (const uint8_t *)d_imgs; pr.img0_stride = (long long)img_stride; pr.img0_pitch = (int)pitch;
     pr.pyr = e->d_pyr; pr.pyr_stride = G.pyr_bytes;
@@ -1244,7 +1248,9 @@ extern "C" int orbx_sync(orbx_extractor *e, void *stream)
     ORBX_HIP(hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     // the kernel error flag rides the same stream into pinned memory: one synchronisation, no blocking pageable copy
-    ORBX_HIP(hipMemcpyAsync(e->h_flag, e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels, sizeof(int), hipMemcpyDeviceToHost, s));
+    int *d_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;
+    ORBX_HIP(hipMemcpyAsync(e->h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), s)); // the error belongs to the work synchronised here, not to later frames
     ORBX_HIP(hipStreamSynchronize(s));
     e->prof_chain = false; // the stream idles from here on: the next launch must not share its begin event with the last one
     const int flag = *e->h_flag;
@@ -1252,9 +1258,17 @@ extern "C" int orbx_sync(orbx_extractor *e, void *stream)
     return ORBX_OK;
 }
 
+int orbx_quiesce(orbx_extractor *e)
+{
+    ORBX_HIP(hipStreamSynchronize(e->stream));
+    if (e->last_launch_stream && e->last_launch_stream != e->stream) ORBX_HIP(hipStreamSynchronize(e->last_launch_stream));
+    return ORBX_OK;
+}
+
 int orbx_ensure_out_staging(orbx_extractor *e, int batch, int cap)
 {
     if (e->d_out_kps && e->out_cap >= cap && e->out_batch >= batch) return ORBX_OK;
+    { const int qrc = orbx_quiesce(e); if (qrc) return qrc; }
     void **ps[] = { &e->d_out_kps, &e->d_out_desc, &e->d_out_n, (void **)&e->d_out_ur, (void **)&e->d_out_depth };
     for (void **p : ps) if (*p) { ORBX_HIP(hipFree(*p)); *p = nullptr; }
     const size_t n = (size_t)batch * cap;
@@ -1558,6 +1572,7 @@ extern "C" int orbx_debug_candidates(orbx_extractor *e, int image_index, int lev
 int orbx_scratch(orbx_extractor *e, int slot, size_t bytes, void **out)
 {
     if (bytes > e->scratch_cap[slot] || !e->scratch[slot]) {
+        { const int qrc = orbx_quiesce(e); if (qrc) return qrc; }
         if (e->scratch[slot]) { ORBX_HIP(hipFree(e->scratch[slot])); e->scratch[slot] = nullptr; e->scratch_cap[slot] = 0; }
         ORBX_HIP(hipMalloc(&e->scratch[slot], bytes ? bytes : 16));
         e->scratch_cap[slot] = bytes;

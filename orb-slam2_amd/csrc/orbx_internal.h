@@ -70,6 +70,7 @@ struct orbx_extractor {
     int umax[16];
 
     hipStream_t stream;
+    hipStream_t last_launch_stream;  // stream of the most recent kernel launches on this handle's workspaces (caller's or `stream`)
     // geometry of the current image size
     Geom geom;           // host copy (geom.w == 0: none yet)
     Geom *d_geom;        // device copy
@@ -141,6 +142,10 @@ void orbx_prof_begin(orbx_extractor *e, int stage, hipStream_t s);
 void orbx_prof_end(orbx_extractor *e, hipStream_t s);
 int orbx_ensure_out_staging(orbx_extractor *e, int batch, int cap);
 int orbx_scratch(orbx_extractor *e, int slot, size_t bytes, void **out);
+// waits for everything launched on this handle's workspaces (its own stream and the caller stream of the most recent
+// launches): called before any geometry rebuild or workspace reallocation, so tables are never rewritten and buffers
+// never freed under running kernels
+int orbx_quiesce(orbx_extractor *e);
 
 // level-0 / level-l pixel pointer of image b (device side helper)
 struct PyrRef {

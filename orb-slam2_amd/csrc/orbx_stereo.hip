@@ -325,6 +325,7 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
     const size_t need = (size_t)batch * cap * sizeof(int);
     if (need > L->st_cap || !L->d_st_dist) {
         ORBX_HIP(hipStreamSynchronize(s));
+        { const int qrc = orbx_quiesce(L); if (qrc) return qrc; }
         if (L->d_st_dist) ORBX_HIP(hipFree(L->d_st_dist));
         L->d_st_dist = nullptr;
         ORBX_HIP(hipMalloc((void **)&L->d_st_dist, need));
@@ -342,6 +343,7 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
         const size_t need_e = (size_t)batch * ent_cap * sizeof(uint2);
         if (need_e > L->st_ent_cap || !L->d_st_entries) {
             ORBX_HIP(hipStreamSynchronize(s));
+            { const int qrc = orbx_quiesce(L); if (qrc) return qrc; }
             if (L->d_st_entries) ORBX_HIP(hipFree(L->d_st_entries));
             L->d_st_entries = nullptr;
             ORBX_HIP(hipMalloc((void **)&L->d_st_entries, need_e));
@@ -354,6 +356,7 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
     pl.pyr = L->d_pyr; pl.pyr_stride = L->geom.pyr_bytes;
     pr.img0 = R->last_img0; pr.img0_stride = (long long)R->last_img_stride; pr.img0_pitch = (int)R->last_pitch;
     pr.pyr = R->d_pyr; pr.pyr_stride = R->geom.pyr_bytes;
+    L->last_launch_stream = s;
     const float max_d = bf / min_z; // src/Frame.cc:609
     orbx_prof_begin(L, ORBX_STAGE_STEREO, s);
     hipLaunchKernelGGL(k_stereo_prep, dim3(batch), dim3(256), (size_t)2 * ((rows + 4) & ~3) * sizeof(int), s, L->d_geom,

@@ -116,8 +116,14 @@ def lib():
     L.orbx_profile_read.argtypes = [vp, vp, vp, i]
     L.orbx_debug_candidates.argtypes = [vp, i, i, vp, vp, vp, i, ip]
     L.orbx_debug_level_counts.argtypes = [vp, i, vp]
+    L.orbx_debug_set_bow_form.argtypes = [i]
     _lib = L
     return L
+
+
+def debug_set_bow_form(form):
+    """test hook: "auto" / "wave" / "table" form of the SearchByBoW kernels (orbx_debug_set_bow_form)"""
+    _check(lib().orbx_debug_set_bow_form({"auto": 0, "wave": 1, "table": 2}[form]))
 
 
 def _check(rc):

@@ -405,12 +405,15 @@ def test_hamming_host(pkg, oracle):
 def test_bow_searches_table_form(pkg, oracle, monkeypatch):
     """the same SearchByBoW parity cases through the throughput form of the kernel (LDS distance table + row fixpoint),
     which a call only picks by itself from 4096 pairs up (orbx_bow.hip: bow_launch)"""
-    monkeypatch.setenv("ORBX_BOW_FORM", "table")
-    test_search_by_bow_kf_f(pkg, oracle, 0.75, True)
-    test_search_by_bow_kf_f(pkg, oracle, 0.9, False)
-    test_bow_database(pkg, oracle)
-    test_search_by_bow_kf_kf(pkg, oracle)
-    test_bow_edge_cases(pkg, oracle)
+    pkg.orbx.debug_set_bow_form("table")
+    try:
+        test_search_by_bow_kf_f(pkg, oracle, 0.75, True)
+        test_search_by_bow_kf_f(pkg, oracle, 0.9, False)
+        test_bow_database(pkg, oracle)
+        test_search_by_bow_kf_kf(pkg, oracle)
+        test_bow_edge_cases(pkg, oracle)
+    finally:
+        pkg.orbx.debug_set_bow_form("auto")
 
 
 @pytest.mark.gpu

@@ -15,17 +15,17 @@ BF, MIN_Z = 386.1448, 386.1448 / 718.856     # Examples/Stereo/KITTI00-02.yaml:8
 
 
 def _pairs(n, seed0):
-    """n distinct KITTI-shape pairs; pair 3 is featureless (both eyes flat), pair 5 has a right eye whose lower
-    half is flat and pair 6 a left eye whose right half is flat (unequal keypoint counts inside one batch)"""
+    """n distinct KITTI-shape pairs; pair 3 is featureless (both eyes flat), pair 5 has a right eye and pair 6 a left
+    eye that is flat outside a 120x100 window (about 640 keypoints instead of the quota: unequal counts inside one batch)"""
     out = []
     for i in range(n):
         l, r, _ = synth.stereo_pair(seed0 + i, W, H)
         if i == 3:
             l = np.full((H, W), 77, np.uint8); r = np.full((H, W), 77, np.uint8)
         if i == 5:
-            r = r.copy(); r[H // 2:] = 60
+            r2 = np.full_like(r, 60); r2[100:200, 500:620] = r[100:200, 500:620]; r = r2
         if i == 6:
-            l = l.copy(); l[:, W // 2:] = 200
+            l2 = np.full_like(l, 200); l2[100:200, 500:620] = l[100:200, 500:620]; l = l2
         out.append((l, r))
     return out
 
@@ -86,7 +86,7 @@ def test_stereo_match_batch_one_handle(pkg, oracle, nf, B):
     matched = [(ur_h[p, :n_h[p]] >= 0).sum() for p in range(B)]
     assert matched[3] == 0 and n_h[3] == 0                       # the featureless pair
     assert n_h[B + 5] < 0.8 * n_h[5] and n_h[6] < 0.8 * n_h[B + 6]   # unequal counts really occur
-    assert sum(m > 50 for m in matched) >= B - 3                 # the test is not vacuous
+    assert sum(m > 50 for m in matched) >= B - 4                 # the test is not vacuous
 
 
 def test_stereo_match_batch_two_handles_offset(pkg, oracle):

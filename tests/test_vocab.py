@@ -200,14 +200,14 @@ def test_hip_device_resident_bow_chain(pkg, oracle):
     expect = [[oracle.search_by_bow_kf_f(kf, frames[i], 0.75, True) for kf in kfs] for i in range(B)]
     import os
     for form in ("table", "wave"):       # the throughput and the latency form of the search kernel (orbx_bow.hip: bow_launch)
-        os.environ["ORBX_BOW_FORM"] = form
+        pkg.orbx.debug_set_bow_form(form)
         try:
             d_match.fill_(-7); d_nm.zero_()
             torch.cuda.synchronize()
             fr.search(db, B, d_match.data_ptr(), d_nm.data_ptr(), 0.75, True, st)
             stream.synchronize()
         finally:
-            del os.environ["ORBX_BOW_FORM"]
+            pkg.orbx.debug_set_bow_form("auto")
         m = d_match.cpu().numpy(); nm = d_nm.cpu().numpy()
         total = 0
         for i in range(B):

@@ -49,7 +49,7 @@ while time.time() - t0 < budget:
     e1, n1 = O.search_by_bow_kf_f(A, B, ratio, ori)
     e2, n2 = O.search_by_bow_kf_kf(A, B, ratio, ori)
     for form in ("table", "wave"):
-        os.environ["ORBX_BOW_FORM"] = form
+        pkg.orbx.debug_set_bow_form(form)
         m = pkg.ORBmatcher(ratio, ori)
         g1, gn1 = m.SearchByBoW(A, B)
         Bk = dict(B); Bk["kind"] = "keyframe"
