@@ -198,16 +198,30 @@ __device__ __forceinline__ int fast_score_full(const uint8_t *t, int th)
     return s > th ? s - 1 : 0;
 }
 
-// One wave (64-thread workgroup) per (cell, image) -- no workgroup barriers, many independent cells
-// in flight per CU.  The cell (+3 px halo) is staged in LDS with aligned dword loads; a 4-point
-// pretest (any 9-arc holds two adjacent compass pixels) compacts the candidate pixels into an LDS
-// list so that the full 16-point network runs on dense lanes; then in-cell 3x3 strict NMS with one
-// ballot per 64 pixels (kept in LDS), iniThFAST/minThFAST selection and ordered (row-major)
-// emission into the cell's candidate slots.  Candidate = x | y<<12 | score<<24, (x,y) relative to (16,16).
+// One wave (64-thread workgroup) per (cell, image) -- no workgroup barriers, many independent cells in flight per CU.
+// The kernel is VALU-issue bound, and on gfx950 only a few wave64 opcodes issue at the full rate (add / sub / and / or /
+// xor / lshr / mov and the 16-bit VOP2 forms: ~2.5 cycles per wave-instruction; min / max / min3 / perm / alignbyte /
+// packed-16 / mul / cmp / cndmask / mbcnt / DPP / SDWA: ~4.3, tools/ubench/op_cost.hip), so every phase is written for few
+// instruction-cycles per pixel:
+//  1. the cell (+3 px halo) goes to LDS with direct loads (global_load_lds_dword: no VGPR round trip, no ds_write; one
+//     instruction = RPL whole tile rows), all in flight at once, while the wave zeroes its score tile and bitmaps;
+//  2. pretest on 4 horizontally adjacent pixels per lane in byte-parallel (SWAR) form with full-rate ops only: on values
+//     halved to 7 bits a borrow-free per-byte subtract leaves "x7 <= c7 - s7" in bit 7 of every byte.  Halving makes the test
+//     CONSERVATIVE (never a false negative; floor((c-s)/2) <= c7 - s7), which is all a pretest needs: a FAST-9 corner has two
+//     adjacent compass pixels (of N, E, S, W at distance 3) darker than c - t or brighter than c + t.  The four flag bits are
+//     OR-ed into a per-row candidate bitmap in LDS (ds_or_b32): no ballots, no per-iteration prefix sums;
+//  3. lane = row: the row bitmaps are unrolled into the dense ordered candidate list (one wave prefix sum per cell);
+//  4. threshold-free cornerScore (v_min3 / v_max3 arc network) on dense lanes -> score tile;
+//  5. strict in-cell 3x3 maximum per listed pixel -> survivor bitmap; lane = row again: ordered emission.
+// Threshold schedule of src/ORBextractor.cc:988-995 as it stands: the whole sequence runs at iniThFAST; only a cell that
+// keeps nothing (no corner, or only tied maxima) runs again at minThFAST.  Scores do not depend on the threshold and the
+// iniThFAST pretest passes ~40 % fewer pixels to the score network than a minThFAST one, which nearly every textured cell
+// used to pay for.  Candidate = x | y<<12 | score<<24, (x,y) relative to (16,16).
 extern __shared__ __align__(16) unsigned char fast_smem[];
 #ifndef FAST_XG
 #define FAST_XG 4
 #endif
+#define FAST_BM_ROWS 72   // bitmap rows (u64 each): detect rows <= 59 plus the row overrun of the last pretest iteration
 
 #ifdef ORBX_DIAG
 __device__ unsigned long long g_fast_stamp[4096 * 8]; // diagnostic build only: summed phase cycles of k_fast, 4096 slots
@@ -221,16 +235,19 @@ __device__ unsigned long long g_desc_stamp[4096 * 8]; // same for k_desc
 #define DSTAMP(k) do { } while (0)
 #endif
 
-// P / SP = LDS pitches of the pixel tile and the score tile: (48, 40) when every cell of the pyramid fits
-// (cells up to 38 px wide), else (72, 64); smaller tiles = more resident waves per CU.
+// P / SP = LDS pitches of the pixel tile and the score tile: (64, 40) when every cell of the pyramid is at most 38 px wide
+// (one direct load = 4 tile rows of 16 dwords), else (128, 64).
 template <int P, int SP>
 __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const CellRec *__restrict__ cells, PyrRef pr,
                                              int *__restrict__ cell_cnt, uint32_t *__restrict__ cand, int ini_th, int min_th)
 {
+    constexpr int DWR = P / 4;      // dwords per tile row = lanes per row of one direct load
+    constexpr int RPL = 64 / DWR;   // tile rows per direct load
     uint8_t *tile = fast_smem;
     uint8_t *sc = fast_smem + g->fast_lds_sc;
     uint16_t *list = reinterpret_cast<uint16_t *>(fast_smem + g->fast_lds_list);
-    unsigned long long *masks = reinterpret_cast<unsigned long long *>(fast_smem + g->fast_lds_mask);
+    uint32_t *bm = reinterpret_cast<uint32_t *>(fast_smem + g->fast_lds_bm); // candidate bitmap, then survivor bitmap: u64 per row
+    uint32_t *sv = bm + 2 * FAST_BM_ROWS;
     const int b = blockIdx.y, lane = threadIdx.x;
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8, speed only): remap so that FAST_XG
     // horizontally adjacent cells land on the same XCD (their halos share cache lines in that XCD's L2) while each
@@ -254,134 +271,141 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
     const int pitch = rec.level == 0 ? pr.img0_pitch : rec.pitch;
     const uint8_t *img = rec.level == 0 ? pr.img0 + (long long)b * pr.img0_stride
                                         : pr.pyr + (long long)b * pr.pyr_stride + rec.pyr_off;
-    // The tile is fetched with dword loads that start one byte left of the cell (gfx950 global loads need no alignment),
-    // so the first detectable pixel always sits at tile column 4: every pretest group of four pixels is a whole LDS
-    // dword whatever the cell's position or the caller's pitch, and a 30-px cell is 8 groups per row (4 wave iterations;
-    // with source-aligned loads it was 9 groups = 5 iterations for three alignments out of four).
+    // ---- 1. tile: the fetch starts one byte left of the cell (gfx950 global and LDS-direct loads need no alignment), so the
+    // first detectable pixel always sits at tile column 4: every pretest group of four pixels is a whole LDS dword whatever
+    // the cell's position or the caller's pitch.  Lane = (row lane / DWR, dword lane % DWR) of RPL whole rows per load; the data
+    // lands at tile + 256 * k + 4 * lane, i.e. row-major with pitch P.
     constexpr int xo = 1; // tile column of image column ini_x
     {
-        struct __attribute__((packed)) U32 { uint32_t v; };
-        const int ndw = (tw + xo + 3) >> 2; // <= 17 dwords per row
-        const FastDiv fd(ndw);
-        // Lane = (row lr, dword lc) of a band of rpb = 64 / ndw whole rows; band k covers rows k*rpb .. k*rpb + rpb - 1.
-        // The lane part of every address is computed once, a band adds a wave-uniform row offset (scalar): the former
-        // element-wise (r, c) walk cost ~25 VALU instructions per load/store pair.  Loads go out in batches of eight
-        // before any is consumed (a rolled load/store loop is one global round trip per iteration).
-        const int lr = fd.div(lane), lc = lane - lr * ndw;
-        const int rpb = fd.div(64);
-        const bool lane_on = lr < rpb;
-        const uint8_t *lsrc = img + (long long)(ini_y + lr) * pitch + (ini_x - xo) + 4 * lc;
-        uint32_t *ldst = reinterpret_cast<uint32_t *>(tile + lr * P) + lc;
-        const int band_bytes = rpb * pitch, band_dw = rpb * (P / 4);
-        for (int b0 = 0; b0 * rpb < th; b0 += 8) {
-            uint32_t tv[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (lane_on && (b0 + k) * rpb + lr < th) tv[k] = reinterpret_cast<const U32 *>(lsrc + (long long)(b0 + k) * band_bytes)->v;
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (lane_on && (b0 + k) * rpb + lr < th) ldst[(b0 + k) * band_dw] = tv[k];
+        const int lr0 = lane / DWR, lc = lane & (DWR - 1);
+        const int ndw = (tw + xo + 3) >> 2;             // dwords per row that hold cell pixels (<= 17)
+        const uint8_t *src = img + (long long)ini_y * pitch + (ini_x - xo) + (lr0 * pitch + 4 * lc);
+        const int full = th / RPL;
+        if (lc < ndw) {
+            for (int k = 0; k < full; k++)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(src + (long long)k * RPL * pitch),
+                                                 reinterpret_cast<uint32_t *>(tile + 256 * k), 4, 0, 0);
+            if (full * RPL + lr0 < th)                  // the last, partial group of rows never reads below the cell
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(src + (long long)full * RPL * pitch),
+                                                 reinterpret_cast<uint32_t *>(tile + 256 * full), 4, 0, 0);
         }
     }
-    {
+    {   // meanwhile: zero score tile (1-px zero rim included) and both bitmaps
         uint4 *z = reinterpret_cast<uint4 *>(sc);
         for (int i = lane; i < ((dh + 2) * SP + 15) / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
+        uint4 *zb = reinterpret_cast<uint4 *>(bm);
+        for (int i = lane; i < 2 * FAST_BM_ROWS * 8 / 16; i += 64) zb[i] = make_uint4(0, 0, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the direct loads have landed in LDS
     __syncthreads();
     STAMP(0);
-    const uint8_t *t0 = tile + 3 * P + xo + 3;
-    // ---- pretest, 4 horizontally adjacent pixels per lane: five aligned dword LDS loads (centre, W, E,
-    // N, S), packed-i16 differences; dark  <=> min(max(dN,dS), max(dE,dW)) >  th,
-    //                                bright <=> max(min(dN,dS), min(dE,dW)) < -th.
-    // Survivors are appended in row-major order (ballot prefix over the per-lane counts).
-    int nlist = 0;
-    {
-        const int tc_lo = xo + 3, tc_hi = xo + 2 + dw;      // tile columns of the detectable pixels
-        const int g_lo = tc_lo >> 2, gpr = (tc_hi >> 2) - g_lo + 1;
-        const int nitems = dh * gpr;
-        const FastDiv fg(gpr);
-        const i16x2 thv = { (short)min_th, (short)min_th };
-        for (int i0 = 0; i0 < nitems; i0 += 64) {
-            const int i = i0 + lane, ic = min(i, nitems - 1);
-            const int py = fg.div(ic), gcol = g_lo + (ic - py * gpr);
-            const uint32_t *rc = reinterpret_cast<const uint32_t *>(tile + (py + 3) * P) + gcol;
-            const unsigned C = rc[0], Wd = rc[-1], Ed = rc[1], N = rc[3 * (P / 4)], S = rc[-3 * (P / 4)];
-            const unsigned Wv = __builtin_amdgcn_alignbyte(C, Wd, 1), Ev = __builtin_amdgcn_alignbyte(Ed, C, 3);
-            unsigned bits = 0;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const unsigned sel = h ? 0x0c030c02u : 0x0c010c00u; // bytes (2h, 2h+1) -> two u16
-                const i16x2 c = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, C, sel));
-                // with d = c - x: min(max(dN,dS), max(dE,dW)) = c - A, A = max(min(N,S), min(E,W)), and
-                //                 max(min(dN,dS), min(dE,dW)) = c - B, B = min(max(N,S), max(E,W)); r = max(c - A, B - c)
-                const i16x2 n = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, N, sel)), s_ = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, S, sel));
-                const i16x2 e = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, Ev, sel)), w_ = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(0u, Wv, sel));
-                const i16x2 A = __builtin_elementwise_max(__builtin_elementwise_min(n, s_), __builtin_elementwise_min(e, w_));
-                const i16x2 B = __builtin_elementwise_min(__builtin_elementwise_max(n, s_), __builtin_elementwise_max(e, w_));
-                const i16x2 r = __builtin_elementwise_max(c - A, B - c);
-                const unsigned t = __builtin_bit_cast(unsigned, thv - r); // negative halves <=> r > th
-                bits |= (((t >> 15) & 1u) | ((t >> 30) & 2u)) << (2 * h);
-            }
-            // keep only pixels inside the detectable columns of a real item (tc_lo == 4: only the last group is partial)
-            const int tc = 4 * gcol;
-            unsigned valid = 0xFu;
-            if (tc + 3 > tc_hi) valid = 0xFu >> (tc + 3 - tc_hi);
-            bits &= (i < nitems) ? valid : 0u;
-            const int cnt = __popc(bits);
-            // exclusive prefix of cnt (0..4) over the wave from three ballots
-            const unsigned long long m0 = __ballot(cnt & 1), m1 = __ballot(cnt & 2), m2 = __ballot(cnt & 4);
-            int pos = nlist + __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0)) +
-                      2 * __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0)) +
-                      4 * __builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0));
-            const int e0 = (py << 6) + (tc - tc_lo); // tc - tc_lo may be negative for the first group
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (bits & (1u << j)) list[pos++] = (uint16_t)(e0 + j);
-            nlist += __popcll(m0) + 2 * __popcll(m1) + 4 * __popcll(m2);
-        }
-    }
-    __syncthreads();
-    STAMP(1);
-    // ---- full score on the compacted pixels (dense lanes); list entries are (py<<6 | px), ascending
-    for (int i = lane; i < nlist; i += 64) {
-        const int e = list[i], py = e >> 6, px = e & 63;
-        sc[(py + 1) * SP + px + 1] = (uint8_t)fast_score_full<P>(t0 + py * P + px, min_th);
-    }
-    __syncthreads();
-    STAMP(2);
-    // ---- NMS on the same list (only listed pixels can score > 0); one ballot per 64 entries
-    const int nchunk = (nlist + 63) >> 6;
-    unsigned long long any_ini = 0;
-    for (int ch = 0; ch < nchunk; ch++) {
-        const int i = ch * 64 + lane;
-        const int e = list[min(i, nlist - 1)], py = e >> 6, px = e & 63;
-        const uint8_t *c = sc + (py + 1) * SP + px + 1;
-        const int s = c[0];
-        const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)c[-SP - 1], (int)c[-SP])),
-                           max(max((int)c[-SP + 1], (int)c[SP - 1]), max((int)c[SP], (int)c[SP + 1])));
-        const bool is_max = (i < nlist) & (s > nb); // strict 3x3 maximum; s > nb >= 0 implies s > 0
-        const unsigned long long mm = __ballot(is_max), mi = __ballot(is_max & (s >= ini_th));
-        if (lane == 0) { masks[2 * ch] = mm; masks[2 * ch + 1] = mi; }
-        any_ini |= mi;
-    }
-    __syncthreads();
-    STAMP(3);
-    const int pick = any_ini ? 1 : 0; // the cell falls back to minThFAST only if iniThFAST kept nothing (:991-995)
+    const uint8_t *t0 = tile + 3 * P + xo + 3;           // detectable pixel (0, 0)
+    // pretest geometry: tile dwords 1 .. gpr of a row hold the detectable pixels (tile columns 4 .. dw + 3); one iteration =
+    // rpi whole rows, lane = (row lr, group gq); lanes beyond rpi * gpr idle with an empty pixel mask
+    const int gpr = (dw + 3) >> 2;
+    const FastDiv fg(gpr);
+    const int rpi = min(fg.div(64), 8);                   // (the last column's cells can be narrow: keep the row overrun <= 8)
+    const int lr = min(fg.div(lane), rpi), gq = lane - fg.div(lane) * gpr;
+    const int nvalid = max(1, min(4, dw - 4 * gq));      // only the last group of a row can be partial
+    const unsigned vmask = lr < rpi ? (0x80808080u >> (8 * (4 - nvalid))) : 0u;
+    const int bm_sh = 4 * (gq & 7);
     uint32_t *slot = cand + (long long)b * g->cand_total + rec.cand_slot;
-    int off = 0;
-    for (int ch = 0; ch < nchunk; ch++) {
-        const unsigned long long sel = masks[2 * ch + pick];
-        if (sel == 0) continue;
-        if ((sel >> lane) & 1ull) {
-            const int e = list[ch * 64 + lane], py = e >> 6, px = e & 63;
-            const int s = sc[(py + 1) * SP + px + 1];
-            const int X = ini_x + 3 + px - ORBX_MIN_BORDER, Y = ini_y + 3 + py - ORBX_MIN_BORDER;
-            const int o = off + __builtin_amdgcn_mbcnt_hi((unsigned)(sel >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sel, 0));
-            if (o < rec.cand_cap) slot[o] = (uint32_t)X | ((uint32_t)Y << 12) | ((uint32_t)s << 24);
+    int th_cur = ini_th, nsurv = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        // ---- 2. SWAR pretest.  With s = t + 1 and x7 = x >> 1 per byte: x < c - t  ==>  x7 <= c7 - s7 (dark) and
+        // x > c + t  ==>  (127 - x7) <= (127 - c7) - s7 (bright).  R = (c7 | 0x80) - s7 cannot borrow across bytes; its bit 7
+        // says c7 >= s7 (else no x can pass) and its low 7 bits are c7 - s7; (R | 0x80) - x7 then has bit 7 set iff
+        // x7 <= c7 - s7.  The bright side is the same on complemented values, folded into an add: KB + x7 with
+        // KB = (RB | 0x80) - 0x7f.  Corner candidates: (N | S) & (E | W) on either side.
+        {
+            const unsigned s7 = (unsigned)((th_cur + 1) >> 1) * 0x01010101u;
+            const uint8_t *pc = tile + (lr + 3) * P + 4 * (1 + gq);
+            uint32_t *pb = bm + lr * 2 + (gq >> 3);
+            for (int r0 = 0; r0 < dh; r0 += rpi, pc += rpi * P, pb += rpi * 2) {
+                const uint32_t *rc = reinterpret_cast<const uint32_t *>(pc);
+                const unsigned C = rc[0], Wd = rc[-1], Ed = rc[1], N = rc[3 * DWR], S = rc[-3 * DWR];
+                const unsigned Wv = __builtin_amdgcn_alignbyte(C, Wd, 1), Ev = __builtin_amdgcn_alignbyte(Ed, C, 3);
+                const unsigned c7 = (C >> 1) & 0x7f7f7f7fu, n7 = (N >> 1) & 0x7f7f7f7fu, u7 = (S >> 1) & 0x7f7f7f7fu,
+                               e7 = (Ev >> 1) & 0x7f7f7f7fu, w7 = (Wv >> 1) & 0x7f7f7f7fu;
+                const unsigned R = (c7 | 0x80808080u) - s7, RD = R | 0x80808080u;
+                const unsigned RB = ((c7 ^ 0x7f7f7f7fu) | 0x80808080u) - s7, KB = (RB | 0x80808080u) - 0x7f7f7f7fu;
+                const unsigned dark = ((RD - n7) | (RD - u7)) & ((RD - e7) | (RD - w7)) & R;
+                const unsigned bright = ((KB + n7) | (KB + u7)) & ((KB + e7) | (KB + w7)) & RB;
+                const unsigned any = (dark | bright) & vmask;
+                // bits 7, 15, 23, 31 -> one nibble: the multiplier routes bit 8k of (any >> 7) to bit 24 + k, no carries
+                const unsigned nib = (((any >> 7) * 0x01020408u) >> 24) << bm_sh;
+                atomicOr(pb, nib);   // rows >= dh of the last iteration land in bitmap rows that are never read
+            }
         }
-        off += __popcll(sel);
+        __syncthreads();
+        STAMP(1);
+        // ---- 3. bitmap -> ordered list of (py << 6 | px): lane = row, exclusive prefix of the row populations
+        int nlist;
+        {
+            unsigned lo = 0, hi = 0;
+            if (lane < dh) { const uint2 m = *reinterpret_cast<const uint2 *>(bm + 2 * lane); lo = m.x; hi = m.y; }
+            const int cnt = __popc(lo) + __popc(hi);
+            const int incl = wave_incl_scan(cnt);
+            nlist = __builtin_amdgcn_readlane(incl, 63);
+            uint16_t *lp = list + (incl - cnt);
+            const unsigned base = (unsigned)lane << 6;
+            while (lo) { *lp++ = (uint16_t)(base | (unsigned)__builtin_ctz(lo)); lo &= lo - 1; }
+            while (hi) { *lp++ = (uint16_t)(base | 32u | (unsigned)__builtin_ctz(hi)); hi &= hi - 1; }
+        }
+        __syncthreads();
+        // ---- 4. full score on the compacted pixels (dense lanes); entries ascend in (py, px)
+        for (int i = lane; i < nlist; i += 64) {
+            const int e = list[i], py = e >> 6, px = e & 63;
+            sc[(py + 1) * SP + px + 1] = (uint8_t)fast_score_full<P>(t0 + py * P + px, th_cur);
+        }
+        __syncthreads();
+        STAMP(2);
+        // ---- 5. strict 3x3 maximum on the same list (only listed pixels can score > 0) -> survivor bitmap
+        for (int i0 = 0; i0 < nlist; i0 += 64) {
+            const int i = i0 + lane;
+            const int e = list[min(i, nlist - 1)], py = e >> 6, px = e & 63;
+            const uint8_t *c = sc + (py + 1) * SP + px + 1;
+            const int s = c[0];
+            const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)c[-SP - 1], (int)c[-SP])),
+                               max(max((int)c[-SP + 1], (int)c[SP - 1]), max((int)c[SP], (int)c[SP + 1])));
+            const bool is_max = (i < nlist) & (s > nb);   // s > nb >= 0 implies a corner at th_cur
+            atomicOr(sv + 2 * py + (px >> 5), is_max ? 1u << (px & 31) : 0u);
+        }
+        __syncthreads();
+        STAMP(3);
+        {
+            unsigned lo = 0, hi = 0;
+            if (lane < dh) { const uint2 m = *reinterpret_cast<const uint2 *>(sv + 2 * lane); lo = m.x; hi = m.y; }
+            nsurv = __popc(lo) + __popc(hi);
+        }
+        // the cell falls back to minThFAST only if iniThFAST kept nothing (:991-995); pretest, scores and bitmaps of the
+        // second pass are supersets of the first, so nothing has to be cleared
+        if (__builtin_amdgcn_readfirstlane(__any(nsurv != 0)) || th_cur == min_th) break;
+        th_cur = min_th;
     }
-    if (lane == 0) *my_cnt = min(off, rec.cand_cap);
+    // ---- ordered (row-major) emission into the cell's candidate slots: lane = row
+    {
+        unsigned lo = 0, hi = 0;
+        if (lane < dh) { const uint2 m = *reinterpret_cast<const uint2 *>(sv + 2 * lane); lo = m.x; hi = m.y; }
+        const int incl = wave_incl_scan(nsurv);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        int o = incl - nsurv;
+        const int Y = ini_y + 3 + lane - ORBX_MIN_BORDER, X0 = ini_x + 3 - ORBX_MIN_BORDER;
+        const uint8_t *srow = sc + (lane + 1) * SP + 1;
+        while (lo) {
+            const int px = __builtin_ctz(lo);
+            lo &= lo - 1;
+            if (o < rec.cand_cap) slot[o] = (uint32_t)(X0 + px) | ((uint32_t)Y << 12) | ((uint32_t)srow[px] << 24);
+            o++;
+        }
+        while (hi) {
+            const int px = 32 + __builtin_ctz(hi);
+            hi &= hi - 1;
+            if (o < rec.cand_cap) slot[o] = (uint32_t)(X0 + px) | ((uint32_t)Y << 12) | ((uint32_t)srow[px] << 24);
+            o++;
+        }
+        if (lane == 0) *my_cnt = min(total, rec.cand_cap);
+    }
     STAMP(4);
 #ifdef ORBX_DIAG
     if (lane == 0) atomicAdd(&g_fast_stamp[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + 7], 1ull);
@@ -963,13 +987,16 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         }
         int max_w_cell = 0;
         for (int l = 0; l < e->nlevels; l++) if (G.lv[l].w_cell > max_w_cell) max_w_cell = G.lv[l].w_cell;
-        // tile row = w_cell + 6 (+3 alignment slack, +4 for the E neighbour dword) <= 48 ; score row = w_cell + 2 <= 40
-        G.fast_small = (max_w_cell + 6 + 3 + 4 <= 48 && max_w_cell + 2 <= 40) ? 1 : 0;
-        const int tp = G.fast_small ? 48 : ORBX_TILE_PITCH, sp = G.fast_small ? 40 : ORBX_SCORE_PITCH;
-        G.fast_lds_sc = (int)align_up((size_t)max_th * tp + 8, 16);
+        // tile row = 1 + w_cell + 6 pixels rounded up to dwords (+1 dword for the E neighbour of the last group) <= 64 bytes;
+        // score row = w_cell + 2 <= 40
+        G.fast_small = (((max_w_cell + 7 + 3) & ~3) + 4 <= 64 && max_w_cell + 2 <= 40) ? 1 : 0;
+        const int tp = G.fast_small ? 64 : ORBX_TILE_PITCH, sp = G.fast_small ? 40 : ORBX_SCORE_PITCH;
+        // tile rows: the cell, the whole rows of the last direct load, and the row overrun of the last pretest iteration
+        // (up to 7 rows of at least 8 groups) plus its S neighbour three rows further down
+        G.fast_lds_sc = (int)align_up((size_t)(max_th + 12) * tp, 16);
         G.fast_lds_list = G.fast_lds_sc + (int)align_up((size_t)(max_dh + 2) * sp, 16);
-        G.fast_lds_mask = G.fast_lds_list + (int)align_up((size_t)max_npx * 2 + 16, 16);
-        G.fast_lds_bytes = G.fast_lds_mask + 16 * ((max_npx + 63) / 64) + 16;
+        G.fast_lds_bm = G.fast_lds_list + (int)align_up((size_t)max_npx * 2 + 16, 16);
+        G.fast_lds_bytes = G.fast_lds_bm + 2 * 72 * 8;
     }
     // resize tables
     std::vector<int16_t> tabs(tab_units ? tab_units : 1);
@@ -1223,7 +1250,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
     }
     orbx_prof_begin(e, ORBX_STAGE_FAST, s);
     if (G.fast_small)
-        hipLaunchKernelGGL((k_fast<48, 40>), dim3((G.total_cells + 8 * FAST_XG - 1) / (8 * FAST_XG) * (8 * FAST_XG), batch), dim3(64), G.fast_lds_bytes, s, e->d_geom, e->d_cells, pr,
+        hipLaunchKernelGGL((k_fast<64, 40>), dim3((G.total_cells + 8 * FAST_XG - 1) / (8 * FAST_XG) * (8 * FAST_XG), batch), dim3(64), G.fast_lds_bytes, s, e->d_geom, e->d_cells, pr,
                            e->d_cell_cnt, e->d_cand, e->ini_th, e->min_th);
     else
         hipLaunchKernelGGL((k_fast<ORBX_TILE_PITCH, ORBX_SCORE_PITCH>), dim3((G.total_cells + 8 * FAST_XG - 1) / (8 * FAST_XG) * (8 * FAST_XG), batch), dim3(64), G.fast_lds_bytes, s,

@@ -153,8 +153,8 @@ static int mode_run(const char *in_path, const char *out_path)
     KeyFrame kfR, kfL;
     std::vector<MapPoint> storeR, storeL;
     const std::vector<float> sf = exL.GetScaleFactors(), s2 = exL.GetScaleSigmaSquares();
-    fill_keyframe(kfR, F.mvKeysRight, F.mDescriptorsRight, std::vector<float>(), storeR, 5, 7, sf, s2);
-    fill_keyframe(kfL, F.mvKeys, F.mDescriptors, F.mvuRight, storeL, 6, 4, sf, s2);
+    fill_keyframe(kfR, F.mvKeysRight, F.mDescriptorsRight, std::vector<float>(), storeR, 5, 3, sf, s2);
+    fill_keyframe(kfL, F.mvKeys, F.mDescriptors, F.mvuRight, storeL, 6, 3, sf, s2);
     ORBmatcher matcher(0.75f, true);
     std::vector<MapPoint *> vpF;
     const int n1 = matcher.SearchByBoW(&kfR, F, vpF);

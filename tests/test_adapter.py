@@ -130,8 +130,8 @@ def test_adapter_runs_and_matches_oracle(pkg, oracle, tmp_path):
     assert _f32(r["oneCallURight"]).tobytes() == our.tobytes()
     # ORBmatcher::SearchByBoW x 2 and SearchForTriangulation with the driver's MapPoint pattern
     iR, iL = np.arange(len(kR)), np.arange(len(kL))
-    has_r, bad_r = iR % 7 != 2, iR % 5 == 1
-    has_l, bad_l = iL % 4 != 2, iL % 6 == 1
+    has_r, bad_r = iR % 3 != 2, iR % 5 == 1
+    has_l, bad_l = iL % 3 != 2, iL % 6 == 1
     none_r = np.full(len(kR), -1.0, np.float32)
     f_frame = _featset(dL, kL, np.zeros(len(kL)), our)
     kf_r = _featset(dR, kR, has_r & ~bad_r, none_r)
