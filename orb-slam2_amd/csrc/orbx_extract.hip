@@ -235,14 +235,16 @@ __device__ unsigned long long g_desc_stamp[4096 * 8]; // same for k_desc
 #define DSTAMP(k) do { } while (0)
 #endif
 
-// P / SP = LDS pitches of the pixel tile and the score tile: (64, 40) when every cell of the pyramid is at most 38 px wide
-// (one direct load = 4 tile rows of 16 dwords), else (128, 64).
+// P / SP = LDS pitches of the pixel tile and the score tile: (48, 40) when every cell of the pyramid is at most 38 px wide
+// (one direct load = 5 tile rows of 12 dwords, 60 lanes), else (80, 64) (3 rows of 20 dwords).  Both tile pitches put rows
+// r and r + 8 (and no closer pair) on the same LDS banks: candidates line up along vertical image edges, and with a
+// 64-byte pitch (rows r, r + 2 on the same banks) the byte reads of the score network ran 3.4x the bank-conflict cycles.
 template <int P, int SP>
 __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const CellRec *__restrict__ cells, PyrRef pr,
                                              int *__restrict__ cell_cnt, uint32_t *__restrict__ cand, int ini_th, int min_th)
 {
     constexpr int DWR = P / 4;      // dwords per tile row = lanes per row of one direct load
-    constexpr int RPL = 64 / DWR;   // tile rows per direct load
+    constexpr int RPL = 64 / DWR;   // whole tile rows per direct load (lanes >= RPL * DWR stay idle)
     uint8_t *tile = fast_smem;
     uint8_t *sc = fast_smem + g->fast_lds_sc;
     uint16_t *list = reinterpret_cast<uint16_t *>(fast_smem + g->fast_lds_list);
@@ -274,20 +276,20 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
     // ---- 1. tile: the fetch starts one byte left of the cell (gfx950 global and LDS-direct loads need no alignment), so the
     // first detectable pixel always sits at tile column 4: every pretest group of four pixels is a whole LDS dword whatever
     // the cell's position or the caller's pitch.  Lane = (row lane / DWR, dword lane % DWR) of RPL whole rows per load; the data
-    // lands at tile + 256 * k + 4 * lane, i.e. row-major with pitch P.
+    // lands at tile + RPL * P * k + 4 * lane, i.e. row-major with pitch P.
     constexpr int xo = 1; // tile column of image column ini_x
     {
-        const int lr0 = lane / DWR, lc = lane & (DWR - 1);
+        const int lr0 = lane / DWR, lc = lane - lr0 * DWR;
         const int ndw = (tw + xo + 3) >> 2;             // dwords per row that hold cell pixels (<= 17)
         const uint8_t *src = img + (long long)ini_y * pitch + (ini_x - xo) + (lr0 * pitch + 4 * lc);
         const int full = th / RPL;
-        if (lc < ndw) {
+        if (lc < ndw && lr0 < RPL) {
             for (int k = 0; k < full; k++)
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(src + (long long)k * RPL * pitch),
-                                                 reinterpret_cast<uint32_t *>(tile + 256 * k), 4, 0, 0);
+                                                 reinterpret_cast<uint32_t *>(tile + RPL * P * k), 4, 0, 0);
             if (full * RPL + lr0 < th)                  // the last, partial group of rows never reads below the cell
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(src + (long long)full * RPL * pitch),
-                                                 reinterpret_cast<uint32_t *>(tile + 256 * full), 4, 0, 0);
+                                                 reinterpret_cast<uint32_t *>(tile + RPL * P * full), 4, 0, 0);
         }
     }
     {   // meanwhile: zero score tile (1-px zero rim included) and both bitmaps
@@ -987,10 +989,9 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         }
         int max_w_cell = 0;
         for (int l = 0; l < e->nlevels; l++) if (G.lv[l].w_cell > max_w_cell) max_w_cell = G.lv[l].w_cell;
-        // tile row = 1 + w_cell + 6 pixels rounded up to dwords (+1 dword for the E neighbour of the last group) <= 64 bytes;
-        // score row = w_cell + 2 <= 40
-        G.fast_small = (((max_w_cell + 7 + 3) & ~3) + 4 <= 64 && max_w_cell + 2 <= 40) ? 1 : 0;
-        const int tp = G.fast_small ? 64 : ORBX_TILE_PITCH, sp = G.fast_small ? 40 : ORBX_SCORE_PITCH;
+        // tile row = 1 + w_cell + 6 pixels rounded up to dwords <= 48 bytes; score row = w_cell + 2 <= 40
+        G.fast_small = (((max_w_cell + 7 + 3) & ~3) <= 48 && max_w_cell + 2 <= 40) ? 1 : 0;
+        const int tp = G.fast_small ? 48 : ORBX_TILE_PITCH, sp = G.fast_small ? 40 : ORBX_SCORE_PITCH;
         // tile rows: the cell, the whole rows of the last direct load, and the row overrun of the last pretest iteration
         // (up to 7 rows of at least 8 groups) plus its S neighbour three rows further down
         G.fast_lds_sc = (int)align_up((size_t)(max_th + 12) * tp, 16);
@@ -1250,7 +1251,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
     }
     orbx_prof_begin(e, ORBX_STAGE_FAST, s);
     if (G.fast_small)
-        hipLaunchKernelGGL((k_fast<64, 40>), dim3((G.total_cells + 8 * FAST_XG - 1) / (8 * FAST_XG) * (8 * FAST_XG), batch), dim3(64), G.fast_lds_bytes, s, e->d_geom, e->d_cells, pr,
+        hipLaunchKernelGGL((k_fast<48, 40>), dim3((G.total_cells + 8 * FAST_XG - 1) / (8 * FAST_XG) * (8 * FAST_XG), batch), dim3(64), G.fast_lds_bytes, s, e->d_geom, e->d_cells, pr,
                            e->d_cell_cnt, e->d_cand, e->ini_th, e->min_th);
     else
         hipLaunchKernelGGL((k_fast<ORBX_TILE_PITCH, ORBX_SCORE_PITCH>), dim3((G.total_cells + 8 * FAST_XG - 1) / (8 * FAST_XG) * (8 * FAST_XG), batch), dim3(64), G.fast_lds_bytes, s,

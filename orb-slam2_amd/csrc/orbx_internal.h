@@ -9,7 +9,7 @@
 #define ORBX_MAX_LEVELS 16
 #define ORBX_EDGE 19          // EDGE_THRESHOLD, reference src/ORBextractor.cc:74
 #define ORBX_MIN_BORDER 16    // EDGE_THRESHOLD-3, src/ORBextractor.cc:934
-#define ORBX_TILE_PITCH 128   // LDS pitch of a FAST cell tile when a cell is wider than 38 px (cell side <= 59 + 6 halo + 1): 2 rows per direct load
+#define ORBX_TILE_PITCH 80    // LDS pitch of a FAST cell tile when a cell is wider than 38 px (cell side <= 59 + 6 halo + 1): 3 rows per direct load
 #define ORBX_SCORE_PITCH 64   // LDS pitch of a FAST cell score tile (detect side <= 59 + 2)
 #define ORBX_MAX_DIM 4096     // packed candidate = x | y<<12 | score<<24
 #define ORBX_NODE_BITS 14     // quadtree node id bits inside the per-point label
@@ -42,7 +42,7 @@ struct Geom {
     int max_cells_level;    // max n_cells over levels
     int max_node_cap;
     int fast_lds_sc, fast_lds_list, fast_lds_bm, fast_lds_bytes; // LDS carve of k_fast
-    int fast_small;         // 1: k_fast<64,40> (every cell <= 38 px wide), 0: k_fast<128,64>
+    int fast_small;         // 1: k_fast<48,40> (every cell <= 38 px wide), 0: k_fast<80,64>
     LevelGeom lv[ORBX_MAX_LEVELS];
 };
 
