@@ -221,7 +221,15 @@ extern __shared__ __align__(16) unsigned char fast_smem[];
 #ifndef FAST_XG
 #define FAST_XG 4
 #endif
-#define FAST_BM_ROWS 72   // bitmap rows (u64 each): detect rows <= 59 plus the row overrun of the last pretest iteration
+// Launch constants of k_fast by value (kernel-argument segment): fetching them through the Geom pointer was one more level in
+// the chain of dependent scalar loads every wave starts with (arguments -> geometry -> cell record -> tile).
+struct FastArgs {
+    int total_cells;
+    int lds_sc, lds_list, lds_bm;   // LDS carve: score tile, candidate list, candidate bitmap (the survivor bitmap follows it)
+    int bm_rows;                    // bitmap rows (u64 each): tallest detect area plus the row overrun of the last pretest iteration
+    int ini_th, min_th;
+    long long cand_total;
+};
 
 #ifdef ORBX_DIAG
 __device__ unsigned long long g_fast_stamp[4096 * 8]; // diagnostic build only: summed phase cycles of k_fast, 4096 slots
@@ -240,16 +248,17 @@ __device__ unsigned long long g_desc_stamp[4096 * 8]; // same for k_desc
 // r and r + 8 (and no closer pair) on the same LDS banks: candidates line up along vertical image edges, and with a
 // 64-byte pitch (rows r, r + 2 on the same banks) the byte reads of the score network ran 3.4x the bank-conflict cycles.
 template <int P, int SP>
-__global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const CellRec *__restrict__ cells, PyrRef pr,
-                                             int *__restrict__ cell_cnt, uint32_t *__restrict__ cand, int ini_th, int min_th)
+__global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *__restrict__ cells, PyrRef pr,
+                                             int *__restrict__ cell_cnt, uint32_t *__restrict__ cand)
 {
     constexpr int DWR = P / 4;      // dwords per tile row = lanes per row of one direct load
     constexpr int RPL = 64 / DWR;   // whole tile rows per direct load (lanes >= RPL * DWR stay idle)
     uint8_t *tile = fast_smem;
-    uint8_t *sc = fast_smem + g->fast_lds_sc;
-    uint16_t *list = reinterpret_cast<uint16_t *>(fast_smem + g->fast_lds_list);
-    uint32_t *bm = reinterpret_cast<uint32_t *>(fast_smem + g->fast_lds_bm); // candidate bitmap, then survivor bitmap: u64 per row
-    uint32_t *sv = bm + 2 * FAST_BM_ROWS;
+    uint8_t *sc = fast_smem + fa.lds_sc;
+    uint16_t *list = reinterpret_cast<uint16_t *>(fast_smem + fa.lds_list);
+    uint32_t *bm = reinterpret_cast<uint32_t *>(fast_smem + fa.lds_bm); // candidate bitmap, then survivor bitmap: u64 per row
+    uint32_t *sv = bm + 2 * fa.bm_rows;
+    const int ini_th = fa.ini_th, min_th = fa.min_th;
     const int b = blockIdx.y, lane = threadIdx.x;
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8, speed only): remap so that FAST_XG
     // horizontally adjacent cells land on the same XCD (their halos share cache lines in that XCD's L2) while each
@@ -258,13 +267,26 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
     {
         const int bx = blockIdx.x, grp = bx / (8 * FAST_XG), r = bx - grp * (8 * FAST_XG);
         cell = grp * (8 * FAST_XG) + (r & 7) * FAST_XG + (r >> 3);
-        if (cell >= g->total_cells) return;
+        if (cell >= fa.total_cells) return;
     }
 #ifdef ORBX_DIAG
     unsigned long long _t_prev = __builtin_amdgcn_s_memtime();
 #endif
-    const CellRec rec = cells[cell];
-    int *my_cnt = cell_cnt + (long long)b * g->total_cells + cell;
+    // the 40-byte record as ten dwords (scalar loads; 16-bit fields fetched by themselves become vector loads on gfx950)
+    CellRec rec;
+    {
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(cells + cell);
+        uint32_t w[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) w[i] = cw[i];
+        rec.level = (short)(w[0] & 0xFFFF); rec.skip = (short)(w[0] >> 16);
+        rec.ini_x = (short)(w[1] & 0xFFFF); rec.ini_y = (short)(w[1] >> 16);
+        rec.tw = (short)(w[2] & 0xFFFF); rec.th = (short)(w[2] >> 16);
+        rec.pitch = (int)w[3]; rec.cand_cap = (int)w[4];
+        rec.pyr_off = (long long)(((unsigned long long)w[7] << 32) | w[6]);
+        rec.cand_slot = (long long)(((unsigned long long)w[9] << 32) | w[8]);
+    }
+    int *my_cnt = cell_cnt + (long long)b * fa.total_cells + cell;
     if (rec.skip) { // src/ORBextractor.cc:961-976 skip rules, evaluated on the host
         if (lane == 0) *my_cnt = 0;
         return;
@@ -296,7 +318,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
         uint4 *z = reinterpret_cast<uint4 *>(sc);
         for (int i = lane; i < ((dh + 2) * SP + 15) / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
         uint4 *zb = reinterpret_cast<uint4 *>(bm);
-        for (int i = lane; i < 2 * FAST_BM_ROWS * 8 / 16; i += 64) zb[i] = make_uint4(0, 0, 0, 0);
+        for (int i = lane; i < fa.bm_rows; i += 64) zb[i] = make_uint4(0, 0, 0, 0);   // 2 bitmaps x 8 bytes per row
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the direct loads have landed in LDS
     __syncthreads();
@@ -311,7 +333,7 @@ __global__ __launch_bounds__(64) void k_fast(const Geom *__restrict__ g, const C
     const int nvalid = max(1, min(4, dw - 4 * gq));      // only the last group of a row can be partial
     const unsigned vmask = lr < rpi ? (0x80808080u >> (8 * (4 - nvalid))) : 0u;
     const int bm_sh = 4 * (gq & 7);
-    uint32_t *slot = cand + (long long)b * g->cand_total + rec.cand_slot;
+    uint32_t *slot = cand + (long long)b * fa.cand_total + rec.cand_slot;
     int th_cur = ini_th, nsurv = 0;
     for (int pass = 0; pass < 2; pass++) {
         // ---- 2. SWAR pretest.  With s = t + 1 and x7 = x >> 1 per byte: x < c - t  ==>  x7 <= c7 - s7 (dark) and
@@ -994,10 +1016,12 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         const int tp = G.fast_small ? 48 : ORBX_TILE_PITCH, sp = G.fast_small ? 40 : ORBX_SCORE_PITCH;
         // tile rows: the cell, the whole rows of the last direct load, and the row overrun of the last pretest iteration
         // (up to 7 rows of at least 8 groups) plus its S neighbour three rows further down
-        G.fast_lds_sc = (int)align_up((size_t)(max_th + 12) * tp, 16);
+        // (row dh - 1 + 8 of the pretest reads its S neighbour at tile row th + 7)
+        G.fast_lds_sc = (int)align_up((size_t)(max_th + 8) * tp + 8, 16);
         G.fast_lds_list = G.fast_lds_sc + (int)align_up((size_t)(max_dh + 2) * sp, 16);
         G.fast_lds_bm = G.fast_lds_list + (int)align_up((size_t)max_npx * 2 + 16, 16);
-        G.fast_lds_bytes = G.fast_lds_bm + 2 * 72 * 8;
+        G.fast_bm_rows = (max_dh + 9 + 1) & ~1;          // even: the two bitmaps are zeroed as one run of 16-byte stores
+        G.fast_lds_bytes = G.fast_lds_bm + 2 * G.fast_bm_rows * 8;
     }
     // resize tables
     std::vector<int16_t> tabs(tab_units ? tab_units : 1);
@@ -1250,12 +1274,17 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
         orbx_prof_end(e, s);
     }
     orbx_prof_begin(e, ORBX_STAGE_FAST, s);
-    if (G.fast_small)
-        hipLaunchKernelGGL((k_fast<48, 40>), dim3((G.total_cells + 8 * FAST_XG - 1) / (8 * FAST_XG) * (8 * FAST_XG), batch), dim3(64), G.fast_lds_bytes, s, e->d_geom, e->d_cells, pr,
-                           e->d_cell_cnt, e->d_cand, e->ini_th, e->min_th);
-    else
-        hipLaunchKernelGGL((k_fast<ORBX_TILE_PITCH, ORBX_SCORE_PITCH>), dim3((G.total_cells + 8 * FAST_XG - 1) / (8 * FAST_XG) * (8 * FAST_XG), batch), dim3(64), G.fast_lds_bytes, s,
-                           e->d_geom, e->d_cells, pr, e->d_cell_cnt, e->d_cand, e->ini_th, e->min_th);
+    {
+        FastArgs fa;
+        fa.total_cells = G.total_cells; fa.lds_sc = G.fast_lds_sc; fa.lds_list = G.fast_lds_list; fa.lds_bm = G.fast_lds_bm;
+        fa.bm_rows = G.fast_bm_rows; fa.ini_th = e->ini_th; fa.min_th = e->min_th; fa.cand_total = G.cand_total;
+        const dim3 grid((G.total_cells + 8 * FAST_XG - 1) / (8 * FAST_XG) * (8 * FAST_XG), batch);
+        if (G.fast_small)
+            hipLaunchKernelGGL((k_fast<48, 40>), grid, dim3(64), G.fast_lds_bytes, s, fa, e->d_cells, pr, e->d_cell_cnt, e->d_cand);
+        else
+            hipLaunchKernelGGL((k_fast<ORBX_TILE_PITCH, ORBX_SCORE_PITCH>), grid, dim3(64), G.fast_lds_bytes, s, fa, e->d_cells, pr, e->d_cell_cnt,
+                               e->d_cand);
+    }
     orbx_prof_end(e, s);
     int *err_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;
     orbx_prof_begin(e, ORBX_STAGE_TREE, s);

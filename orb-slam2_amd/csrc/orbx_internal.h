@@ -41,7 +41,7 @@ struct Geom {
     long long pyr_bytes;    // per image, levels >= 1
     int max_cells_level;    // max n_cells over levels
     int max_node_cap;
-    int fast_lds_sc, fast_lds_list, fast_lds_bm, fast_lds_bytes; // LDS carve of k_fast
+    int fast_lds_sc, fast_lds_list, fast_lds_bm, fast_bm_rows, fast_lds_bytes; // LDS carve of k_fast
     int fast_small;         // 1: k_fast<48,40> (every cell <= 38 px wide), 0: k_fast<80,64>
     LevelGeom lv[ORBX_MAX_LEVELS];
 };
