@@ -12,8 +12,20 @@ MAX-reduction of the elapsed time) -> "scaling": "weak".
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (largest share of the HIP-event
 time measured live on the launch stream during the timed region) by its ALGORITHMIC bytes
-(DESIGN.md section "Kernels"); `cpu_baseline` times the CPU oracle (oracle/, a port: the reference
-itself needs OpenCV and cannot be built) on a bounded sample of the same workload on rank 0, N=1.
+(DESIGN.md section "Kernels") and, under `roofline.issue`, by its measured VALU instruction count against
+the chip's wave-instruction issue rate (the bound these integer kernels actually run into);
+`cpu_baseline` times the CPU oracle (oracle/, a port: the reference itself needs OpenCV and cannot be
+built) on a bounded sample of the same workload on rank 0, N=1.
+
+Outside the timed region the headline run also (rank 0 / every rank as noted):
+  * compares the LAST step's device outputs of every frame of the batch (keypoints, descriptors, uRight, depth) with the
+    CPU oracle's results for the distinct synthetic pairs -> "verified"; a mismatch makes the exit code non-zero;
+  * sweeps the batch size (frames per launch set) -> config.batch_sweep_frames_per_s;
+  * measures the host-fed rates -> config.host_fed: `batched` = pinned host frames -> double-buffered H2D on a copy
+    stream overlapped with compute on two handles -> D2H of all results; `single_stream_c_abi` = one camera stream through
+    orbx_extract_stereo_submit / _wait from a plain C client (examples/stereo_stream.c).  The headline `value` excludes PCIe;
+  * times the KITTI 2000-feature workload (BASELINE configs 2 / 5) on every rank with its own barrier-aligned window ->
+    config.kitti2000_frames_per_s (whole-job aggregate), so that an N-GPU line also carries BASELINE config 5.
 """
 import argparse
 import json
@@ -66,24 +78,178 @@ def algorithmic_bytes(stage, n_images, n_pairs, nkp_avg):
     return n_pairs * nkp_avg * 12
 
 
-def cpu_baseline(frames):
+def _oracle_frame(oL, oR, left, right):
+    """one stereo frame the way the reference runs it: L/R extraction on two threads (src/Frame.cc:82-85), then the matcher"""
+    from oracle import oracle_py
+    res = {}
+    tl = threading.Thread(target=lambda: res.__setitem__("l", oL.extract(left)))
+    tr = threading.Thread(target=lambda: res.__setitem__("r", oR.extract(right)))
+    tl.start(); tr.start(); tl.join(); tr.join()
+    ur, dp = oracle_py.stereo_match(oL, oR, res["l"][0], res["l"][1], res["r"][0], res["r"][1], BF, MIN_Z)
+    return res["l"][0], res["l"][1], res["r"][0], res["r"][1], ur, dp
+
+
+def oracle_results(pairs):
+    """CPU oracle outputs for the distinct synthetic pairs: the checker of the `verified` block"""
+    from oracle import oracle_py
+    oL, oR = oracle_py.Oracle(NFEAT, 1.2, NLEVELS, 20, 7), oracle_py.Oracle(NFEAT, 1.2, NLEVELS, 20, 7)
+    return [_oracle_frame(oL, oR, l, r) for l, r in pairs]
+
+
+def cpu_baseline(frames, all_core_frames=4):
     """the CPU oracle driven like the reference: stereo = 2 threads (L/R), src/Frame.cc:82-85"""
     from oracle import oracle_py
     oL, oR = oracle_py.Oracle(NFEAT, 1.2, NLEVELS, 20, 7), oracle_py.Oracle(NFEAT, 1.2, NLEVELS, 20, 7)
     times = []
     for left, right in frames:
-        res = {}
         t0 = time.perf_counter()
-        tl = threading.Thread(target=lambda: res.__setitem__("l", oL.extract(left)))
-        tr = threading.Thread(target=lambda: res.__setitem__("r", oR.extract(right)))
-        tl.start(); tr.start(); tl.join(); tr.join()
-        oracle_py.stereo_match(oL, oR, res["l"][0], res["l"][1], res["r"][0], res["r"][1], BF, MIN_Z)
+        _oracle_frame(oL, oR, left, right)
         times.append(time.perf_counter() - t0)
     times = np.array(times)
-    return {"value": round(float(len(times) / times.sum()), 3), "unit": "frames/s", "cores": 2, "kind": "port",
-            "sample": f"{len(times)} stereo frames {W}x{H} @{NFEAT} feats through oracle/liborb_oracle.so "
-                      f"(-O3 -march=native), L/R extraction on 2 threads, median {np.median(times) * 1e3:.1f} ms/frame",
-            "host_cpus": os.cpu_count()}
+    out = {"value": round(float(len(times) / times.sum()), 3), "unit": "frames/s", "cores": 2, "kind": "port",
+           "sample": f"{len(times)} stereo frames {W}x{H} @{NFEAT} feats through oracle/liborb_oracle.so: a scalar C port "
+                     "(-O3 -march=native; no SIMD FAST / GaussianBlur / resize as OpenCV has them, so OpenCV itself would be several "
+                     f"times faster), L/R extraction on 2 threads, median {np.median(times) * 1e3:.1f} ms/frame",
+           "host_cpus": os.cpu_count()}
+    # SURVEY 8d (ii): all cores, one independent camera stream per core (each stream extracts L then R on its own core)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))      # the share of host cores one GPU gets on the bench box
+    done = [0] * cores
+
+    def stream(ci):
+        a, b = oracle_py.Oracle(NFEAT, 1.2, NLEVELS, 20, 7), oracle_py.Oracle(NFEAT, 1.2, NLEVELS, 20, 7)
+        for i in range(all_core_frames):
+            left, right = frames[(ci + i) % len(frames)]
+            kl, dl = a.extract(left); kr, dr = b.extract(right)
+            oracle_py.stereo_match(a, b, kl, dl, kr, dr, BF, MIN_Z)
+            done[ci] += 1
+    ths = [threading.Thread(target=stream, args=(ci,)) for ci in range(cores)]
+    t0 = time.perf_counter()
+    for t in ths: t.start()
+    for t in ths: t.join()
+    el = time.perf_counter() - t0
+    out["all_cores"] = {"value": round(sum(done) / el, 2), "unit": "frames/s", "cores": cores,
+                        "sample": f"{cores} independent streams (one per available core, threads in the C oracle), {all_core_frames} stereo frames each"}
+    return out
+
+
+def load_issue_model():
+    """measured VALU wave-instructions per image of every kernel (rocprofv3 SQ_INSTS_VALU, tools/collect_sq.py) and the
+    issue-rate model of DESIGN.md section 5: 1024 SIMDs, mix-weighted cycles per wave64 VALU instruction from
+    tools/ubench/op_cost.hip (full-rate opcodes ~2.5 cycles, the rest ~4.3)"""
+    path = os.path.join(ROOT, "profiles", "r02_sq_counters.json")
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path))
+
+
+class StereoRig:
+    """device-resident batch of B stereo frames on one handle: the launch set of one bench step"""
+
+    def __init__(self, pkg, torch, dev, local, w, h, nfeat, B, pairs, stream=None):
+        self.pkg, self.torch, self.B, self.w, self.h = pkg, torch, B, w, h
+        self.pitch = (w + 63) // 64 * 64
+        host = np.zeros((2 * B, h, self.pitch), np.uint8)
+        for i in range(B):
+            host[i, :, :w] = pairs[i % len(pairs)][0]
+            host[B + i, :, :w] = pairs[i % len(pairs)][1]
+        self.imgs = torch.from_numpy(host).to(dev)
+        self.ex = pkg.ORBextractor(nfeat, 1.2, NLEVELS, 20, 7, device=local, max_size=(w, h), max_batch=2 * B)
+        self.cap = cap = self.ex.max_keypoints(w, h)
+        self.kps = torch.zeros((2 * B, cap, 7), dtype=torch.float32, device=dev)
+        self.desc = torch.zeros((2 * B, cap, 32), dtype=torch.uint8, device=dev)
+        self.nout = torch.zeros(2 * B, dtype=torch.int32, device=dev)
+        self.ur = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+        self.dp = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+        self.stream = stream or torch.cuda.Stream(device=dev)
+        self.sp = self.stream.cuda_stream
+
+    def step(self, imgs=None):
+        B, cap = self.B, self.cap
+        src = self.imgs if imgs is None else imgs
+        self.ex.extract_batch_device(src.data_ptr(), self.h * self.pitch, self.pitch, 2 * B, self.w, self.h, self.kps.data_ptr(),
+                                     self.desc.data_ptr(), cap, self.nout.data_ptr(), self.sp)
+        self.pkg.orbx.stereo_match_batch_device(self.ex, 0, self.ex, B, B, self.kps.data_ptr(), self.desc.data_ptr(), self.nout.data_ptr(),
+                                                self.kps[B:].data_ptr(), self.desc[B:].data_ptr(), self.nout[B:].data_ptr(), cap,
+                                                BF, MIN_Z, self.ur.data_ptr(), self.dp.data_ptr(), self.sp)
+
+    def verify(self, expect, npairs):
+        """every frame of the batch (frame i holds pair i % npairs) against the oracle's outputs for that pair, byte for byte"""
+        self.stream.synchronize()
+        B, cap = self.B, self.cap
+        n = self.nout.cpu().numpy()
+        k = self.kps.cpu().numpy().view(np.uint8).reshape(2 * B, cap, 28)
+        d = self.desc.cpu().numpy(); ur = self.ur.cpu().numpy(); dp = self.dp.cpu().numpy()
+        bad = []
+        for i in range(B):
+            kL, dL, kR, dR, our, odp = expect[i % npairs]
+            nl, nr = int(n[i]), int(n[B + i])
+            ok = (nl == len(kL) and nr == len(kR) and k[i, :nl].tobytes() == kL.tobytes() and d[i, :nl].tobytes() == dL.tobytes() and
+                  k[B + i, :nr].tobytes() == kR.tobytes() and d[B + i, :nr].tobytes() == dR.tobytes() and
+                  ur[i, :nl].tobytes() == our.tobytes() and dp[i, :nl].tobytes() == odp.tobytes())
+            if not ok:
+                bad.append(i)
+        return {"frames": B, "distinct_pairs": npairs, "checked": "keypoints (28 B each), descriptors, uRight, depth of every frame of the last step",
+                "against": "oracle/liborb_oracle.so", "bit_exact": not bad, "mismatching_frames": bad[:8]}
+
+
+def host_fed_batched(pkg, torch, dev, local, pairs, B, steps):
+    """frames start in pinned HOST memory: H2D of batch k+1 on a copy stream while batch k computes, D2H of batch k-1's
+    results on a second copy stream; two handles (two compute streams) alternate.  One FRAME crosses PCIe as 2 images in and
+    n / keypoints / descriptors / uRight / depth out."""
+    rigs = [StereoRig(pkg, torch, dev, local, W, H, NFEAT, B, pairs) for _ in range(2)]
+    h_in = [torch.from_numpy(r.imgs.cpu().numpy()).pin_memory() for r in rigs]
+    d_in = [torch.empty_like(r.imgs) for r in rigs]
+    h_out = [[torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in (r.nout, r.kps, r.desc, r.ur, r.dp)] for r in rigs]
+    cin, cout = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    ev_in = [torch.cuda.Event() for _ in rigs]; ev_done = [torch.cuda.Event() for _ in rigs]; ev_out = [torch.cuda.Event() for _ in rigs]
+
+    def submit(j):
+        r = rigs[j]
+        with torch.cuda.stream(cin):
+            cin.wait_event(ev_done[j])          # the previous batch on this handle has finished reading its level 0
+            d_in[j].copy_(h_in[j], non_blocking=True)
+            ev_in[j].record(cin)
+        r.stream.wait_event(ev_in[j])
+        r.stream.wait_event(ev_out[j])          # its previous results have left the device buffers
+        r.step(d_in[j])
+        ev_done[j].record(r.stream)
+        with torch.cuda.stream(cout):
+            cout.wait_event(ev_done[j])
+            for ht, dt in zip(h_out[j], (r.nout, r.kps, r.desc, r.ur, r.dp)):
+                ht.copy_(dt, non_blocking=True)
+            ev_out[j].record(cout)
+
+    for j in range(2):
+        ev_done[j].record(rigs[j].stream); ev_out[j].record(cout)
+    for i in range(4):
+        submit(i % 2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        submit(i % 2)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out_bytes = sum(t.numel() * t.element_size() for t in h_out[0]) / B
+    return {"frames_per_s": round(B * steps / el, 1), "frames_per_batch": B, "handles": 2, "batches": steps,
+            "h2d_bytes_per_frame": int(h_in[0].numel() / B), "d2h_bytes_per_frame": int(out_bytes),
+            "pcie_gbytes_per_s": round((h_in[0].numel() / B + out_bytes) * B * steps / el / 1e9, 2)}
+
+
+def host_fed_c_client(streams, frames=1500):
+    """one camera stream (or several) through the pipelined host-pointer C ABI, measured by the plain C client"""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "stereo_stream")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "--streams", str(streams), "--frames", str(frames), "--nfeat", str(NFEAT)], capture_output=True, text=True, timeout=180)
+        return json.loads(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 else {"error": (out.stderr or out.stdout)[-200:]}
+    except Exception as exc:    # measurement leg only: never fail the bench line over it
+        return {"error": str(exc)[:200]}
 
 
 def main():
@@ -97,6 +263,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=240, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--bow-host-path", action="store_true", help="euroc_bow: per-frame host-pointer ComputeBoW + search (round-1 form)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs (tiled to the batch)")
+    ap.add_argument("--extras", type=int, default=1, help="0 = only the timed headline region (profiling runs): no batch sweep, host-fed or KITTI-2000 legs")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of the last step's outputs")
     args = ap.parse_args()
     global W, H, NFEAT
     W, H, NFEAT, kind, def_batch, metric = WORKLOADS[args.workload]
@@ -118,6 +286,7 @@ def main():
     torch.cuda.set_device(dev)
     rank, world = st.init(backend, device_id=dev if backend == "nccl" else None)   # "nccl" is RCCL on ROCm; no-op for a single process
     assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
+    dist_dev = dev if backend == "nccl" else None
 
     pkg.lib()  # fails loudly if liborbx.so is missing: there is no fallback path
     from tools import synth
@@ -128,29 +297,26 @@ def main():
     pitch = (W + 63) // 64 * 64
     stereo = kind == "stereo"
     NI = 2 * B if stereo else B                        # images per step
-    host = np.zeros((NI, H, pitch), np.uint8)
+    rig = None
     if stereo:
         pairs = [synth.stereo_pair(seed0 + i, W, H)[:2] for i in range(args.distinct)]
-        for i in range(B):
-            host[i, :, :W] = pairs[i % len(pairs)][0]
-            host[B + i, :, :W] = pairs[i % len(pairs)][1]
+        rig = StereoRig(pkg, torch, dev, local, W, H, NFEAT, B, pairs)
+        ex, imgs, kps, desc, nout, ur, stream, cap = rig.ex, rig.imgs, rig.kps, rig.desc, rig.nout, rig.ur, rig.stream, rig.cap
     else:
         pairs = None
+        host = np.zeros((NI, H, pitch), np.uint8)
         monos = [synth.image(seed0 + i, W, H, nshapes=max(400, W * H // 311)) for i in range(args.distinct)]
         for i in range(B):
             host[i, :, :W] = monos[i % len(monos)]
-    imgs = torch.from_numpy(host).to(dev)
-
-    ex = pkg.ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local, max_size=(W, H), max_batch=NI)
-    cap = ex.max_keypoints(W, H)
-    kps = torch.zeros((NI, cap, 7), dtype=torch.float32, device=dev)
-    desc = torch.zeros((NI, cap, 32), dtype=torch.uint8, device=dev)
-    nout = torch.zeros(NI, dtype=torch.int32, device=dev)
-    ur = torch.zeros((B, cap), dtype=torch.float32, device=dev)
-    dp = torch.zeros((B, cap), dtype=torch.float32, device=dev)
-    stream = torch.cuda.Stream(device=dev)
+        imgs = torch.from_numpy(host).to(dev)
+        ex = pkg.ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local, max_size=(W, H), max_batch=NI)
+        cap = ex.max_keypoints(W, H)
+        kps = torch.zeros((NI, cap, 7), dtype=torch.float32, device=dev)
+        desc = torch.zeros((NI, cap, 32), dtype=torch.uint8, device=dev)
+        nout = torch.zeros(NI, dtype=torch.int32, device=dev)
+        ur = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+        stream = torch.cuda.Stream(device=dev)
     sp = stream.cuda_stream
-    orbx = pkg.orbx
 
     def extract():
         ex.extract_batch_device(imgs.data_ptr(), H * pitch, pitch, NI, W, H, kps.data_ptr(), desc.data_ptr(), cap, nout.data_ptr(), sp)
@@ -189,17 +355,17 @@ def main():
         bow = {"db": pkg.BowDatabase(kfs, device=local), "voc": voc, "frames": frames_fs, "ms": 0.0, "tms": 0.0, "queries": 0, "matches": 0,
                "fr": pkg.BowFrames(NI, cap, device=local),
                "d_match": torch.zeros((NI, 500, cap), dtype=torch.int32, device=dev), "d_nm": torch.zeros((NI, 500), dtype=torch.int32, device=dev),
-               "ev": [], "host_path": args.bow_host_path}
+               "ev": [], "host_path": args.bow_host_path, "kf_feats": int(sum(len(k_["desc"]) for k_ in kfs)),
+               "kf_list": int(sum(len(k_["feat"]) for k_ in kfs)), "kf_nodes": int(sum(len(k_["node_id"]) for k_ in kfs))}
 
     def step():
         if bow is not None and prof_on[0]:
             ex.profile_enable(True)   # BoW work sits between two extractions on this stream: start a fresh event chain
-        extract()
         if stereo:
-            orbx.stereo_match_batch_device(ex, 0, ex, B, B, kps.data_ptr(), desc.data_ptr(), nout.data_ptr(),
-                                           kps[B:].data_ptr(), desc[B:].data_ptr(), nout[B:].data_ptr(), cap,
-                                           BF, MIN_Z, ur.data_ptr(), dp.data_ptr(), sp)
-        elif bow is not None and not bow["host_path"]:
+            rig.step()
+            return
+        extract()
+        if bow is not None and not bow["host_path"]:
             # device-resident chain: Frame::ComputeBoW for the batch, then every keyframe against every frame, all on `sp`
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record(stream)
@@ -237,7 +403,7 @@ def main():
     ex.profile_read(reset=True)
     prof_on[0] = True
     ex.profile_enable(True)           # HIP events on the launch stream, around every kernel of the timed steps
-    elapsed = st.timed_steps(step, args.steps, local_sync, world, device=dev if backend == "nccl" else None)   # barrier + sync both sides, MAX over ranks
+    elapsed = st.timed_steps(step, args.steps, local_sync, world, device=dist_dev)   # barrier + sync both sides, MAX over ranks
     ex.profile_enable(False)
     prof = ex.profile_read(reset=True)
     ex.sync(sp)
@@ -247,6 +413,12 @@ def main():
     matched = float((ur.cpu().numpy() >= 0).sum() / B) if stereo else 0.0
     value = st.aggregate_rate(B, args.steps, world, elapsed)
 
+    # ---- outside the timed region: the last step's outputs against the CPU oracle (rank 0)
+    verified, expect = None, None
+    if stereo and rank == 0 and not args.no_verify:
+        expect = oracle_results(pairs)
+        verified = rig.verify(expect, len(pairs))
+
     # dominant kernel + roofline (per launch: total stage time / launches; resize = 7 launches per step)
     stage_ms = {k: v[0] for k, v in prof.items()}
     dom = max(stage_ms, key=stage_ms.get)
@@ -254,29 +426,54 @@ def main():
     avg_ms = stage_ms[dom] / launches
     per_step_launches = launches / args.steps
     bytes_per_launch = algorithmic_bytes(dom, NI, B, nkp_avg) / per_step_launches
-    bow_dev = None
+    bow_dev, bow_models = None, None
     if bow is not None and bow["ev"]:
         t_tr = sum(a.elapsed_time(b_) for a, b_, _ in bow["ev"]); t_se = sum(b_.elapsed_time(c) for _, b_, c in bow["ev"])
         bow_dev = {"transform_ms_per_step": round(t_tr / len(bow["ev"]), 4), "search_ms_per_step": round(t_se / len(bow["ev"]), 4)}
         bow["matches"] = int(bow["d_nm"].sum().item()) * len(bow["ev"])
-        if t_se > stage_ms[dom]:   # the search launch dominates: one launch per step, B_bow of SURVEY.md 8d per (keyframe, frame) pair
+        if t_se > stage_ms[dom]:   # the search launch dominates: one launch per step
             dom, avg_ms, per_step_launches = "bow<0>", t_se / len(bow["ev"]), 1.0
-            bytes_per_launch = 500 * B * (32 + 4 + 1 + 4) * 2 * nkp_avg + 500 * B * 4 * nkp_avg
+            # COMPULSORY bytes of one launch (the map side is read once per query batch): the 500-keyframe map
+            # (list-order descriptors 32 B + flag 1 B per listed feature, node ids 4 B + offsets 4 B per node, angles 4 B per
+            # feature) once + the B frames' sides once + one int32 match row per (keyframe, frame) pair out.  The round-1 model
+            # (SURVEY's B_bow per pair x 16 000 pairs) re-counted the frame side 500x and the map side B x: kept as
+            # `per_pair_model_bytes` for comparison.
+            frame_side = B * nkp_avg * (32 + 1 + 4 + 4) + B * 100 * 8
+            map_side = bow["kf_list"] * 33 + bow["kf_nodes"] * 8 + bow["kf_feats"] * 4
+            bytes_per_launch = map_side + frame_side + 500 * B * 4 * nkp_avg
+            bow_models = {"compulsory_bytes": int(bytes_per_launch), "of_which_match_rows_out": int(500 * B * 4 * nkp_avg),
+                          "per_pair_model_bytes": int(500 * B * (32 + 4 + 1 + 4) * 2 * nkp_avg + 500 * B * 4 * nkp_avg)}
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None   # HBM bytes per launch from the rocprofv3 PMC passes (tools/collect_pmc.py), same workload only
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if args.workload == "stereo1000" and os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        kern = tj.get("kernels", {}).get("k_" + dom)
-        if kern and tj.get("images_per_launch"):
-            traffic = int(kern["hbm_bytes_per_launch"] * NI / tj["images_per_launch"])
+    for tname in ("r02_traffic.json", "r01_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", tname if args.workload == "stereo1000" else tname.replace("traffic", "traffic_" + args.workload))
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            kern = tj.get("kernels", {}).get("k_" + dom.split("<")[0])
+            if kern and tj.get("images_per_launch"):
+                traffic = int(kern["hbm_bytes_per_launch"] * NI / tj["images_per_launch"])
+            break
     roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in stage_ms.items()}}
+    if bow_models:
+        roofline["byte_models"] = bow_models
+    im = load_issue_model()
+    if im and args.workload == "stereo1000" and ("k_" + dom) in im.get("kernels", {}):
+        kk = im["kernels"]["k_" + dom]
+        per_image = kk["SQ_INSTS_VALU"] / im["images_per_launch"]
+        valu = per_image * NI / per_step_launches
+        cyc = im["issue_model"]["cycles_per_valu_inst"]["k_" + dom]
+        peak = im["issue_model"]["simds"] * im["issue_model"]["clock_ghz"] * 1e9 / cyc
+        roofline["issue"] = {"valu_insts": int(valu), "cycles_per_valu_inst": cyc, "peak_wave_insts_per_s": round(peak, 0),
+                             "frac": round(valu / (avg_ms * 1e-3) / peak, 4),
+                             "note": "wave64 VALU instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/r02_sq_counters.json) / launch time, against "
+                                     "1024 SIMDs x clock / mix-weighted cycles per instruction measured by tools/ubench/op_cost.hip (DESIGN.md section 5)"}
 
     desc_txt = {"stereo": f"KITTI-shape stereo {W}x{H}, nFeatures={NFEAT}/eye, 8 levels, FAST 20/7: "
-                          "extract(L)+extract(R)+ComputeStereoMatches; 1 frame = 1 stereo pair",
+                          "extract(L)+extract(R)+ComputeStereoMatches; 1 frame = 1 stereo pair; images RESIDENT IN HBM when the timed region "
+                          "starts (kernel throughput: excludes PCIe; the host-fed rates are under config.host_fed)",
                 "mono": f"mono {W}x{H}, nFeatures={NFEAT}, 8 levels, FAST 20/7: extract only",
                 "bow": f"mono {W}x{H}, nFeatures={NFEAT}: extract + ComputeBoW (synthetic k=10 L=6 vocabulary on device) + SearchByBoW(ratio 0.75, "
                        "checkOri) of every frame against a device-resident 500-keyframe synthetic map; device-resident chain "
@@ -290,6 +487,8 @@ def main():
                       "keypoints_per_image": round(nkp_avg, 1), "stereo_matches_per_frame": round(matched, 1),
                       "parallelism": f"{world} independent camera-stream batches, one per GPU"},
            "roofline": roofline}
+    if verified is not None:
+        out["verified"] = verified
     if bow is not None and bow["queries"]:
         if bow_dev:
             out["config"]["bow_device_chain"] = bow_dev
@@ -297,6 +496,48 @@ def main():
             out["config"]["bow_ms_per_query_frame_incl_host"] = round(bow["ms"] / bow["queries"], 4)
             out["config"]["of_which_bow_transform_ms"] = round(bow["tms"] / bow["queries"], 4)
         out["config"]["bow_matches_per_query_frame"] = round(bow["matches"] / bow["queries"], 1)
+
+    # ---- extra legs, all outside the timed headline region
+    if stereo and args.extras and args.workload == "stereo1000":
+        # BASELINE configs 2 / 5 on every rank: KITTI 2000 features per eye, its own barrier-aligned window
+        del rig, imgs, kps, desc, nout, ur
+        torch.cuda.empty_cache()
+        B2 = max(B // 2, 1)
+        pairs2 = pairs[:4]
+        rig2 = StereoRig(pkg, torch, dev, local, W, H, 2000, B2, pairs2)
+        for _ in range(2):
+            rig2.step()
+
+        def sync2():
+            rig2.stream.synchronize(); torch.cuda.synchronize()
+        k2 = max(5, args.steps // 3)
+        el2 = st.timed_steps(rig2.step, k2, sync2, world, device=dist_dev)
+        out["config"]["kitti2000_frames_per_s"] = {"value": round(st.aggregate_rate(B2, k2, world, el2), 1), "frames_per_step_per_gpu": B2, "steps": k2,
+                                                   "keypoints_per_image": round(float(rig2.nout.float().mean().item()), 1),
+                                                   "what": "BASELINE configs 2 / 5: 1241x376 @2000 feats per eye, extract L+R + stereo match, whole-job aggregate over n_gpus"}
+        del rig2
+        torch.cuda.empty_cache()
+        if rank == 0 and world == 1:
+            sweep = {}
+            for bs in (1, 8, 64, 256):
+                r = StereoRig(pkg, torch, dev, local, W, H, NFEAT, bs, pairs)
+                for _ in range(3):
+                    r.step()
+                r.stream.synchronize()
+                ks = max(10, min(200, 2048 // bs))
+                t0 = time.perf_counter()
+                for _ in range(ks):
+                    r.step()
+                r.stream.synchronize()
+                sweep[str(bs)] = round(bs * ks / (time.perf_counter() - t0), 1)
+                del r
+            out["config"]["batch_sweep_frames_per_s"] = sweep
+            torch.cuda.empty_cache()
+            hf = {"batched": host_fed_batched(pkg, torch, dev, local, pairs, 64, 40)}
+            torch.cuda.synchronize()
+            hf["single_stream_c_abi"] = host_fed_c_client(1)
+            hf["four_streams_c_abi"] = host_fed_c_client(4)
+            out["config"]["host_fed"] = hf
     if rank == 0 and world == 1 and args.cpu_frames > 0 and stereo:
         out["cpu_baseline"] = cpu_baseline([pairs[i % len(pairs)] for i in range(args.cpu_frames)])
     elif rank == 0:
@@ -305,6 +546,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if verified is not None and not verified["bit_exact"]:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -112,6 +112,25 @@ int orbx_extract_stereo(orbx_extractor *e, const uint8_t *img_left, const uint8_
                         float bf, float min_z, orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out,
                         float *u_right, float *depth);
 
+/* Pipelined form of orbx_extract_stereo for a camera stream fed from host memory: _submit enqueues one stereo frame
+ * (upload on a copy stream, both extractions + ComputeStereoMatches on the compute stream, download on a second copy
+ * stream) and returns a ticket without waiting; _wait blocks until that frame's results are on the host and copies them
+ * out (same output contract as orbx_extract_stereo).  Up to orbx_pipeline_depth() frames may be in flight per handle:
+ * frame i+1 uploads and frame i-1 downloads while frame i computes.  Tickets must be waited for in submission order;
+ * a submit with all slots in flight fails with ORBX_E_INVALID.  If img_left / img_right lie in memory obtained from
+ * orbx_pinned_alloc and stride == w, the upload reads them in place (they must stay untouched until _wait returns);
+ * otherwise they are copied to the handle's pinned staging inside _submit and may be reused at once.
+ * Replaces the per-frame sequence of Frame::Frame(imLeft, imRight, ...) (src/Frame.cc:82-97) in the frame loop of
+ * Examples/Stereo/stereo_kitti.cc:68-117. */
+int orbx_pipeline_depth(void);
+int orbx_extract_stereo_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t *img_right, int w, int h, size_t stride,
+                               float bf, float min_z, int *ticket);
+int orbx_extract_stereo_wait(orbx_extractor *e, int ticket, orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out,
+                             float *u_right, float *depth);
+/* page-locked host memory for frame buffers (uploads from it need no staging copy) */
+void *orbx_pinned_alloc(size_t bytes);
+void orbx_pinned_free(void *p);
+
 /* B images of one size in one pass (host pointers). kps[B*cap], desc[B*cap*32], n_out[B]. */
 int orbx_extract_batch(orbx_extractor *e, const uint8_t *const *imgs, int batch, int w, int h, size_t stride,
                        orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out);

@@ -1196,6 +1196,17 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *e)
                      e->d_lvl_cnt, e->d_lvl_kp, e->d_out_kps, e->d_out_desc, e->d_out_n, e->d_out_ur, e->d_out_depth, e->d_st_dist, e->d_st_entries };
     for (void *p : ptrs) if (p) hipFree(p);
     for (void *p : e->scratch) if (p) hipFree(p);
+    for (PipeSlot &s : e->pipe) {
+        if (s.ev_d2h) hipEventSynchronize(s.ev_d2h);
+        void *dp[] = { s.d_in, s.d_kps, s.d_desc, s.d_n, s.d_ur, s.d_z };
+        for (void *p : dp) if (p) hipFree(p);
+        if (s.h_in) hipHostFree(s.h_in);
+        if (s.h_out) hipHostFree(s.h_out);
+        hipEvent_t evs[] = { s.ev_h2d, s.ev_done, s.ev_d2h };
+        for (hipEvent_t ev : evs) if (ev) hipEventDestroy(ev);
+    }
+    if (e->copy_in) hipStreamDestroy(e->copy_in);
+    if (e->copy_out) hipStreamDestroy(e->copy_out);
     if (e->h_stage_in) hipHostFree(e->h_stage_in);
     if (e->h_out) hipHostFree(e->h_out);
     if (e->h_flag) hipHostFree(e->h_flag);
@@ -1319,6 +1330,8 @@ int orbx_quiesce(orbx_extractor *e)
 {
     ORBX_HIP(hipStreamSynchronize(e->stream));
     if (e->last_launch_stream && e->last_launch_stream != e->stream) ORBX_HIP(hipStreamSynchronize(e->last_launch_stream));
+    if (e->copy_in) ORBX_HIP(hipStreamSynchronize(e->copy_in));
+    if (e->copy_out) ORBX_HIP(hipStreamSynchronize(e->copy_out));
     return ORBX_OK;
 }
 
@@ -1561,6 +1574,150 @@ extern "C" int orbx_extract_stereo(orbx_extractor *e, const uint8_t *img_left, c
     }
     memcpy(u_right, e->h_out + o_ur, 4 * (size_t)hn[0]);
     memcpy(depth, e->h_out + o_z, 4 * (size_t)hn[0]);
+    return ORBX_OK;
+}
+
+// ---- pipelined host-pointer stereo frames (a camera stream fed from host memory)
+
+extern "C" int orbx_pipeline_depth(void) { return ORBX_PIPE_DEPTH; }
+
+extern "C" void *orbx_pinned_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { orbx_set_error("hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+extern "C" void orbx_pinned_free(void *p) { if (p) hipHostFree(p); }
+
+static bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+static int pipe_slot_prepare(orbx_extractor *e, PipeSlot &s, size_t in_bytes, int need)
+{
+    if (!s.ev_h2d) {
+        ORBX_HIP(hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming));
+        ORBX_HIP(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+        ORBX_HIP(hipEventCreateWithFlags(&s.ev_d2h, hipEventDisableTiming));
+    }
+    if (in_bytes > s.in_cap) {
+        if (s.h_in) ORBX_HIP(hipHostFree(s.h_in));
+        if (s.d_in) ORBX_HIP(hipFree(s.d_in));
+        s.h_in = nullptr; s.d_in = nullptr; s.in_cap = 0;
+        ORBX_HIP(hipHostMalloc((void **)&s.h_in, in_bytes, hipHostMallocDefault));
+        ORBX_HIP(hipMalloc((void **)&s.d_in, in_bytes));
+        s.in_cap = in_bytes;
+    }
+    if (need > s.out_cap) {
+        void **ps[] = { &s.d_kps, &s.d_desc, &s.d_n, (void **)&s.d_ur, (void **)&s.d_z };
+        for (void **p : ps) if (*p) { ORBX_HIP(hipFree(*p)); *p = nullptr; }
+        ORBX_HIP(hipMalloc(&s.d_kps, sizeof(orbx_keypoint) * 2 * (size_t)need));
+        ORBX_HIP(hipMalloc(&s.d_desc, (size_t)64 * need));
+        ORBX_HIP(hipMalloc(&s.d_n, 16));
+        ORBX_HIP(hipMalloc((void **)&s.d_ur, 4 * (size_t)need));
+        ORBX_HIP(hipMalloc((void **)&s.d_z, 4 * (size_t)need));
+        s.out_cap = need;
+    }
+    const size_t out_bytes = 64 + align_up(sizeof(orbx_keypoint) * 2 * (size_t)need, 64) + (size_t)64 * need + 2 * align_up(4 * (size_t)need, 64);
+    if (out_bytes > s.h_out_cap) {
+        if (s.h_out) ORBX_HIP(hipHostFree(s.h_out));
+        s.h_out = nullptr; s.h_out_cap = 0;
+        ORBX_HIP(hipHostMalloc((void **)&s.h_out, out_bytes, hipHostMallocDefault));
+        s.h_out_cap = out_bytes;
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_stereo_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t *img_right, int w, int h, size_t stride,
+                                          float bf, float min_z, int *ticket)
+{
+    if (!e || !img_left || !img_right || !ticket || w < 1 || h < 1 || stride < (size_t)w || !(min_z > 0)) {
+        orbx_set_error("orbx_extract_stereo_submit: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    if (e->max_batch < 2) { orbx_set_error("orbx_extract_stereo_submit needs an extractor created with max_batch >= 2"); return ORBX_E_INVALID; }
+    ORBX_HIP(hipSetDevice(e->device));
+    int rc = orbx_prepare_geometry(e, w, h);   // waits for everything in flight only when the image size changes
+    if (rc) return rc;
+    PipeSlot &s = e->pipe[e->pipe_next % ORBX_PIPE_DEPTH];
+    if (s.busy) { orbx_set_error("all %d pipeline slots are in flight: call orbx_extract_stereo_wait first", ORBX_PIPE_DEPTH); return ORBX_E_INVALID; }
+    const int need = e->geom.kp_total;
+    const bool in_place = stride == (size_t)w && is_pinned_host(img_left) && is_pinned_host(img_right);
+    const size_t pitch = in_place ? (size_t)w : align_up(w, 64), img_bytes = pitch * h;
+    if (!e->copy_in) {
+        ORBX_HIP(hipStreamCreateWithFlags(&e->copy_in, hipStreamNonBlocking));
+        ORBX_HIP(hipStreamCreateWithFlags(&e->copy_out, hipStreamNonBlocking));
+    }
+    if ((rc = pipe_slot_prepare(e, s, 2 * align_up(w, 64) * (size_t)h, need))) return rc;
+    // upload: the slot's device input was last read by the kernels of the frame that used it ORBX_PIPE_DEPTH submissions ago,
+    // which its _wait has already seen finish (ev_d2h follows ev_done), so the copy stream may overwrite it right away
+    if (in_place) {
+        ORBX_HIP(hipMemcpyAsync(s.d_in, img_left, img_bytes, hipMemcpyHostToDevice, e->copy_in));
+        ORBX_HIP(hipMemcpyAsync(s.d_in + img_bytes, img_right, img_bytes, hipMemcpyHostToDevice, e->copy_in));
+    } else {
+        const uint8_t *eyes[2] = { img_left, img_right };
+        for (int i = 0; i < 2; i++) {
+            uint8_t *dst = s.h_in + img_bytes * i;
+            if (stride == pitch) memcpy(dst, eyes[i], img_bytes);
+            else for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * pitch, eyes[i] + (size_t)y * stride, (size_t)w);
+        }
+        ORBX_HIP(hipMemcpyAsync(s.d_in, s.h_in, img_bytes * 2, hipMemcpyHostToDevice, e->copy_in));
+    }
+    ORBX_HIP(hipEventRecord(s.ev_h2d, e->copy_in));
+    ORBX_HIP(hipStreamWaitEvent(e->stream, s.ev_h2d, 0));
+    e->prof_chain = false;
+    rc = orbx_extract_batch_device(e, s.d_in, img_bytes, pitch, 2, w, h, s.d_kps, s.d_desc, need, s.d_n, nullptr);
+    if (rc) return rc;
+    orbx_keypoint *dk = (orbx_keypoint *)s.d_kps;
+    uint8_t *dd = (uint8_t *)s.d_desc;
+    int *dn = (int *)s.d_n;
+    rc = orbx_stereo_match_batch_device(e, 0, e, 1, 1, dk, dd, dn, dk + need, dd + (size_t)32 * need, dn + 1, need, bf, min_z, s.d_ur, s.d_z, nullptr);
+    if (rc) return rc;
+    // the kernel error flag of this frame travels with its counts; cleared for the next frame on the same (in-order) stream
+    int *d_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;
+    ORBX_HIP(hipMemcpyAsync(dn + 2, d_flag, sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+    ORBX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), e->stream));
+    ORBX_HIP(hipEventRecord(s.ev_done, e->stream));
+    // download on the second copy stream
+    const size_t o_kps = 64, o_desc = o_kps + align_up(sizeof(orbx_keypoint) * 2 * (size_t)need, 64), o_ur = o_desc + (size_t)64 * need,
+                 o_z = o_ur + align_up(4 * (size_t)need, 64);
+    ORBX_HIP(hipStreamWaitEvent(e->copy_out, s.ev_done, 0));
+    ORBX_HIP(hipMemcpyAsync(s.h_out, dn, 3 * sizeof(int), hipMemcpyDeviceToHost, e->copy_out));
+    ORBX_HIP(hipMemcpyAsync(s.h_out + o_kps, dk, sizeof(orbx_keypoint) * 2 * (size_t)need, hipMemcpyDeviceToHost, e->copy_out));
+    ORBX_HIP(hipMemcpyAsync(s.h_out + o_desc, dd, (size_t)64 * need, hipMemcpyDeviceToHost, e->copy_out));
+    ORBX_HIP(hipMemcpyAsync(s.h_out + o_ur, s.d_ur, 4 * (size_t)need, hipMemcpyDeviceToHost, e->copy_out));
+    ORBX_HIP(hipMemcpyAsync(s.h_out + o_z, s.d_z, 4 * (size_t)need, hipMemcpyDeviceToHost, e->copy_out));
+    ORBX_HIP(hipEventRecord(s.ev_d2h, e->copy_out));
+    s.busy = true; s.cap = need; s.ticket = e->pipe_next;
+    *ticket = e->pipe_next++;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_stereo_wait(orbx_extractor *e, int ticket, orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out,
+                                        float *u_right, float *depth)
+{
+    if (!e || !kps || !desc || !n_out || !u_right || !depth || ticket < 0) { orbx_set_error("orbx_extract_stereo_wait: invalid argument"); return ORBX_E_INVALID; }
+    PipeSlot &s = e->pipe[ticket % ORBX_PIPE_DEPTH];
+    if (!s.busy || s.ticket != ticket) { orbx_set_error("ticket %d is not in flight", ticket); return ORBX_E_INVALID; }
+    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(hipEventSynchronize(s.ev_d2h));
+    s.busy = false;
+    const int need = s.cap;
+    if (cap < need) { orbx_set_error("keypoint capacity %d < orbx_max_keypoints() = %d", cap, need); return ORBX_E_CAPACITY; }
+    const size_t o_kps = 64, o_desc = o_kps + align_up(sizeof(orbx_keypoint) * 2 * (size_t)need, 64), o_ur = o_desc + (size_t)64 * need,
+                 o_z = o_ur + align_up(4 * (size_t)need, 64);
+    const int *hn = reinterpret_cast<const int *>(s.h_out);
+    if (hn[2]) { orbx_set_error("quadtree kernel reported a node-table overflow"); return ORBX_E_CAPACITY; }
+    for (int i = 0; i < 2; i++) {
+        n_out[i] = hn[i];
+        memcpy(kps + (size_t)i * cap, s.h_out + o_kps + sizeof(orbx_keypoint) * (size_t)need * i, sizeof(orbx_keypoint) * (size_t)hn[i]);
+        memcpy(desc + (size_t)i * cap * 32, s.h_out + o_desc + (size_t)32 * need * i, (size_t)32 * hn[i]);
+    }
+    memcpy(u_right, s.h_out + o_ur, 4 * (size_t)hn[0]);
+    memcpy(depth, s.h_out + o_z, 4 * (size_t)hn[0]);
     return ORBX_OK;
 }
 

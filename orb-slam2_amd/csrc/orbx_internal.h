@@ -60,6 +60,16 @@ static_assert(sizeof(CellRec) == 40, "CellRec layout");
 
 struct ProfEvent { hipEvent_t a, b; int stage; bool owns_a; };
 
+// One frame in flight of the pipelined host-pointer stereo path (orbx_extract_stereo_submit / _wait)
+struct PipeSlot {
+    uint8_t *h_in, *d_in; size_t in_cap;     // both eyes, pinned host staging and device level 0
+    uint8_t *h_out; size_t h_out_cap;        // pinned: [n0 n1 flag | keypoints x2 | descriptors x2 | uRight | depth]
+    void *d_kps, *d_desc, *d_n; float *d_ur, *d_z; int out_cap;
+    hipEvent_t ev_h2d, ev_done, ev_d2h;      // input landed / kernels finished / results landed in h_out
+    int cap, ticket; bool busy;
+};
+#define ORBX_PIPE_DEPTH 4
+
 struct orbx_extractor {
     int device;
     int nfeatures, nlevels, ini_th, min_th;
@@ -95,6 +105,8 @@ struct orbx_extractor {
     int *d_st_dist; size_t st_cap;         // SAD per left keypoint (or -1)
     void *d_st_entries; size_t st_ent_cap;  // row table entries (vRowIndices): (iR | octave<<16, x)
     void *scratch[8]; size_t scratch_cap[8]; // host-API upload buffers
+    // pipelined stereo frames: copies ride their own streams so that frame i+1 uploads and frame i-1 downloads while frame i computes
+    PipeSlot pipe[ORBX_PIPE_DEPTH]; hipStream_t copy_in, copy_out; int pipe_next;
     // state of the most recent extract
     const uint8_t *last_img0; size_t last_img_stride, last_pitch; int last_batch;
     // profiling

@@ -68,6 +68,10 @@ def lib():
     L.orbx_max_keypoints.argtypes = [vp, i, i]
     L.orbx_extract.argtypes = [vp, vp, i, i, sz, vp, vp, i, ip]
     L.orbx_extract_stereo.argtypes = [vp, vp, vp, i, i, sz, f, f, vp, vp, i, vp, vp, vp]
+    L.orbx_extract_stereo_submit.argtypes = [vp, vp, vp, i, i, sz, f, f, ip]
+    L.orbx_extract_stereo_wait.argtypes = [vp, i, vp, vp, i, vp, vp, vp]
+    L.orbx_pinned_alloc.argtypes = [sz]; L.orbx_pinned_alloc.restype = vp
+    L.orbx_pinned_free.argtypes = [vp]; L.orbx_pinned_free.restype = None
     L.orbx_extract_color.argtypes = [vp, vp, i, i, sz, i, i, vp, vp, i, ip, vp, sz]
     L.orbx_extract_batch.argtypes = [vp, vp, i, i, i, sz, vp, vp, i, vp]
     L.orbx_extract_batch_device.argtypes = [vp, vp, sz, sz, i, i, i, vp, vp, i, vp, vp]
@@ -119,6 +123,34 @@ def lib():
     L.orbx_debug_set_bow_form.argtypes = [i]
     _lib = L
     return L
+
+
+def pipeline_depth():
+    return lib().orbx_pipeline_depth()
+
+
+class _Pinned:
+    def __init__(self, nbytes):
+        self.ptr = lib().orbx_pinned_alloc(nbytes)
+        if not self.ptr:
+            raise OrbxError(-5, lib().orbx_last_error().decode(errors="replace"))
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().orbx_pinned_free(self.ptr); self.ptr = None
+
+
+def pinned_array(shape, dtype=np.uint8):
+    """numpy array in page-locked host memory (orbx_pinned_alloc): uploads from it need no staging copy"""
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    owner = _Pinned(nbytes)
+    buf = (C.c_uint8 * nbytes).from_address(owner.ptr)
+    a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+    _PINNED_OWNERS[id(buf)] = owner      # keep the allocation alive as long as the process (frame buffers are long-lived)
+    return a
+
+
+_PINNED_OWNERS = {}
 
 
 def debug_set_bow_form(form):
@@ -229,6 +261,30 @@ class ORBextractor:
         kps = np.zeros((2, cap), KP_DTYPE); desc = np.zeros((2, cap, 32), np.uint8); n = np.zeros(2, np.int32)
         ur = np.zeros(cap, np.float32); z = np.zeros(cap, np.float32)
         _check(self._L.orbx_extract_stereo(self._h, _p(L_), _p(R_), w, h, L_.strides[0], bf, min_z, _p(kps), _p(desc), cap, _p(n), _p(ur), _p(z)))
+        return (kps[0, :n[0]].copy(), desc[0, :n[0]].copy(), kps[1, :n[1]].copy(), desc[1, :n[1]].copy(), ur[:n[0]].copy(), z[:n[0]].copy())
+
+    # -- pipelined form: up to pipeline_depth() frames in flight, uploads / downloads overlap the kernels of the neighbouring frames
+    def extract_stereo_submit(self, imLeft, imRight, bf, min_z):
+        """-> ticket; the images are copied (or, if they live in pinned_array() memory, must stay untouched until the wait)"""
+        if imLeft.shape != imRight.shape or imLeft.ndim != 2 or imLeft.dtype != np.uint8 or imLeft.strides != imRight.strides or imLeft.strides[1] != 1:
+            raise OrbxError(-1, "left and right image must be equal 2-D uint8 arrays with unit column stride")
+        h, w = imLeft.shape
+        t = C.c_int()
+        _check(self._L.orbx_extract_stereo_submit(self._h, imLeft.ctypes.data, imRight.ctypes.data, w, h, imLeft.strides[0], bf, min_z, C.byref(t)))
+        self._pipe_shape = (w, h)
+        return t.value
+
+    def extract_stereo_wait(self, ticket, copy=True):
+        w, h = self._pipe_shape
+        cap = self.max_keypoints(w, h)
+        b = getattr(self, "_pipe_out", None)
+        if b is None or b[0].shape[1] != cap:
+            b = self._pipe_out = (np.zeros((2, cap), KP_DTYPE), np.zeros((2, cap, 32), np.uint8), np.zeros(2, np.int32),
+                                  np.zeros(cap, np.float32), np.zeros(cap, np.float32))
+        kps, desc, n, ur, z = b
+        _check(self._L.orbx_extract_stereo_wait(self._h, ticket, _p(kps), _p(desc), cap, _p(n), _p(ur), _p(z)))
+        if not copy:      # views into buffers that the next wait overwrites (measurement loops)
+            return kps[0, :n[0]], desc[0, :n[0]], kps[1, :n[1]], desc[1, :n[1]], ur[:n[0]], z[:n[0]]
         return (kps[0, :n[0]].copy(), desc[0, :n[0]].copy(), kps[1, :n[1]].copy(), desc[1, :n[1]].copy(), ur[:n[0]].copy(), z[:n[0]].copy())
 
     def extract_color(self, image, rgb=True, want_gray=False):

@@ -488,3 +488,51 @@ def test_stereo_border_windows(pkg, oracle):
     our, odp = oracle.stereo_match(oL, oR, kL2, dL2, kR2, dR2, bf, b)
     assert ur.tobytes() == our.tobytes() and dp.tobytes() == odp.tobytes()
     assert (our[idx] >= 0).sum() >= 5 or (our >= 0).sum() > 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pinned", [False, True])
+def test_extract_stereo_pipelined(pkg, oracle, pinned):
+    """orbx_extract_stereo_submit / _wait: frames in flight up to the pipeline depth, results per ticket equal the oracle's
+    (and the synchronous one-call form); resubmitting a slot before its wait is refused"""
+    w, h, nf = 1241, 376, 1000
+    bf, b = 386.1448, 386.1448 / 718.856
+    depth = pkg.orbx.pipeline_depth()
+    nframes = 2 * depth + 1
+    pairs = [synth.stereo_pair(700 + i, w, h)[:2] for i in range(3)]
+    pairs[1] = (np.full((h, w), 50, np.uint8), np.full((h, w), 50, np.uint8))      # a featureless frame inside the stream
+    exp = []
+    for l, r in pairs:
+        oL, oR = oracle.Oracle(nf, 1.2, 8, 20, 7), oracle.Oracle(nf, 1.2, 8, 20, 7)
+        kL, dL = oL.extract(l); kR, dR = oR.extract(r)
+        exp.append((kL, dL, kR, dR) + tuple(oracle.stereo_match(oL, oR, kL, dL, kR, dR, bf, b)))
+    if pinned:
+        bufs = []
+        for l, r in pairs:
+            pl, pr_ = pkg.orbx.pinned_array((h, w)), pkg.orbx.pinned_array((h, w))
+            pl[:] = l; pr_[:] = r
+            bufs.append((pl, pr_))
+        pairs = bufs
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7, device=0, max_size=(w, h), max_batch=2)
+    tickets = []
+    for i in range(depth):
+        tickets.append(ex.extract_stereo_submit(pairs[i % 3][0], pairs[i % 3][1], bf, b))
+    with pytest.raises(pkg.OrbxError):                       # every slot is in flight
+        ex.extract_stereo_submit(pairs[0][0], pairs[0][1], bf, b)
+    done = 0
+    for i in range(depth, nframes + depth):
+        t = tickets.pop(0)
+        got = ex.extract_stereo_wait(t)
+        e = exp[done % 3]
+        for g_, e_ in zip(got, e):
+            assert g_.tobytes() == e_.tobytes(), f"frame {done} (ticket {t})"
+        done += 1
+        if i < nframes:
+            tickets.append(ex.extract_stereo_submit(pairs[i % 3][0], pairs[i % 3][1], bf, b))
+    assert done == nframes and not tickets
+    with pytest.raises(pkg.OrbxError):                       # a ticket can be waited for once
+        ex.extract_stereo_wait(t)
+    # the synchronous forms still work on the same handle afterwards
+    got = ex.extract_stereo(np.asarray(pairs[2][0]), np.asarray(pairs[2][1]), bf, b)
+    for g_, e_ in zip(got, exp[2]):
+        assert g_.tobytes() == e_.tobytes()

@@ -26,7 +26,7 @@ env = dict(os.environ, TMPDIR="/tmp")
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(out_dir, counter)
     subprocess.check_call(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-                           "python3", os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--cpu-frames", "0",
+                           "python3", os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--cpu-frames", "0", "--extras", "0", "--no-verify",
                            "--batch", str(batch)], cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
     acc = collections.defaultdict(list)

@@ -17,7 +17,7 @@ env = dict(os.environ, TMPDIR="/tmp")
 for i, counters in enumerate(PASSES):
     d = os.path.join(ROOT, "gpurun_out", f"sq_{tag}", f"pass{i}")
     rc = subprocess.call(["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-                          "python3", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-frames", "0"],
+                          "python3", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-frames", "0", "--extras", "0", "--no-verify"],
                          cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
     if rc != 0 or not files:
