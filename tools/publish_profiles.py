@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Copies the measurement summaries of gpurun_out/final_<tag>/ (tools/final_meas.sh) into profiles/ (tracked) and merges the SQ
+counters with the static instruction mix (tools/isa_mix.py) into profiles/<tag>_sq_counters.json, the file bench.py's
+roofline.issue reads.  Runs in the build container after the gpurun call:  python tools/publish_profiles.py r02"""
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join(ROOT, "gpurun_out", f"final_{tag}")
+dst = os.path.join(ROOT, "profiles")
+
+
+def last_json_line(path):
+    lines = [l for l in open(path).read().splitlines() if l.startswith("{")]
+    return json.loads(lines[-1])
+
+
+for name, out in (("bench_default.json", f"{tag}_z_bench_default.json"), ("bench_under_rocprof.json", f"{tag}_z_bench_under_rocprof.json"),
+                  ("stereo2000.json", f"{tag}_z_bench_stereo2000.json"), ("fhd4000.json", f"{tag}_z_bench_fhd4000.json"),
+                  ("euroc_bow.json", f"{tag}_z_bench_euroc_bow.json")):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        json.dump(last_json_line(p), open(os.path.join(dst, out), "w"), indent=1)
+stats = glob.glob(os.path.join(src, "prof", "*", "*kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, f"{tag}_z_kernel_stats.csv"))
+tr = os.path.join(ROOT, "gpurun_out", f"{tag}_traffic.json")
+if os.path.exists(tr):
+    shutil.copy(tr, os.path.join(dst, f"{tag}_traffic.json"))
+sq = os.path.join(ROOT, "gpurun_out", f"{tag}_sq.json")
+if os.path.exists(sq):
+    mix = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py")]))
+    kern = json.load(open(sq))
+    cyc = {}
+    for k in kern:
+        cands = [v for n, v in mix["kernels"].items() if n.split("<")[0] == k]
+        if cands:
+            cyc[k] = cands[0]["cycles_per_valu_inst"]
+    doc = {"note": "rocprofv3 --pmc SQ counters, 4 passes (tools/collect_sq.py), per-launch means summed over XCDs/SEs as rocprofv3 reports them; "
+                   "default bench workload (512 images per launch).  SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count in units of 4 cycles. "
+                   "issue_model: wave64 VALU issue cost per SIMD by opcode class measured with tools/ubench/op_cost.hip on the same GPU "
+                   "(profiles/%s_op_cost.txt), weighted with each kernel's static instruction mix (tools/isa_mix.py)." % tag,
+           "images_per_launch": 512, "kernels": kern,
+           "issue_model": {"simds": 1024, "clock_ghz": 2.4, "fast_class_cycles": mix["fast_cycles"], "slow_class_cycles": mix["slow_cycles"],
+                           "cycles_per_valu_inst": cyc, "static_mix": mix["kernels"]}}
+    json.dump(doc, open(os.path.join(dst, f"{tag}_sq_counters.json"), "w"), indent=1)
+for name in ("op_cost.txt", "issue_rate.txt", "hostfed_c.log"):
+    p = os.path.join(ROOT, "gpurun_out", name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, f"{tag}_{name.replace('.log', '.txt')}"))
+print("published:", sorted(f for f in os.listdir(dst) if f.startswith(tag)))
