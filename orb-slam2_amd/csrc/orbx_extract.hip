@@ -472,7 +472,8 @@ extern __shared__ __align__(16) unsigned char tree_smem[];
 __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const int *__restrict__ cell_cnt,
                                               const uint32_t *__restrict__ cand, uint32_t *__restrict__ g_pts,
                                               uint16_t *__restrict__ g_nid, int *__restrict__ lvl_cnt,
-                                              uint32_t *__restrict__ lvl_kp, int lds_pts_cap, int *__restrict__ err_flag)
+                                              uint32_t *__restrict__ lvl_kp, int lds_pts_cap, int *__restrict__ err_flag,
+                                              unsigned char *__restrict__ g_tab, long long g_tab_stride)
 {
     constexpr int NB = ORBX_NODE_BITS, NMASK = (1 << NB) - 1;
     // x = image, y = level: workgroups are dealt to the 8 XCDs by linear id % 8, so every XCD gets the same mix of
@@ -480,7 +481,13 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
     const int l = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
     const LevelGeom &L = g->lv[l];
     const int cap = g->max_node_cap; // multiple of 4
-    int *cnt = reinterpret_cast<int *>(tree_smem);
+    // node tables (76 B per leaf): in LDS when they fit beside the points (every ORB-SLAM2 configuration: <= ~1900 leaves per
+    // level), else in this workgroup's slice of an HBM workspace (any nfeatures the reference accepts up to the 14-bit node
+    // id: __syncthreads orders the workgroup's own global stores and loads, the same code runs on either memory)
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const size_t tab_bytes = (size_t)cap * 76;
+    unsigned char *tab = g_tab ? g_tab + (size_t)wg * (size_t)g_tab_stride : tree_smem;
+    int *cnt = reinterpret_cast<int *>(tab);
     int *cnt_n = cnt + cap;
     uint2 *box = reinterpret_cast<uint2 *>(cnt_n + cap);
     uint2 *box_n = box + cap;
@@ -491,7 +498,8 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
     int *a3 = a2 + cap;                             // unsplit flags -> ranks
     int *a4 = a3 + cap;                             // phase-2 gains
     int *ncarr = a4 + cap;                          // non-empty children per node (0 = not split)
-    int *cellpref = ncarr + cap;                    // [max_cells_level + 4]
+    int *cellpref = g_tab ? reinterpret_cast<int *>(tree_smem) : ncarr + cap;   // [max_cells_level + 4], always LDS
+    (void)tab_bytes;
     uint32_t *lpts = reinterpret_cast<uint32_t *>(cellpref + ((g->max_cells_level + 4) & ~3));
     uint16_t *lnid = reinterpret_cast<uint16_t *>(lpts + lds_pts_cap);
     __shared__ int s_w[4];
@@ -929,21 +937,22 @@ static int ensure(T **p, size_t *cap, size_t need)
     return ORBX_OK;
 }
 
+static const size_t kTreeLdsLimit = 150 * 1024;
+static size_t tree_tab_bytes(const Geom &G) { return (size_t)G.max_node_cap * (4 + 4 + 8 + 8 + 16 + 16 + 4 * 5); }
+static size_t tree_fixed_lds(const Geom &G) { return (size_t)((G.max_cells_level + 4) & ~3) * 4 + 64; }
+// the node tables (76 B per leaf) go to LDS when they fit there together with the cell prefix array and at least 3072 points
+static bool tree_tab_in_lds(const Geom &G) { return tree_tab_bytes(G) + tree_fixed_lds(G) + (size_t)3072 * 6 <= kTreeLdsLimit; }
 static size_t tree_lds_bytes(const Geom &G, int lds_pts_cap)
 {
-    const size_t cap = G.max_node_cap;
-    return cap * (4 + 4 + 8 + 8 + 16 + 16 + 4 * 5) + (size_t)((G.max_cells_level + 4) & ~3) * 4 + (size_t)lds_pts_cap * 6 + 64;
+    return (tree_tab_in_lds(G) ? tree_tab_bytes(G) : 0) + tree_fixed_lds(G) + (size_t)lds_pts_cap * 6;
 }
-static const size_t kTreeLdsLimit = 150 * 1024;
-// LDS point capacity of k_tree: about a level's typical candidate count, bounded so that
-// several (level, image) workgroups fit one CU and so that the node tables (76 B per leaf) still fit;
-// levels with more candidates keep their points in the HBM scratch.  < 0: the node tables alone do not fit.
+// LDS point capacity of k_tree: about a level's typical candidate count, bounded so that several (level, image)
+// workgroups fit one CU; levels with more candidates keep their points in the HBM scratch
 static int lds_pts_cap(const Geom &G)
 {
     int c = (G.lv[0].w * G.lv[0].h / 160 + 1023) & ~1023; // P_0/160: measured best at 512 images per launch (1241x376: 3072)
     c = c < 3072 ? 3072 : c > 12288 ? 12288 : c;
-    while (c > 0 && tree_lds_bytes(G, c) > kTreeLdsLimit) c -= 1024;
-    if (tree_lds_bytes(G, c) > kTreeLdsLimit) return -1;
+    while (c > 3072 && tree_lds_bytes(G, c) > kTreeLdsLimit) c -= 1024;
     return c;
 }
 
@@ -986,7 +995,11 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         L.hx = (float)L.tree_w / L.n_ini;                  // :628
         int nc = L.quota + 3 > 4 * L.n_ini ? L.quota + 3 : 4 * L.n_ini;
         L.node_cap = (nc + 4 + 3) & ~3;
-        if (L.node_cap >= (1 << ORBX_NODE_BITS)) { orbx_set_error("nfeatures too large for the quadtree kernel"); return ORBX_E_INVALID; }
+        if (L.node_cap >= (1 << ORBX_NODE_BITS)) {
+            orbx_set_error("level %d asks for %d features: the quadtree labels hold %d leaves per level (nfeatures <= ~%d at scale factor 1.2)",
+                           l, L.quota, (1 << ORBX_NODE_BITS) - 8, 70000);
+            return ORBX_E_INVALID;
+        }
         L.kp_cap = L.node_cap; L.kp_off = G.kp_total; G.kp_total += L.kp_cap;
         L.scale = e->sf[l];
         L.patch_size = (int)(31 * e->sf[l]);               // :1023
@@ -1066,10 +1079,8 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
             c.cand_slot = L.cand_off + (long long)ci * L.cand_cap;
         }
     }
-    if (lds_pts_cap(G) < 0) {
-        orbx_set_error("the quadtree kernel's LDS tables do not fit: %d leaves per level x 76 B + %d FAST cells per level x 4 B exceed %zu KB "
-                       "(about 2000 features per level on small images, fewer on very large ones)", G.max_node_cap, G.max_cells_level,
-                       kTreeLdsLimit / 1024);
+    if (tree_lds_bytes(G, lds_pts_cap(G)) > kTreeLdsLimit) {
+        orbx_set_error("internal: %d FAST cells per level do not fit the quadtree kernel's LDS", G.max_cells_level);
         return ORBX_E_INVALID;
     }
     ORBX_HIP(hipSetDevice(e->device));
@@ -1096,6 +1107,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         }
     }
     if ((rc = ensure(&e->d_lvl_kp, &e->lvl_kp_cap, (size_t)G.kp_total * B * 4))) return rc;
+    if (!tree_tab_in_lds(G) && (rc = ensure(&e->d_tree_tab, &e->tree_tab_cap, align_up(tree_tab_bytes(G), 256) * e->nlevels * B))) return rc;
     ORBX_HIP(hipMemcpy(e->d_tabs, tabs.data(), tabs.size() * 2, hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(e->d_cells, cells.data(), cells.size() * sizeof(CellRec), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(e->d_geom, &G, sizeof G, hipMemcpyHostToDevice));
@@ -1192,7 +1204,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *e)
     if (e->stream) hipStreamSynchronize(e->stream);
     for (auto &ev : e->prof_ev) { if (ev.owns_a && ev.a) hipEventDestroy(ev.a); if (ev.b) hipEventDestroy(ev.b); }
     for (auto ev : e->prof_pool) hipEventDestroy(ev);
-    void *ptrs[] = { e->d_cells, e->d_geom, e->d_tabs, e->d_pyr, e->d_stage_in, e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid,
+    void *ptrs[] = { e->d_tree_tab, e->d_cells, e->d_geom, e->d_tabs, e->d_pyr, e->d_stage_in, e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid,
                      e->d_lvl_cnt, e->d_lvl_kp, e->d_out_kps, e->d_out_desc, e->d_out_n, e->d_out_ur, e->d_out_depth, e->d_st_dist, e->d_st_entries };
     for (void *p : ptrs) if (p) hipFree(p);
     for (void *p : e->scratch) if (p) hipFree(p);
@@ -1300,7 +1312,8 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
     int *err_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;
     orbx_prof_begin(e, ORBX_STAGE_TREE, s);
     hipLaunchKernelGGL(k_tree, dim3(batch, G.nlevels), dim3(256), tree_lds_bytes(G, lds_pts_cap(G)), s, e->d_geom,
-                       e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, lds_pts_cap(G), err_flag);
+                       e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, lds_pts_cap(G), err_flag,
+                       tree_tab_in_lds(G) ? nullptr : e->d_tree_tab, (long long)align_up(tree_tab_bytes(G), 256));
     orbx_prof_end(e, s);
     orbx_prof_begin(e, ORBX_STAGE_DESC, s);
     hipLaunchKernelGGL(k_desc, dim3(G.kp_total, batch), dim3(64), 0, s, e->d_geom, pr, e->d_lvl_cnt, e->d_lvl_kp,

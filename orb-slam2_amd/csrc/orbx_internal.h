@@ -92,6 +92,7 @@ struct orbx_extractor {
     int *d_cell_cnt; size_t cell_cnt_cap;
     uint32_t *d_cand; size_t cand_cap;
     uint32_t *d_tree_pts; uint16_t *d_tree_nid; size_t tree_cap; // overflow scratch of the quadtree
+    unsigned char *d_tree_tab; size_t tree_tab_cap; // quadtree node tables of configurations whose tables exceed the LDS (else unused)
     int *d_lvl_cnt;                        // [max_batch][nlevels]
     uint32_t *d_lvl_kp; size_t lvl_kp_cap; // [max_batch][kp_total]
     // host-API pinned staging (pageable 2-D copies cost milliseconds)

@@ -83,11 +83,11 @@ def test_random_geometry_sweep(pkg, oracle):
     """seeded sweep over image sizes / feature counts / level counts / scale factors: every combination changes the
     cell grid, the resize tables, the quadtree roots and the LDS carve; all stages must stay bit-exact"""
     rng = np.random.Generator(np.random.PCG64(2024))
-    done = 0
+    done = big = 0
     for trial in range(60):
         w = int(rng.integers(120, 1400)); h = int(rng.integers(100, 900))
         nlevels = int(rng.integers(1, 9)); sf = float(rng.choice([1.1, 1.2, 1.2, 1.2, 1.25, 1.4, 1.7]))
-        nf = int(rng.integers(50, 3000))
+        nf = int(rng.integers(50, 3000)) if trial % 6 else int(rng.integers(9000, 16000))   # every sixth: beyond the LDS node tables
         try:
             orc = oracle.Oracle(nf, sf, nlevels, 20, 7)
             img = synth.image(3000 + trial, w, h, nshapes=int(w * h / 400) + 50)
@@ -100,18 +100,30 @@ def test_random_geometry_sweep(pkg, oracle):
             continue
         ex = pkg.ORBextractor(nf, sf, nlevels, 20, 7, device=0, max_size=(w, h))
         tag = f"trial {trial}: {w}x{h} nf={nf} levels={nlevels} sf={sf}"
-        if orc.features_per_level().max() > 1900:
-            # documented limit (Limits): the quadtree's node tables live in LDS (76 B per leaf, ~2000 leaves)
-            if orc.features_per_level().max() > 2050:
-                with pytest.raises(pkg.OrbxError, match="quadtree kernel.s LDS tables do not fit"):
-                    ex(img)
-            continue
+        big += int(orc.features_per_level().max() > 2050)   # node tables in the HBM workspace instead of LDS (same code path otherwise)
         kps, desc = ex(img)
         assert len(kps) == len(okps), tag
         assert kps.tobytes() == okps.tobytes(), tag
         assert desc.tobytes() == odesc.tobytes(), tag
         done += 1
-    assert done >= 40
+    assert done >= 40 and big >= 3
+
+
+def test_large_nfeatures_hbm_node_tables(pkg, oracle):
+    """nfeatures far beyond ORB-SLAM2's settings (src/ORBextractor.cc:468-493 accepts any): per-level quotas of several
+    thousand leaves put the quadtree's node tables into the HBM workspace; same results as the oracle.  The only remaining bound is
+    the 14-bit node id of the point labels (about 16 000 leaves per level)."""
+    w, h = 1241, 376
+    img = synth.image(77, w, h, nshapes=4000)
+    for nf in (12000, 24000):
+        ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7, device=0, max_size=(w, h))
+        orc = oracle.Oracle(nf, 1.2, 8, 20, 7)
+        assert orc.features_per_level().max() > 2500
+        kps, desc = ex(img)
+        okps, odesc = orc.extract(img)
+        assert len(kps) == len(okps) > 6000 and kps.tobytes() == okps.tobytes() and desc.tobytes() == odesc.tobytes(), nf
+    with pytest.raises(pkg.OrbxError, match="quadtree labels hold"):
+        pkg.ORBextractor(120000, 1.2, 8, 20, 7, device=0, max_size=(w, h))(img)
 
 
 def test_two_handles_two_threads(pkg, oracle):
