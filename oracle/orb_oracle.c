@@ -127,6 +127,17 @@ static void linear_coeffs(int ssize, int dsize, int *ofs, short *c0, short *c1)
 void oracle_resize_linear(const uint8_t *src, int sw, int sh, size_t sstride,
                           uint8_t *dst, int dw, int dh, size_t dstride)
 {
+    /* cv::resize replaces INTER_LINEAR by INTER_AREA when both scale factors are exactly 2 (imgproc/src/imgwarp.cpp [OpenCV 3.2,
+     * from memory]: `if( interpolation == INTER_LINEAR && is_area_fast && iscale_x == 2 && iscale_y == 2 ) interpolation = INTER_AREA;`);
+     * the 8U fast-area kernel for a 2x2 block is (a + b + c + d + 2) >> 2.  scaleFactor 1.2 never gets here; 2.0 does on even sizes. */
+    if (sw == 2 * dw && sh == 2 * dh) {
+        for (int dy = 0; dy < dh; dy++) {
+            const uint8_t *r0 = src + (size_t)(2 * dy) * sstride, *r1 = r0 + sstride;
+            for (int dx = 0; dx < dw; dx++)
+                dst[(size_t)dy * dstride + dx] = (uint8_t)((r0[2 * dx] + r0[2 * dx + 1] + r1[2 * dx] + r1[2 * dx + 1] + 2) >> 2);
+        }
+        return;
+    }
     int *xofs = malloc(sizeof(int) * dw), *yofs = malloc(sizeof(int) * dh);
     short *a0 = malloc(2 * dw), *a1 = malloc(2 * dw), *b0 = malloc(2 * dh), *b1 = malloc(2 * dh);
     linear_coeffs(sw, dw, xofs, a0, a1);

@@ -127,6 +127,17 @@ __global__ __launch_bounds__(256) void k_resize_direct(const Geom *__restrict__ 
     int spitch;
     const uint8_t *src = orbx_level_ptr(pr, S, l - 1, b, &spitch);
     uint8_t *dst = pyr_w + (long long)b * pr.pyr_stride + D.pyr_off;
+    if (D.resize_lds == 2) { // exact 2x in both directions: cv::resize switches INTER_LINEAR to the 2x2 area average
+        const uint8_t *r0 = src + (long long)(2 * y) * spitch, *r1 = r0 + spitch;
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int x = x4 + i;
+            if (x < D.w) out |= (uint32_t)((r0[2 * x] + r0[2 * x + 1] + r1[2 * x] + r1[2 * x + 1] + 2) >> 2) << (8 * i);
+        }
+        *reinterpret_cast<uint32_t *>(dst + (long long)y * D.pitch + x4) = out;
+        return;
+    }
     const int16_t *tx = tabs + D.tab_x, *ty = tabs + D.tab_y;
     const int sy0 = ty[4 * y], b0 = ty[4 * y + 1], b1 = ty[4 * y + 2];
     const int sy1 = sy0 + 1 < S.h ? sy0 + 1 : S.h - 1;
@@ -1059,7 +1070,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
             const int smax = ty[4 * yl] + 1 < S.h - 1 ? ty[4 * yl] + 1 : S.h - 1;
             if (smax - ty[4 * y0] + 1 > RS_ROWS) ok = false;
         }
-        L.resize_lds = ok ? 1 : 0;
+        L.resize_lds = (S.w == 2 * L.w && S.h == 2 * L.h) ? 2 : ok ? 1 : 0;   // 2: area-average kernel path (k_resize_direct)
     }
     std::vector<CellRec> cells(G.total_cells);
     for (int l = 0; l < e->nlevels; l++) {
@@ -1288,7 +1299,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
     for (int l = 1; l < G.nlevels; l++) {
         const LevelGeom &L = G.lv[l];
         orbx_prof_begin(e, ORBX_STAGE_RESIZE, s);
-        if (L.resize_lds)
+        if (L.resize_lds == 1)
             hipLaunchKernelGGL(k_resize, dim3((L.w + RS_TW - 1) / RS_TW, (L.h + RS_TH - 1) / RS_TH, batch), dim3(RS_NT), 0, s,
                                e->d_geom, l, pr, e->d_pyr, e->d_tabs);
         else

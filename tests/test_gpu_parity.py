@@ -70,7 +70,7 @@ def test_one_pixel_wide_cells(pkg, oracle):
     _check_stages(ex, orc, img, "783x814")
 
 
-@pytest.mark.parametrize("sf,nlevels", [(1.5, 4), (1.1, 6), (1.9, 3)])
+@pytest.mark.parametrize("sf,nlevels", [(1.5, 4), (1.1, 6), (1.9, 3), (2.0, 3)])
 def test_other_scale_factors(pkg, oracle, sf, nlevels):
     """non-default scaleFactor: resize tables, quotas and (for large factors) the non-LDS resize path"""
     img = synth.image(7, 640, 480)

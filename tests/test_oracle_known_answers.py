@@ -143,6 +143,20 @@ def test_resize_constant_and_bounds(oracle):
     assert np.abs(dst.astype(np.float64) - ref).max() <= 1.0
 
 
+def test_resize_exact_half_is_area_average(oracle):
+    """both scale factors exactly 2: cv::resize turns INTER_LINEAR into INTER_AREA = the rounded mean of each 2x2 block"""
+    L = oracle.lib()
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, (60, 72), dtype=np.uint8); dst = np.zeros((30, 36), np.uint8)
+    L.oracle_resize_linear(src.ctypes.data, 72, 60, 72, dst.ctypes.data, 36, 30, 36)
+    s = src.astype(np.int32)
+    assert (dst == (s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).all()
+    # one dimension off by a pixel: back on the bilinear path (differs from the block mean somewhere)
+    dst2 = np.zeros((30, 35), np.uint8)
+    L.oracle_resize_linear(src.ctypes.data, 72, 60, 72, dst2.ctypes.data, 35, 30, 35)
+    assert (dst2 != dst[:, :35]).any()
+
+
 RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
 
 
