@@ -20,23 +20,28 @@ __constant__ int c_gauss[7];              // 8-bit fixed point 7-tap sigma=2 ker
 // ================================================================ K1: pyramid level (E2)
 // cv::resize INTER_LINEAR 8UC1 from level l-1 to level l.  Coefficient tables are
 // computed on the host with the reference's float/double arithmetic; the kernel is pure integer.
-// A one-wave workgroup produces a 128x16 output tile: the source rectangle it needs (<= 156x21) is staged
-// in LDS with aligned dword loads issued in batches, each lane then computes a 4x8 block (x tables loaded once
-// per lane) and stores one dword per row.  One-wave workgroups need no barrier partners and drift apart in time,
-// so loads of one tile overlap arithmetic of another on the same CU.
+// A one-wave workgroup produces a 128x16 output tile, lane = two adjacent output columns, all 16 rows:
+//  * the source rectangle (<= 156 x 22) goes to LDS with direct loads (global_load_lds_dword, one per source row,
+//    any byte alignment, no VGPR round trip, no address arithmetic per element);
+//  * the loop runs over SOURCE rows (fully unrolled: every LDS offset is an immediate): the horizontal interpolation
+//    of a source row is computed once and serves the (up to two) output rows it belongs to -- at scale 1.2 that is
+//    1.33 instead of 2 horizontal passes per output row; an output row is emitted as soon as its lower source row
+//    is done.  Which output row that is depends only on the tile (every lane has the same rows): scalar control flow.
+// One-wave workgroups need no barrier partners and drift apart in time, so loads of one tile overlap arithmetic of
+// another on the same CU.
 #define RS_TW 128
 #define RS_TH 16
-#define RS_NT 64     // threads per workgroup = (RS_TW / 4) * (RS_TH / 8): one wave, no workgroup barrier partners
-#define RS_PITCH 176 // LDS bytes per staged source row (>= 1.2 * RS_TW + 2 + 3 + alignment)
+#define RS_NT 64     // threads per workgroup = RS_TW / 2: one wave
+#define RS_PITCH 176 // LDS bytes per staged source row (>= 1.2 * RS_TW + 2 + 3, dwords: 44 lanes of a direct load)
 #define RS_ROWS 22
 
 __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, int l, PyrRef pr,
                                                 uint8_t *__restrict__ pyr_w, const int16_t *__restrict__ tabs)
 {
-    __shared__ __align__(16) uint8_t src_t[RS_ROWS * RS_PITCH];
+    __shared__ __align__(16) uint8_t src_t[RS_ROWS * RS_PITCH + 96];   // + the idle lanes' span of the last row's load
     const LevelGeom &D = g->lv[l];
     const LevelGeom &S = g->lv[l - 1];
-    const int b = blockIdx.z, tid = threadIdx.x;
+    const int b = blockIdx.z, lane = threadIdx.x;
     const int x_t = blockIdx.x * RS_TW, y_t = blockIdx.y * RS_TH;
     int spitch;
     const uint8_t *src = orbx_level_ptr(pr, S, l - 1, b, &spitch);
@@ -44,72 +49,70 @@ __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, in
     const int16_t *tx = tabs + D.tab_x, *ty = tabs + D.tab_y;
     const int x_last = min(x_t + RS_TW, D.w) - 1, y_last = min(y_t + RS_TH, D.h) - 1;
     const int sx_min = tx[4 * x_t], sx_max = min(tx[4 * x_last] + 1, S.w - 1);
-    const int sy_min = ty[4 * y_t], sy_max = min(ty[4 * y_last] + 1, S.h - 1);
+    const int sy_min = __builtin_amdgcn_readfirstlane((int)ty[4 * y_t]), sy_max = min(__builtin_amdgcn_readfirstlane((int)ty[4 * y_last]) + 1, S.h - 1);
     const int nrows = sy_max - sy_min + 1;
-    int sxa; // source column held in LDS column 0
-    if ((((uintptr_t)src | (unsigned)spitch) & 3) == 0) {
-        sxa = sx_min & ~3;
-        const int ndw = ((sx_max - sxa) >> 2) + 1; // <= 41
-        const FastDiv fd(ndw);
-        const uint8_t *s0 = src + (long long)sy_min * spitch + sxa;
-        const int total = nrows * ndw; // <= 42 * 84: two batches of eight loads per thread, each issued before it is consumed
-        for (int i0 = 0; i0 < total; i0 += 8 * RS_NT) {
-            uint32_t tv[8];
-            int to[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int i = i0 + RS_NT * k + tid;
-                const int r = fd.div(i), c = i - r * ndw;
-                to[k] = r * (RS_PITCH / 4) + c;
-                if (i < total) tv[k] = *reinterpret_cast<const uint32_t *>(s0 + (long long)r * spitch + 4 * c);
+    {
+        // dwords that lie wholly inside the source row are fetched by direct loads; the <= 3 bytes a right-edge tile still
+        // needs behind them are fetched as bytes (a dword there could reach past the caller's last image row)
+        const int need = sx_max - sx_min + 1, nfull = min((need + 3) >> 2, (S.w - sx_min) >> 2), tail = max(need - 4 * nfull, 0);
+        const uint8_t *s0 = src + (long long)sy_min * spitch + sx_min;
+        if (lane < nfull)
+            for (int r = 0; r < nrows; r++)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(s0 + (long long)r * spitch + 4 * lane),
+                                                 reinterpret_cast<uint32_t *>(src_t + r * RS_PITCH), 4, 0, 0);
+        if (tail)
+            for (int i = lane; i < nrows * tail; i += RS_NT) {
+                const int r = i / tail, c = 4 * nfull + (i - r * tail);
+                src_t[r * RS_PITCH + c] = s0[(long long)r * spitch + c];
             }
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (i0 + RS_NT * k + tid < total) reinterpret_cast<uint32_t *>(src_t)[to[k]] = tv[k];
-        }
-    } else {
-        sxa = sx_min;
-        const int nb = sx_max - sxa + 1;
-        const FastDiv fd(nb);
-        const uint8_t *s0 = src + (long long)sy_min * spitch + sxa;
-        for (int i = tid; i < nrows * nb; i += RS_NT) {
-            const int r = fd.div(i), c = i - r * nb;
-            src_t[r * RS_PITCH + c] = s0[(long long)r * spitch + c];
-        }
     }
-    __syncthreads();
-    const int x4 = x_t + (tid & (RS_TW / 4 - 1)) * 4, y4 = y_t + (tid / (RS_TW / 4)) * 8;
-    if (x4 >= D.pitch) return;
-    int o0[4], o1[4], a0[4], a1[4];
+    // the lane's two output columns: source offsets inside the tile and the 11-bit weights
+    const int x2 = x_t + 2 * lane;
+    int o0[2], o1[2], a0[2], a1[2];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int x = min(x4 + i, D.w - 1);
+    for (int i = 0; i < 2; i++) {
+        const int x = min(x2 + i, D.w - 1);
         const short4 q = *reinterpret_cast<const short4 *>(tx + 4 * x); // (ofs, a0, a1, 0)
         const int sx0 = q.x;
-        o0[i] = sx0 - sxa;
-        o1[i] = min(sx0 + 1, S.w - 1) - sxa;
+        o0[i] = sx0 - sx_min;
+        o1[i] = min(sx0 + 1, S.w - 1) - sx_min;
         a0[i] = q.y;
         a1[i] = q.z;
     }
+    // the 16 output rows' vertical table entries (source row, b0, b1): wave-uniform, fetched up front as scalars so that
+    // no scalar-memory wait sits between the LDS reads below (the table buffer is padded for the last tile's overread)
+    short4 qy[RS_TH];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int y = y4 + j;
-        if (y >= D.h) break;
-        const short4 qy = *reinterpret_cast<const short4 *>(ty + 4 * y);
-        const int sy0 = qy.x, b0 = qy.y, b1 = qy.z;
-        const uint8_t *r0 = src_t + (sy0 - sy_min) * RS_PITCH;
-        const uint8_t *r1 = src_t + (min(sy0 + 1, S.h - 1) - sy_min) * RS_PITCH;
-        uint32_t out = 0;
+    for (int j = 0; j < RS_TH; j++) qy[j] = *reinterpret_cast<const short4 *>(ty + 4 * (y_t + j));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the direct loads have landed in LDS
+    __syncthreads();
+    // running LDS addresses of the lane's four source bytes in the NEXT source row to interpolate
+    const uint8_t *p00 = src_t + o0[0], *p01 = src_t + o1[0], *p10 = src_t + o0[1], *p11 = src_t + o1[1];
+    int k = 0;                                  // source rows interpolated so far (wave-uniform)
+    int hp0 = 0, hp1 = 0, hc0 = 0, hc1 = 0;     // (t >> 4) of source rows k - 2 and k - 1
+    uint8_t *drow = dst + (long long)y_t * D.pitch + x2;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int t0 = r0[o0[i]] * a0[i] + r0[o1[i]] * a1[i];
-            const int t1 = r1[o0[i]] * a0[i] + r1[o1[i]] * a1[i];
+    for (int j = 0; j < RS_TH; j++) {
+        if (y_t + j <= y_last) {                // wave-uniform (every lane of the tile has the same rows)
+            const int sy0 = __builtin_amdgcn_readfirstlane((int)qy[j].x), b0 = __builtin_amdgcn_readfirstlane((int)qy[j].y),
+                      b1 = __builtin_amdgcn_readfirstlane((int)qy[j].z);
+            const int ra = sy0 - sy_min, rb = min(sy0 + 1, S.h - 1) - sy_min;
+            while (k <= rb) {                   // one or two source rows per output row at scale 1.2 (wave-uniform trip count)
+                hp0 = hc0; hp1 = hc1;
+                hc0 = (p00[0] * a0[0] + p01[0] * a1[0]) >> 4;
+                hc1 = (p10[0] * a0[1] + p11[0] * a1[1]) >> 4;
+                p00 += RS_PITCH; p01 += RS_PITCH; p10 += RS_PITCH; p11 += RS_PITCH;
+                k++;
+            }
+            // rows (ra, rb) = (k - 2, k - 1), or both k - 1 at the bottom clamp
+            const int ha0 = ra == rb ? hc0 : hp0, ha1 = ra == rb ? hc1 : hp1;
             // the weights are non-negative and each pair sums to 2048 (+-1 by rounding), so v stays inside [0, 255]:
             // ((2049 * (255 * 2049 >> 4)) >> 16) + 2 >> 2 == 255 -- cv::resize's saturate_cast never fires for INTER_LINEAR
-            const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
-            out |= (uint32_t)v << (8 * i);
+            const int v0 = (((b0 * ha0) >> 16) + ((b1 * hc0) >> 16) + 2) >> 2;
+            const int v1 = (((b0 * ha1) >> 16) + ((b1 * hc1) >> 16) + 2) >> 2;
+            if (x2 < D.w) *reinterpret_cast<uint16_t *>(drow) = (uint16_t)(v0 | (v1 << 8));
+            drow += D.pitch;
         }
-        *reinterpret_cast<uint32_t *>(dst + (long long)y * D.pitch + x4) = out;
     }
 }
 
@@ -1048,7 +1051,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         G.fast_lds_bytes = G.fast_lds_bm + 2 * G.fast_bm_rows * 8;
     }
     // resize tables
-    std::vector<int16_t> tabs(tab_units ? tab_units : 1);
+    std::vector<int16_t> tabs(tab_units + 4 * RS_TH);   // + one tile's rows: k_resize prefetches 16 vertical entries per tile
     for (int l = 1; l < e->nlevels; l++) {
         LevelGeom &L = G.lv[l];
         const LevelGeom &S = G.lv[l - 1];
@@ -1063,7 +1066,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         for (int x0 = 0; x0 < L.w && ok; x0 += RS_TW) {
             const int xl = (x0 + RS_TW < L.w ? x0 + RS_TW : L.w) - 1;
             const int smax = tx[4 * xl] + 1 < S.w - 1 ? tx[4 * xl] + 1 : S.w - 1;
-            if (((smax - (tx[4 * x0] & ~3)) / 4 + 1) * 4 > RS_PITCH) ok = false;
+            if (((smax - tx[4 * x0]) / 4 + 1) * 4 > RS_PITCH) ok = false;
         }
         for (int y0 = 0; y0 < L.h && ok; y0 += RS_TH) {
             const int yl = (y0 + RS_TH < L.h ? y0 + RS_TH : L.h) - 1;

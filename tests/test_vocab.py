@@ -217,3 +217,43 @@ def test_hip_device_resident_bow_chain(pkg, oracle):
                 assert (m[i, j, :n[i]] == exp).all(), (form, i, j)
                 total += en
         assert total > 500 and (nm[3] == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["huge_nodes", "many_nodes"])
+def test_bow_midsize_multipass(pkg, oracle, shape):
+    """64 keyframes x 1000 features against one frame, both kernel forms (moved in from tools/soak_bow.py): `huge_nodes` = 6
+    vocabulary nodes, so a node pair holds ~25 000 distances, larger than the 4096-entry LDS table (wave walk inside the table
+    form) next to nodes that fill several table passes; `many_nodes` = 700 node ids, more than one 256-node chunk per pair."""
+    rng = np.random.Generator(np.random.PCG64(9090 + len(shape)))
+    nn = 6 if shape == "huge_nodes" else 700
+    ids = np.sort(rng.choice(100000, nn, replace=False)).astype(np.uint32)
+    p = rng.gamma(0.6 if shape == "huge_nodes" else 1.0, 1.0, nn) + 1e-9; p /= p.sum()
+    base = rng.integers(0, 256, (200, 32), dtype=np.uint8)      # descriptor prototypes: near-duplicates give ties and steals
+
+    def featset(n, flag_p):
+        proto = rng.integers(0, len(base), n)
+        node = ids[(proto * 7919 + rng.integers(0, 2, n)) % nn] if shape == "many_nodes" else ids[rng.choice(nn, n, p=p)]
+        d = synth.flip_bits(rng, base[proto], 0.06)
+        order = np.argsort(node, kind="stable")
+        u, counts = np.unique(node, return_counts=True)
+        off = np.zeros(len(u) + 1, np.int32); off[1:] = np.cumsum(counts)
+        return dict(desc=d, node_id=u.astype(np.uint32), node_off=off, feat=order.astype(np.uint32),
+                    flag=(rng.random(n) < flag_p).astype(np.uint8), angle=rng.uniform(0, 360, n).astype(np.float32))
+    frame = featset(1000, 0.0)
+    kfs = [featset(int(rng.integers(700, 1100)), 0.7) for _ in range(64)]
+    expect = [oracle.search_by_bow_kf_f(kf, frame, 0.75, True) for kf in kfs]
+    db = pkg.BowDatabase(kfs)
+    try:
+        for form in ("table", "wave"):
+            pkg.orbx.debug_set_bow_form(form)
+            m, n = db.search(frame, 0.75, True)
+            for j, (exp, en) in enumerate(expect):
+                assert n[j] == en, (form, j, int(n[j]), en)
+                assert (m[j] == exp).all(), (form, j)
+    finally:
+        pkg.orbx.debug_set_bow_form("auto")
+    assert sum(en for _, en in expect) > 64 * 20
+    if shape == "huge_nodes":
+        a = np.diff(kfs[0]["node_off"]).max(); b = np.diff(frame["node_off"]).max()
+        assert int(a) * int(b) > 4096          # at least one node pair really exceeds the LDS table

@@ -20,14 +20,15 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-out_dir = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}")
+workload = sys.argv[3] if len(sys.argv) > 3 else "stereo1000"   # euroc_bow: BASELINE config 3 (k_bow<0>, k_vocab_*, k_bow_build)
+out_dir = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{workload}")
 res = collections.defaultdict(dict)
 env = dict(os.environ, TMPDIR="/tmp")
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(out_dir, counter)
     subprocess.check_call(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
                            "python3", os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--cpu-frames", "0", "--extras", "0", "--no-verify",
-                           "--batch", str(batch)], cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                           "--batch", str(batch), "--workload", workload], cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
@@ -39,10 +40,10 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             res[k]["launches_sampled"] = len(v)
 for k in res:
     res[k]["hbm_bytes_per_launch"] = int(1024 * (res[k].get("FETCH_SIZE_KiB_per_launch", 0) + res[k].get("WRITE_SIZE_KiB_per_launch", 0)))
-doc = {"tag": tag, "workload": "stereo1000", "frames_per_step": batch, "images_per_launch": 2 * batch,
+doc = {"tag": tag, "workload": workload, "frames_per_step": batch, "images_per_launch": 2 * batch if workload.startswith("stereo") else batch,
        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace; mean over dispatches; "
                  "no gfx950 x2 correction (4 B per lane loads calibrate at ~1.0x on k_resize)",
        "kernels": res}
-path = os.path.join(ROOT, "gpurun_out", f"{tag}_traffic.json")
+path = os.path.join(ROOT, "gpurun_out", f"{tag}_traffic.json" if workload == "stereo1000" else f"{tag}_traffic_{workload}.json")
 json.dump(doc, open(path, "w"), indent=1)
 print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in res.items()}))
