@@ -88,6 +88,9 @@ __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, in
     __syncthreads();
     // running LDS addresses of the lane's four source bytes in the NEXT source row to interpolate
     const uint8_t *p00 = src_t + o0[0], *p01 = src_t + o1[0], *p10 = src_t + o0[1], *p11 = src_t + o1[1];
+#define STEP() do { hp0 = hc0; hp1 = hc1; hc0 = (p00[0] * a0[0] + p01[0] * a1[0]) >> 4; hc1 = (p10[0] * a0[1] + p11[0] * a1[1]) >> 4; \
+                    p00 += RS_PITCH; p01 += RS_PITCH; p10 += RS_PITCH; p11 += RS_PITCH; k++; } while (0)
+    const int s_h = S.h, d_w = D.w, d_pitch = D.pitch;   // scalars: not reloaded behind the stores
     int k = 0;                                  // source rows interpolated so far (wave-uniform)
     int hp0 = 0, hp1 = 0, hc0 = 0, hc1 = 0;     // (t >> 4) of source rows k - 2 and k - 1
     uint8_t *drow = dst + (long long)y_t * D.pitch + x2;
@@ -96,24 +99,23 @@ __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, in
         if (y_t + j <= y_last) {                // wave-uniform (every lane of the tile has the same rows)
             const int sy0 = __builtin_amdgcn_readfirstlane((int)qy[j].x), b0 = __builtin_amdgcn_readfirstlane((int)qy[j].y),
                       b1 = __builtin_amdgcn_readfirstlane((int)qy[j].z);
-            const int ra = sy0 - sy_min, rb = min(sy0 + 1, S.h - 1) - sy_min;
-            while (k <= rb) {                   // one or two source rows per output row at scale 1.2 (wave-uniform trip count)
-                hp0 = hc0; hp1 = hc1;
-                hc0 = (p00[0] * a0[0] + p01[0] * a1[0]) >> 4;
-                hc1 = (p10[0] * a0[1] + p11[0] * a1[1]) >> 4;
-                p00 += RS_PITCH; p01 += RS_PITCH; p10 += RS_PITCH; p11 += RS_PITCH;
-                k++;
-            }
+            const int ra = sy0 - sy_min, rb = min(sy0 + 1, s_h - 1) - sy_min;
+            // one or two new source rows per output row (none at the bottom clamp); the trip count is wave-uniform and the
+            // tile only fits the LDS carve for scale factors below 1.375, so two explicit steps cover it (the loop is a guard)
+            if (k <= rb) STEP();
+            if (k <= rb) STEP();
+            while (k <= rb) STEP();
             // rows (ra, rb) = (k - 2, k - 1), or both k - 1 at the bottom clamp
             const int ha0 = ra == rb ? hc0 : hp0, ha1 = ra == rb ? hc1 : hp1;
             // the weights are non-negative and each pair sums to 2048 (+-1 by rounding), so v stays inside [0, 255]:
             // ((2049 * (255 * 2049 >> 4)) >> 16) + 2 >> 2 == 255 -- cv::resize's saturate_cast never fires for INTER_LINEAR
             const int v0 = (((b0 * ha0) >> 16) + ((b1 * hc0) >> 16) + 2) >> 2;
             const int v1 = (((b0 * ha1) >> 16) + ((b1 * hc1) >> 16) + 2) >> 2;
-            if (x2 < D.w) *reinterpret_cast<uint16_t *>(drow) = (uint16_t)(v0 | (v1 << 8));
-            drow += D.pitch;
+            if (x2 < d_w) *reinterpret_cast<uint16_t *>(drow) = (uint16_t)(v0 | (v1 << 8));
+            drow += d_pitch;
         }
     }
+#undef STEP
 }
 
 // Fallback for scale factors whose source rectangle does not fit the LDS tile of k_resize
