@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
         rec.level = (short)(w[0] & 0xFFFF); rec.skip = (short)(w[0] >> 16);
         rec.ini_x = (short)(w[1] & 0xFFFF); rec.ini_y = (short)(w[1] >> 16);
         rec.tw = (short)(w[2] & 0xFFFF); rec.th = (short)(w[2] >> 16);
-        rec.pitch = (int)w[3]; rec.cand_cap = (int)w[4];
+        rec.pitch = (int)w[3]; rec.cand_cap = (int)w[4]; rec.gpr_magic = w[5];
         rec.pyr_off = (long long)(((unsigned long long)w[7] << 32) | w[6]);
         rec.cand_slot = (long long)(((unsigned long long)w[9] << 32) | w[8]);
     }
@@ -343,9 +343,10 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
     // pretest geometry: tile dwords 1 .. gpr of a row hold the detectable pixels (tile columns 4 .. dw + 3); one iteration =
     // rpi whole rows, lane = (row lr, group gq); lanes beyond rpi * gpr idle with an empty pixel mask
     const int gpr = (dw + 3) >> 2;
-    const FastDiv fg(gpr);
-    const int rpi = min(fg.div(64), 8);                   // (the last column's cells can be narrow: keep the row overrun <= 8)
-    const int lr = min(fg.div(lane), rpi), gq = lane - fg.div(lane) * gpr;
+    // floor(i / gpr) by multiply-high with the host's magic number (an integer division costs ~30 instructions here)
+    const int lq = gpr == 1 ? lane : (int)__umulhi((unsigned)lane, rec.gpr_magic);
+    const int rpi = min(gpr == 1 ? 64 : (int)__umulhi(64u, rec.gpr_magic), 8);   // (the last column's cells can be narrow: keep the row overrun <= 8)
+    const int lr = min(lq, rpi), gq = lane - lq * gpr;
     const int nvalid = max(1, min(4, dw - 4 * gq));      // only the last group of a row can be partial
     const unsigned vmask = lr < rpi ? (0x80808080u >> (8 * (4 - nvalid))) : 0u;
     const int bm_sh = 4 * (gq & 7);
@@ -1092,6 +1093,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
             // src/ORBextractor.cc:961-976 skip rules (note the asymmetric 3 / 6)
             c.skip = (ini_y >= max_by - 3 || ini_x >= max_bx - 6 || c.tw - 6 <= 0 || c.th - 6 <= 0) ? 1 : 0;
             c.pitch = L.pitch; c.cand_cap = L.cand_cap; c.pyr_off = L.pyr_off;
+            { const int gpr = (c.tw - 6 + 3) >> 2; c.gpr_magic = gpr > 0 ? 0xFFFFFFFFu / (unsigned)gpr + 1u : 0u; }
             c.cand_slot = L.cand_off + (long long)ci * L.cand_cap;
         }
     }

@@ -53,6 +53,7 @@ struct CellRec {
     short ini_x, ini_y, tw, th;  // cell rectangle incl. 3-px halo, level coordinates
     int pitch;                   // level pitch (levels >= 1; level 0 uses the caller's pitch)
     int cand_cap;
+    unsigned gpr_magic;          // 0xFFFFFFFF / gpr + 1, gpr = dword groups per detect row = (tw - 6 + 3) >> 2: multiply-high division by gpr
     long long pyr_off;           // byte offset of the level in one image's pyramid block
     long long cand_slot;         // first candidate slot (u32 units) of this cell in one image's block
 };
