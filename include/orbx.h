@@ -127,6 +127,11 @@ int orbx_extract_stereo_submit(orbx_extractor *e, const uint8_t *img_left, const
                                float bf, float min_z, int *ticket);
 int orbx_extract_stereo_wait(orbx_extractor *e, int ticket, orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out,
                              float *u_right, float *depth);
+/* the same pipeline for a monocular stream (Frame::Frame(imGray, ...), src/Frame.cc:176-215; frame loop of
+ * Examples/Monocular/mono_tum.cc): one extraction per ticket, same output contract as orbx_extract.  Mono and stereo
+ * tickets share the handle's slots and ordering. */
+int orbx_extract_submit(orbx_extractor *e, const uint8_t *img, int w, int h, size_t stride, int *ticket);
+int orbx_extract_wait(orbx_extractor *e, int ticket, orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out);
 /* page-locked host memory for frame buffers (uploads from it need no staging copy) */
 void *orbx_pinned_alloc(size_t bytes);
 void orbx_pinned_free(void *p);

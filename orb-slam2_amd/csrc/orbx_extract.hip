@@ -1662,21 +1662,17 @@ static int pipe_slot_prepare(orbx_extractor *e, PipeSlot &s, size_t in_bytes, in
     return ORBX_OK;
 }
 
-extern "C" int orbx_extract_stereo_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t *img_right, int w, int h, size_t stride,
-                                          float bf, float min_z, int *ticket)
+// one frame into the next pipeline slot: eyes = 2 (stereo: both extractions + ComputeStereoMatches) or 1 (mono: extraction only)
+static int pipe_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t *img_right, int eyes, int w, int h, size_t stride,
+                       float bf, float min_z, int *ticket)
 {
-    if (!e || !img_left || !img_right || !ticket || w < 1 || h < 1 || stride < (size_t)w || !(min_z > 0)) {
-        orbx_set_error("orbx_extract_stereo_submit: invalid argument");
-        return ORBX_E_INVALID;
-    }
-    if (e->max_batch < 2) { orbx_set_error("orbx_extract_stereo_submit needs an extractor created with max_batch >= 2"); return ORBX_E_INVALID; }
     ORBX_HIP(hipSetDevice(e->device));
     int rc = orbx_prepare_geometry(e, w, h);   // waits for everything in flight only when the image size changes
     if (rc) return rc;
     PipeSlot &s = e->pipe[e->pipe_next % ORBX_PIPE_DEPTH];
-    if (s.busy) { orbx_set_error("all %d pipeline slots are in flight: call orbx_extract_stereo_wait first", ORBX_PIPE_DEPTH); return ORBX_E_INVALID; }
+    if (s.busy) { orbx_set_error("all %d pipeline slots are in flight: wait for the oldest ticket first", ORBX_PIPE_DEPTH); return ORBX_E_INVALID; }
     const int need = e->geom.kp_total;
-    const bool in_place = stride == (size_t)w && is_pinned_host(img_left) && is_pinned_host(img_right);
+    const bool in_place = stride == (size_t)w && is_pinned_host(img_left) && (eyes == 1 || is_pinned_host(img_right));
     const size_t pitch = in_place ? (size_t)w : align_up(w, 64), img_bytes = pitch * h;
     if (!e->copy_in) {
         ORBX_HIP(hipStreamCreateWithFlags(&e->copy_in, hipStreamNonBlocking));
@@ -1685,28 +1681,29 @@ extern "C" int orbx_extract_stereo_submit(orbx_extractor *e, const uint8_t *img_
     if ((rc = pipe_slot_prepare(e, s, 2 * align_up(w, 64) * (size_t)h, need))) return rc;
     // upload: the slot's device input was last read by the kernels of the frame that used it ORBX_PIPE_DEPTH submissions ago,
     // which its _wait has already seen finish (ev_d2h follows ev_done), so the copy stream may overwrite it right away
+    const uint8_t *eye_ptr[2] = { img_left, img_right };
     if (in_place) {
-        ORBX_HIP(hipMemcpyAsync(s.d_in, img_left, img_bytes, hipMemcpyHostToDevice, e->copy_in));
-        ORBX_HIP(hipMemcpyAsync(s.d_in + img_bytes, img_right, img_bytes, hipMemcpyHostToDevice, e->copy_in));
+        for (int i = 0; i < eyes; i++) ORBX_HIP(hipMemcpyAsync(s.d_in + img_bytes * i, eye_ptr[i], img_bytes, hipMemcpyHostToDevice, e->copy_in));
     } else {
-        const uint8_t *eyes[2] = { img_left, img_right };
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < eyes; i++) {
             uint8_t *dst = s.h_in + img_bytes * i;
-            if (stride == pitch) memcpy(dst, eyes[i], img_bytes);
-            else for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * pitch, eyes[i] + (size_t)y * stride, (size_t)w);
+            if (stride == pitch) memcpy(dst, eye_ptr[i], img_bytes);
+            else for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * pitch, eye_ptr[i] + (size_t)y * stride, (size_t)w);
         }
-        ORBX_HIP(hipMemcpyAsync(s.d_in, s.h_in, img_bytes * 2, hipMemcpyHostToDevice, e->copy_in));
+        ORBX_HIP(hipMemcpyAsync(s.d_in, s.h_in, img_bytes * eyes, hipMemcpyHostToDevice, e->copy_in));
     }
     ORBX_HIP(hipEventRecord(s.ev_h2d, e->copy_in));
     ORBX_HIP(hipStreamWaitEvent(e->stream, s.ev_h2d, 0));
     e->prof_chain = false;
-    rc = orbx_extract_batch_device(e, s.d_in, img_bytes, pitch, 2, w, h, s.d_kps, s.d_desc, need, s.d_n, nullptr);
+    rc = orbx_extract_batch_device(e, s.d_in, img_bytes, pitch, eyes, w, h, s.d_kps, s.d_desc, need, s.d_n, nullptr);
     if (rc) return rc;
     orbx_keypoint *dk = (orbx_keypoint *)s.d_kps;
     uint8_t *dd = (uint8_t *)s.d_desc;
     int *dn = (int *)s.d_n;
-    rc = orbx_stereo_match_batch_device(e, 0, e, 1, 1, dk, dd, dn, dk + need, dd + (size_t)32 * need, dn + 1, need, bf, min_z, s.d_ur, s.d_z, nullptr);
-    if (rc) return rc;
+    if (eyes == 2) {
+        rc = orbx_stereo_match_batch_device(e, 0, e, 1, 1, dk, dd, dn, dk + need, dd + (size_t)32 * need, dn + 1, need, bf, min_z, s.d_ur, s.d_z, nullptr);
+        if (rc) return rc;
+    }
     // the kernel error flag of this frame travels with its counts; cleared for the next frame on the same (in-order) stream
     int *d_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;
     ORBX_HIP(hipMemcpyAsync(dn + 2, d_flag, sizeof(int), hipMemcpyDeviceToDevice, e->stream));
@@ -1717,39 +1714,71 @@ extern "C" int orbx_extract_stereo_submit(orbx_extractor *e, const uint8_t *img_
                  o_z = o_ur + align_up(4 * (size_t)need, 64);
     ORBX_HIP(hipStreamWaitEvent(e->copy_out, s.ev_done, 0));
     ORBX_HIP(hipMemcpyAsync(s.h_out, dn, 3 * sizeof(int), hipMemcpyDeviceToHost, e->copy_out));
-    ORBX_HIP(hipMemcpyAsync(s.h_out + o_kps, dk, sizeof(orbx_keypoint) * 2 * (size_t)need, hipMemcpyDeviceToHost, e->copy_out));
-    ORBX_HIP(hipMemcpyAsync(s.h_out + o_desc, dd, (size_t)64 * need, hipMemcpyDeviceToHost, e->copy_out));
-    ORBX_HIP(hipMemcpyAsync(s.h_out + o_ur, s.d_ur, 4 * (size_t)need, hipMemcpyDeviceToHost, e->copy_out));
-    ORBX_HIP(hipMemcpyAsync(s.h_out + o_z, s.d_z, 4 * (size_t)need, hipMemcpyDeviceToHost, e->copy_out));
+    ORBX_HIP(hipMemcpyAsync(s.h_out + o_kps, dk, sizeof(orbx_keypoint) * eyes * (size_t)need, hipMemcpyDeviceToHost, e->copy_out));
+    ORBX_HIP(hipMemcpyAsync(s.h_out + o_desc, dd, (size_t)32 * eyes * need, hipMemcpyDeviceToHost, e->copy_out));
+    if (eyes == 2) {
+        ORBX_HIP(hipMemcpyAsync(s.h_out + o_ur, s.d_ur, 4 * (size_t)need, hipMemcpyDeviceToHost, e->copy_out));
+        ORBX_HIP(hipMemcpyAsync(s.h_out + o_z, s.d_z, 4 * (size_t)need, hipMemcpyDeviceToHost, e->copy_out));
+    }
     ORBX_HIP(hipEventRecord(s.ev_d2h, e->copy_out));
-    s.busy = true; s.cap = need; s.ticket = e->pipe_next;
+    s.busy = true; s.cap = need; s.ticket = e->pipe_next; s.eyes = eyes;
     *ticket = e->pipe_next++;
     return ORBX_OK;
+}
+
+static int pipe_wait(orbx_extractor *e, int ticket, int eyes, orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out, float *u_right, float *depth)
+{
+    PipeSlot &s = e->pipe[ticket % ORBX_PIPE_DEPTH];
+    if (!s.busy || s.ticket != ticket || s.eyes != eyes) { orbx_set_error("ticket %d is not in flight (or was submitted through the other form)", ticket); return ORBX_E_INVALID; }
+    ORBX_HIP(hipSetDevice(e->device));
+    const int need = s.cap;
+    if (cap < need) { orbx_set_error("keypoint capacity %d < orbx_max_keypoints() = %d (the ticket stays valid)", cap, need); return ORBX_E_CAPACITY; }
+    ORBX_HIP(hipEventSynchronize(s.ev_d2h));
+    s.busy = false;
+    const size_t o_kps = 64, o_desc = o_kps + align_up(sizeof(orbx_keypoint) * 2 * (size_t)need, 64), o_ur = o_desc + (size_t)64 * need,
+                 o_z = o_ur + align_up(4 * (size_t)need, 64);
+    const int *hn = reinterpret_cast<const int *>(s.h_out);
+    if (hn[2]) { orbx_set_error("quadtree kernel reported a node-table overflow"); return ORBX_E_CAPACITY; }
+    for (int i = 0; i < eyes; i++) {
+        n_out[i] = hn[i];
+        memcpy(kps + (size_t)i * cap, s.h_out + o_kps + sizeof(orbx_keypoint) * (size_t)need * i, sizeof(orbx_keypoint) * (size_t)hn[i]);
+        memcpy(desc + (size_t)i * cap * 32, s.h_out + o_desc + (size_t)32 * need * i, (size_t)32 * hn[i]);
+    }
+    if (eyes == 2) {
+        memcpy(u_right, s.h_out + o_ur, 4 * (size_t)hn[0]);
+        memcpy(depth, s.h_out + o_z, 4 * (size_t)hn[0]);
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_stereo_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t *img_right, int w, int h, size_t stride,
+                                          float bf, float min_z, int *ticket)
+{
+    if (!e || !img_left || !img_right || !ticket || w < 1 || h < 1 || stride < (size_t)w || !(min_z > 0)) {
+        orbx_set_error("orbx_extract_stereo_submit: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    if (e->max_batch < 2) { orbx_set_error("orbx_extract_stereo_submit needs an extractor created with max_batch >= 2"); return ORBX_E_INVALID; }
+    return pipe_submit(e, img_left, img_right, 2, w, h, stride, bf, min_z, ticket);
 }
 
 extern "C" int orbx_extract_stereo_wait(orbx_extractor *e, int ticket, orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out,
                                         float *u_right, float *depth)
 {
     if (!e || !kps || !desc || !n_out || !u_right || !depth || ticket < 0) { orbx_set_error("orbx_extract_stereo_wait: invalid argument"); return ORBX_E_INVALID; }
-    PipeSlot &s = e->pipe[ticket % ORBX_PIPE_DEPTH];
-    if (!s.busy || s.ticket != ticket) { orbx_set_error("ticket %d is not in flight", ticket); return ORBX_E_INVALID; }
-    ORBX_HIP(hipSetDevice(e->device));
-    ORBX_HIP(hipEventSynchronize(s.ev_d2h));
-    s.busy = false;
-    const int need = s.cap;
-    if (cap < need) { orbx_set_error("keypoint capacity %d < orbx_max_keypoints() = %d", cap, need); return ORBX_E_CAPACITY; }
-    const size_t o_kps = 64, o_desc = o_kps + align_up(sizeof(orbx_keypoint) * 2 * (size_t)need, 64), o_ur = o_desc + (size_t)64 * need,
-                 o_z = o_ur + align_up(4 * (size_t)need, 64);
-    const int *hn = reinterpret_cast<const int *>(s.h_out);
-    if (hn[2]) { orbx_set_error("quadtree kernel reported a node-table overflow"); return ORBX_E_CAPACITY; }
-    for (int i = 0; i < 2; i++) {
-        n_out[i] = hn[i];
-        memcpy(kps + (size_t)i * cap, s.h_out + o_kps + sizeof(orbx_keypoint) * (size_t)need * i, sizeof(orbx_keypoint) * (size_t)hn[i]);
-        memcpy(desc + (size_t)i * cap * 32, s.h_out + o_desc + (size_t)32 * need * i, (size_t)32 * hn[i]);
-    }
-    memcpy(u_right, s.h_out + o_ur, 4 * (size_t)hn[0]);
-    memcpy(depth, s.h_out + o_z, 4 * (size_t)hn[0]);
-    return ORBX_OK;
+    return pipe_wait(e, ticket, 2, kps, desc, cap, n_out, u_right, depth);
+}
+
+extern "C" int orbx_extract_submit(orbx_extractor *e, const uint8_t *img, int w, int h, size_t stride, int *ticket)
+{
+    if (!e || !img || !ticket || w < 1 || h < 1 || stride < (size_t)w) { orbx_set_error("orbx_extract_submit: invalid argument"); return ORBX_E_INVALID; }
+    return pipe_submit(e, img, nullptr, 1, w, h, stride, 0.f, 1.f, ticket);
+}
+
+extern "C" int orbx_extract_wait(orbx_extractor *e, int ticket, orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out)
+{
+    if (!e || !kps || !desc || !n_out || ticket < 0) { orbx_set_error("orbx_extract_wait: invalid argument"); return ORBX_E_INVALID; }
+    return pipe_wait(e, ticket, 1, kps, desc, cap, n_out, nullptr, nullptr);
 }
 
 extern "C" int orbx_extract(orbx_extractor *e, const uint8_t *img, int w, int h, size_t stride,

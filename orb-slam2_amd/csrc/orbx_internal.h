@@ -67,7 +67,7 @@ struct PipeSlot {
     uint8_t *h_out; size_t h_out_cap;        // pinned: [n0 n1 flag | keypoints x2 | descriptors x2 | uRight | depth]
     void *d_kps, *d_desc, *d_n; float *d_ur, *d_z; int out_cap;
     hipEvent_t ev_h2d, ev_done, ev_d2h;      // input landed / kernels finished / results landed in h_out
-    int cap, ticket; bool busy;
+    int cap, ticket, eyes; bool busy;
 };
 #define ORBX_PIPE_DEPTH 4
 

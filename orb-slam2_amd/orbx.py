@@ -70,6 +70,8 @@ def lib():
     L.orbx_extract_stereo.argtypes = [vp, vp, vp, i, i, sz, f, f, vp, vp, i, vp, vp, vp]
     L.orbx_extract_stereo_submit.argtypes = [vp, vp, vp, i, i, sz, f, f, ip]
     L.orbx_extract_stereo_wait.argtypes = [vp, i, vp, vp, i, vp, vp, vp]
+    L.orbx_extract_submit.argtypes = [vp, vp, i, i, sz, ip]
+    L.orbx_extract_wait.argtypes = [vp, i, vp, vp, i, vp]
     L.orbx_pinned_alloc.argtypes = [sz]; L.orbx_pinned_alloc.restype = vp
     L.orbx_pinned_free.argtypes = [vp]; L.orbx_pinned_free.restype = None
     L.orbx_extract_color.argtypes = [vp, vp, i, i, sz, i, i, vp, vp, i, ip, vp, sz]
@@ -263,6 +265,23 @@ class ORBextractor:
         _check(self._L.orbx_extract_stereo(self._h, _p(L_), _p(R_), w, h, L_.strides[0], bf, min_z, _p(kps), _p(desc), cap, _p(n), _p(ur), _p(z)))
         return (kps[0, :n[0]].copy(), desc[0, :n[0]].copy(), kps[1, :n[1]].copy(), desc[1, :n[1]].copy(), ur[:n[0]].copy(), z[:n[0]].copy())
 
+    def extract_submit(self, image):
+        """pipelined monocular form of __call__ -> ticket"""
+        if image.ndim != 2 or image.dtype != np.uint8 or image.strides[1] != 1:
+            raise OrbxError(-1, "image must be a 2-D uint8 array with unit column stride")
+        h, w = image.shape
+        t = C.c_int()
+        _check(self._L.orbx_extract_submit(self._h, image.ctypes.data, w, h, image.strides[0], C.byref(t)))
+        self._pipe_shapes = getattr(self, "_pipe_shapes", {}); self._pipe_shapes[t.value] = (w, h); self._pipe_last = (w, h)
+        return t.value
+
+    def extract_wait(self, ticket):
+        w, h = self._pipe_shapes.pop(ticket, self._pipe_last)       # an unknown ticket is the library's error to report
+        cap = self.max_keypoints(w, h)
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int()
+        _check(self._L.orbx_extract_wait(self._h, ticket, _p(kps), _p(desc), cap, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
     # -- pipelined form: up to pipeline_depth() frames in flight, uploads / downloads overlap the kernels of the neighbouring frames
     def extract_stereo_submit(self, imLeft, imRight, bf, min_z):
         """-> ticket; the images are copied (or, if they live in pinned_array() memory, must stay untouched until the wait)"""
@@ -271,11 +290,11 @@ class ORBextractor:
         h, w = imLeft.shape
         t = C.c_int()
         _check(self._L.orbx_extract_stereo_submit(self._h, imLeft.ctypes.data, imRight.ctypes.data, w, h, imLeft.strides[0], bf, min_z, C.byref(t)))
-        self._pipe_shape = (w, h)
+        self._pipe_shapes = getattr(self, "_pipe_shapes", {}); self._pipe_shapes[t.value] = (w, h); self._pipe_last = (w, h)
         return t.value
 
     def extract_stereo_wait(self, ticket, copy=True):
-        w, h = self._pipe_shape
+        w, h = self._pipe_shapes.get(ticket, self._pipe_last)
         cap = self.max_keypoints(w, h)
         b = getattr(self, "_pipe_out", None)
         if b is None or b[0].shape[1] != cap:
@@ -283,6 +302,7 @@ class ORBextractor:
                                   np.zeros(cap, np.float32), np.zeros(cap, np.float32))
         kps, desc, n, ur, z = b
         _check(self._L.orbx_extract_stereo_wait(self._h, ticket, _p(kps), _p(desc), cap, _p(n), _p(ur), _p(z)))
+        self._pipe_shapes.pop(ticket, None)
         if not copy:      # views into buffers that the next wait overwrites (measurement loops)
             return kps[0, :n[0]], desc[0, :n[0]], kps[1, :n[1]], desc[1, :n[1]], ur[:n[0]], z[:n[0]]
         return (kps[0, :n[0]].copy(), desc[0, :n[0]].copy(), kps[1, :n[1]].copy(), desc[1, :n[1]].copy(), ur[:n[0]].copy(), z[:n[0]].copy())

@@ -548,3 +548,36 @@ def test_extract_stereo_pipelined(pkg, oracle, pinned):
     got = ex.extract_stereo(np.asarray(pairs[2][0]), np.asarray(pairs[2][1]), bf, b)
     for g_, e_ in zip(got, exp[2]):
         assert g_.tobytes() == e_.tobytes()
+
+
+@pytest.mark.gpu
+def test_extract_pipelined_mono_and_mixed(pkg, oracle):
+    """orbx_extract_submit / _wait (monocular stream), interleaved with stereo tickets on the same handle, and across a change
+    of image size while frames are in flight"""
+    bf, b = 386.1448, 386.1448 / 718.856
+    ex = pkg.ORBextractor(800, 1.2, 8, 20, 7, device=0, max_size=(752, 480), max_batch=2)
+    orc = oracle.Oracle(800, 1.2, 8, 20, 7)
+    a = [synth.image(810 + i, 752, 480) for i in range(3)]
+    small = synth.image(820, 640, 360)
+    t0 = ex.extract_submit(a[0]); t1 = ex.extract_submit(a[1])
+    l, r, _ = synth.stereo_pair(830, 752, 480)
+    t2 = ex.extract_stereo_submit(l, r, bf, b)
+    for t, im in ((t0, a[0]), (t1, a[1])):
+        k, d = ex.extract_wait(t)
+        ok, od = orc.extract(im)
+        assert k.tobytes() == ok.tobytes() and d.tobytes() == od.tobytes()
+    with pytest.raises(pkg.OrbxError):          # a stereo ticket cannot be collected through the mono form
+        ex.extract_wait(t2)
+    got = ex.extract_stereo_wait(t2)
+    oL, oR = oracle.Oracle(800, 1.2, 8, 20, 7), oracle.Oracle(800, 1.2, 8, 20, 7)
+    kL, dL = oL.extract(l); kR, dR = oR.extract(r)
+    exp = (kL, dL, kR, dR) + tuple(oracle.stereo_match(oL, oR, kL, dL, kR, dR, bf, b))
+    for g_, e_ in zip(got, exp):
+        assert g_.tobytes() == e_.tobytes()
+    # size change with a frame in flight: the new geometry waits for it, its results stay valid
+    t3 = ex.extract_submit(a[2])
+    t4 = ex.extract_submit(small)
+    k, d = ex.extract_wait(t3); ok, od = orc.extract(a[2])
+    assert k.tobytes() == ok.tobytes() and d.tobytes() == od.tobytes()
+    k, d = ex.extract_wait(t4); ok, od = orc.extract(small)
+    assert k.tobytes() == ok.tobytes() and d.tobytes() == od.tobytes()
