@@ -783,21 +783,20 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     constexpr int xo = 0;
     const int x0a = x - 21;
     if (x >= 21 && x + 21 < L.w && y >= 21 && y + 21 < L.h && x0a + 48 <= pitch) {
-        struct __attribute__((packed)) U32 { uint32_t v; };
         const uint8_t *src = img + (long long)(y - 21) * pitch + x0a;
-        // all nine loads of a lane are issued before the first one is consumed: a rolled loop waits for every load
-        // before the next is issued (nine dependent global round trips per wave, 41 % of the wave's life).
-        // Lane = (row lane/12, dword lane%12) of a 5-row band (60 lanes), band k covers rows 5k..5k+4: one division per
-        // lane instead of one per load, and the LDS offset of band k is an immediate (row pitch = 12 dwords).
+        // nine direct loads (global_load_lds_dword: any byte alignment, no VGPR round trip, no ds_write), all in flight together.
+        // Lane = (row lane/12, dword lane%12) of a 5-row band (60 lanes), band k covers rows 5k..5k+4 and lands at raw + 240 k + 4 lane:
+        // row-major with the 48-byte pitch.
         const int lr = lane / 12, lc = lane - lr * 12;
         const uint8_t *lsrc = src + (long long)lr * pitch + 4 * lc;
-        uint32_t pv[9];
+        if (lane < 60) {
 #pragma unroll
-        for (int k = 0; k < 9; k++)
-            if (lane < 60 && lr + 5 * k < 43) pv[k] = reinterpret_cast<const U32 *>(lsrc + (long long)(5 * k) * pitch)->v;
-#pragma unroll
-        for (int k = 0; k < 9; k++)
-            if (lane < 60 && lr + 5 * k < 43) reinterpret_cast<uint32_t *>(raw)[lane + 60 * k] = pv[k];
+            for (int k = 0; k < 8; k++)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(lsrc + (long long)(5 * k) * pitch), reinterpret_cast<uint32_t *>(raw + 240 * k), 4, 0, 0);
+            if (lr < 3)   // rows 40..42
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(lsrc + (long long)40 * pitch), reinterpret_cast<uint32_t *>(raw + 240 * 8), 4, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else { // image edge (BORDER_REFLECT_101 of the cloned level, :1312-1314)
         for (int e = lane; e < 43 * 43; e += 64) {
             const int r = e / 43, c = e - r * 43;
