@@ -77,36 +77,40 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// exclusive scan of one value per thread over a 256-thread workgroup; s_w = 4 ints of LDS
-__device__ __forceinline__ int block_excl_scan256(int v, int *total, int *s_w)
+// exclusive scan of one value per thread over an NT-thread workgroup (NT = 256 or 1024); s_w = NT / 64 ints of LDS
+template <int NT>
+__device__ __forceinline__ int block_excl_scan(int v, int *total, int *s_w)
 {
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     const int inc = wave_incl_scan(v);
     if (lane == WAVE - 1) s_w[wv] = inc;
     __syncthreads();
-    int base = 0;
-    for (int i = 0; i < wv; i++) base += s_w[i];
-    const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NT / WAVE; i++) { const int t = s_w[i]; if (i < wv) base += t; tot += t; }
     __syncthreads();
     *total = tot;
     return base + inc - v;
 }
+__device__ __forceinline__ int block_excl_scan256(int v, int *total, int *s_w) { return block_excl_scan<256>(v, total, s_w); }
 
-// in-place exclusive scan of an LDS array a[0..m) by a 256-thread workgroup; returns the total.
+// in-place exclusive scan of an LDS array a[0..m) by an NT-thread workgroup; returns the total.
 // Callers must __syncthreads() before (inputs complete); outputs are visible on return.
-__device__ __forceinline__ int lds_excl_scan(int *a, int m, int *s_w)
+template <int NT>
+__device__ __forceinline__ int lds_excl_scan_nt(int *a, int m, int *s_w)
 {
-    const int per = (m + 255) >> 8;
+    const int per = (m + NT - 1) / NT;
     const int beg = threadIdx.x * per;
     const int end = beg + per < m ? beg + per : m;
     int s = 0;
     for (int i = beg; i < end; i++) s += a[i];
     int tot;
-    int run = block_excl_scan256(s, &tot, s_w);
+    int run = block_excl_scan<NT>(s, &tot, s_w);
     for (int i = beg; i < end; i++) { int t = a[i]; a[i] = run; run += t; }
     __syncthreads();
     return tot;
 }
+__device__ __forceinline__ int lds_excl_scan(int *a, int m, int *s_w) { return lds_excl_scan_nt<256>(a, m, s_w); }
 
 // floor(i / d) for 0 <= i < 2^16, 1 <= d < 2^16 by multiply-high (d == 1 would overflow the magic)
 struct FastDiv {

@@ -486,7 +486,10 @@ extern "C" int orbx_diag_fast_stamps(unsigned long long *out, int reset)
 // One 256-thread workgroup per (level, image).
 extern __shared__ __align__(16) unsigned char tree_smem[];
 
-__global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const int *__restrict__ cell_cnt,
+// NT threads per workgroup: 256 for batches (many (level, image) workgroups co-resident per CU), 1024 when a launch has
+// fewer workgroups than the chip has CUs (a single frame: the longest workgroup's latency chain IS the kernel time)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const int *__restrict__ cell_cnt,
                                               const uint32_t *__restrict__ cand, uint32_t *__restrict__ g_pts,
                                               uint16_t *__restrict__ g_nid, int *__restrict__ lvl_cnt,
                                               uint32_t *__restrict__ lvl_kp, int lds_pts_cap, int *__restrict__ err_flag,
@@ -519,15 +522,15 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
     (void)tab_bytes;
     uint32_t *lpts = reinterpret_cast<uint32_t *>(cellpref + ((g->max_cells_level + 4) & ~3));
     uint16_t *lnid = reinterpret_cast<uint16_t *>(lpts + lds_pts_cap);
-    __shared__ int s_w[4];
+    __shared__ int s_w[NT / 64];
     __shared__ int s_acc;
 
     int *out_cnt = lvl_cnt + (long long)b * g->nlevels + l;
     // ---- gather this level's candidates (cell-row-major, in-cell row-major)
     const int *ccnt = cell_cnt + (long long)b * g->total_cells + L.cell_base;
-    for (int c = tid; c < L.n_cells; c += 256) cellpref[c] = ccnt[c];
+    for (int c = tid; c < L.n_cells; c += NT) cellpref[c] = ccnt[c];
     __syncthreads();
-    const int n = lds_excl_scan(cellpref, L.n_cells, s_w);
+    const int n = lds_excl_scan_nt<NT>(cellpref, L.n_cells, s_w);
     if (n == 0) {
         if (tid == 0) *out_cnt = 0;
         return;
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
     }
     {   // one thread per cell: the copies of different cells are independent loads in flight together
         const uint32_t *src = cand + (long long)b * g->cand_total + L.cand_off;
-        for (int c = tid; c < L.n_cells; c += 256) {
+        for (int c = tid; c < L.n_cells; c += NT) {
             const int beg = cellpref[c], end = c + 1 < L.n_cells ? cellpref[c + 1] : n;
             const uint32_t *s = src + (long long)c * L.cand_cap;
             for (int e = 0; e < end - beg; e++) pts[beg + e] = s[e];
@@ -549,26 +552,26 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
     }
     // ---- roots (src/ORBextractor.cc:627-705)
     const int N = L.quota;
-    for (int k = tid; k < L.n_ini; k += 256) cc[k] = 0;
+    for (int k = tid; k < L.n_ini; k += NT) cc[k] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NT) {
         int r = (int)((float)(pts[i] & 0xFFF) / L.hx);
         r = r < 0 ? 0 : r >= L.n_ini ? L.n_ini - 1 : r;
         atomicAdd(&cc[r], 1);
         nid[i] = (uint16_t)r;
     }
     __syncthreads();
-    for (int k = tid; k < L.n_ini; k += 256) a1[k] = cc[k] > 0;
+    for (int k = tid; k < L.n_ini; k += NT) a1[k] = cc[k] > 0;
     __syncthreads();
-    int m = lds_excl_scan(a1, L.n_ini, s_w);
-    for (int k = tid; k < L.n_ini; k += 256)
+    int m = lds_excl_scan_nt<NT>(a1, L.n_ini, s_w);
+    for (int k = tid; k < L.n_ini; k += NT)
         if (cc[k] > 0) {
             const int id = a1[k];
             const unsigned x0 = (unsigned)(int)(L.hx * (float)k), x1 = (unsigned)(int)(L.hx * (float)(k + 1));
             box[id] = make_uint2(x0 | (x1 << 16), 0u | ((unsigned)L.tree_h << 16));
             cnt[id] = cc[k];
         }
-    for (int i = tid; i < n; i += 256) nid[i] = (uint16_t)a1[nid[i]];
+    for (int i = tid; i < n; i += NT) nid[i] = (uint16_t)a1[nid[i]];
     __syncthreads();
 
     // ---- sweeps.  Invariant at the top of the loop: cc[0..4m) holds the child counts of the current
@@ -585,9 +588,9 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
         }
         return c;
     };
-    for (int k = tid; k < 4 * m; k += 256) cc[k] = 0;
+    for (int k = tid; k < 4 * m; k += NT) cc[k] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NT) {
         const int id = nid[i];
         nid[i] = (uint16_t)(id | (classify(id, pts[i], cnt, box, cc) << NB));
     }
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
         if (!phase2) {
             // processing order == list order: one packed scan gives both the children offset of every split
             // node (low 16 bits) and the rank of every unsplit node (high 16 bits)
-            for (int k = tid; k < m; k += 256) {
+            for (int k = tid; k < m; k += NT) {
                 const int sp = cnt[k] > 1;
                 const int ncv = sp ? (cc[4 * k] > 0) + (cc[4 * k + 1] > 0) + (cc[4 * k + 2] > 0) + (cc[4 * k + 3] > 0) : 0;
                 ncarr[k] = ncv;
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
             }
             if (tid == 0) s_acc = 0;
             __syncthreads();
-            const int tot = lds_excl_scan(a2, m, s_w);
+            const int tot = lds_excl_scan_nt<NT>(a2, m, s_w);
             S = tot & 0xFFFF; U = tot >> 16;
         } else {
             // processing order: count desc, list position asc (src/ORBextractor.cc:832-834 with the
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
             if (tid == 0) s_acc = 0;
             __syncthreads();
             int ncand_local = 0;
-            for (int k = tid; k < m; k += 256) {
+            for (int k = tid; k < m; k += NT) {
                 const int ck = cnt[k];
                 int r = -1, ncv = 0;
                 if (ck > 1) {
@@ -633,29 +636,29 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
             if (ncand_local) atomicAdd(&s_acc, ncand_local);
             __syncthreads();
             const int ncand = s_acc;
-            for (int k = tid; k < m; k += 256)
+            for (int k = tid; k < m; k += NT)
                 if (a1[k] >= 0) { a2[a1[k]] = ncarr[k] - 1; a4[a1[k]] = ncarr[k] - 1; }
             __syncthreads();
             if (tid == 0) s_acc = 0;
-            lds_excl_scan(a2, ncand, s_w);
+            lds_excl_scan_nt<NT>(a2, ncand, s_w);
             int less = 0;
-            for (int r = tid; r < ncand; r += 256) less += (prev + a2[r] + a4[r] < N);
+            for (int r = tid; r < ncand; r += NT) less += (prev + a2[r] + a4[r] < N);
             if (less) atomicAdd(&s_acc, less);
             __syncthreads();
             nsplit = min(ncand, s_acc + 1);
             __syncthreads();
-            for (int k = tid; k < m; k += 256) {
+            for (int k = tid; k < m; k += NT) {
                 const bool sp = a1[k] >= 0 && a1[k] < nsplit;
                 if (!sp) ncarr[k] = 0;
                 a3[k] = !sp;
             }
             if (tid == 0) s_acc = 0;
             __syncthreads();
-            for (int k = tid; k < m; k += 256)
+            for (int k = tid; k < m; k += NT)
                 if (ncarr[k] > 0) a2[a1[k]] = ncarr[k];
             __syncthreads();
-            S = lds_excl_scan(a2, nsplit, s_w);
-            U = lds_excl_scan(a3, m, s_w);
+            S = lds_excl_scan_nt<NT>(a2, nsplit, s_w);
+            U = lds_excl_scan_nt<NT>(a3, m, s_w);
         }
         if (S + U > cap) { // cannot happen (SURVEY.md A.4 bound); never write out of bounds
             if (tid == 0) { atomicExch(err_flag, 1); *out_cnt = 0; }
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
         }
         // ---- apply: build the next table, turn cc into child positions, zero the next table's counters
         int expand_local = 0;
-        for (int k = tid; k < m; k += 256) {
+        for (int k = tid; k < m; k += NT) {
             if (ncarr[k] > 0) {
                 const uint2 bx = box[k];
                 const int x0 = bx.x & 0xFFFF, x1 = bx.x >> 16, y0 = bx.y & 0xFFFF, y1 = bx.y >> 16;
@@ -698,7 +701,7 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
         const bool done = m >= N || m == prev;                     // :803-806, :883-884
         if (!phase2 && !done && m + 3 * n_to_expand > N) phase2 = true; // :814
         if (done) {
-            for (int i = tid; i < n; i += 256) {
+            for (int i = tid; i < n; i += NT) {
                 const int v = nid[i];
                 nid[i] = (uint16_t)cc[(v & NMASK) * 4 + (v >> NB)];
             }
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
             break;
         }
         // ---- relabel fused with the next sweep's classification (one pass over the points)
-        for (int i = tid; i < n; i += 256) {
+        for (int i = tid; i < n; i += NT) {
             const int v = nid[i];
             const int id = cc[(v & NMASK) * 4 + (v >> NB)];
             nid[i] = (uint16_t)(id | (classify(id, pts[i], cnt_n, box_n, cc_n) << NB));
@@ -718,13 +721,13 @@ __global__ __launch_bounds__(256) void k_tree(const Geom *__restrict__ g, const 
 
     // ---- one keypoint per leaf: max response, first in list order wins ties (:895-912)
     unsigned *best = reinterpret_cast<unsigned *>(cc);
-    for (int k = tid; k < m; k += 256) best[k] = 0;
+    for (int k = tid; k < m; k += NT) best[k] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 256)
+    for (int i = tid; i < n; i += NT)
         atomicMax(&best[nid[i] & NMASK], ((pts[i] >> 24) << 24) | (0xFFFFFFu - (unsigned)i));
     __syncthreads();
     uint32_t *okp = lvl_kp + (long long)b * g->kp_total + L.kp_off;
-    for (int k = tid; k < m; k += 256) {
+    for (int k = tid; k < m; k += NT) {
         const uint32_t p = pts[0xFFFFFFu - (best[k] & 0xFFFFFFu)];
         const unsigned x = (p & 0xFFF) + ORBX_MIN_BORDER, y = ((p >> 12) & 0xFFF) + ORBX_MIN_BORDER;
         if (k < L.kp_cap) okp[k] = x | (y << 12) | (p & 0xFF000000u);
@@ -1128,7 +1131,9 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
     ORBX_HIP(hipMemcpy(e->d_tabs, tabs.data(), tabs.size() * 2, hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(e->d_cells, cells.data(), cells.size() * sizeof(CellRec), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(e->d_geom, &G, sizeof G, hipMemcpyHostToDevice));
-    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree), hipFuncAttributeMaxDynamicSharedMemorySize,
+    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)tree_lds_bytes(G, lds_pts_cap(G))));
+    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)tree_lds_bytes(G, lds_pts_cap(G))));
     e->geom = G;
     return ORBX_OK;
@@ -1328,9 +1333,14 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
     orbx_prof_end(e, s);
     int *err_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;
     orbx_prof_begin(e, ORBX_STAGE_TREE, s);
-    hipLaunchKernelGGL(k_tree, dim3(batch, G.nlevels), dim3(256), tree_lds_bytes(G, lds_pts_cap(G)), s, e->d_geom,
-                       e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, lds_pts_cap(G), err_flag,
-                       tree_tab_in_lds(G) ? nullptr : e->d_tree_tab, (long long)align_up(tree_tab_bytes(G), 256));
+    if (batch * G.nlevels >= 256)
+        hipLaunchKernelGGL(k_tree<256>, dim3(batch, G.nlevels), dim3(256), tree_lds_bytes(G, lds_pts_cap(G)), s, e->d_geom,
+                           e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, lds_pts_cap(G), err_flag,
+                           tree_tab_in_lds(G) ? nullptr : e->d_tree_tab, (long long)align_up(tree_tab_bytes(G), 256));
+    else    // fewer workgroups than CUs: 1024 threads each shorten the per-workgroup chain (a single stereo frame: 51 -> ~30 us)
+        hipLaunchKernelGGL(k_tree<1024>, dim3(batch, G.nlevels), dim3(1024), tree_lds_bytes(G, lds_pts_cap(G)), s, e->d_geom,
+                           e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, lds_pts_cap(G), err_flag,
+                           tree_tab_in_lds(G) ? nullptr : e->d_tree_tab, (long long)align_up(tree_tab_bytes(G), 256));
     orbx_prof_end(e, s);
     orbx_prof_begin(e, ORBX_STAGE_DESC, s);
     hipLaunchKernelGGL(k_desc, dim3(G.kp_total, batch), dim3(64), 0, s, e->d_geom, pr, e->d_lvl_cnt, e->d_lvl_kp,
