@@ -743,13 +743,24 @@ __global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const i
 // compared with one ballot per 64 pairs (computeOrbDescriptor, :116-157).
 __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef pr, const int *__restrict__ lvl_cnt,
                                              const uint32_t *__restrict__ lvl_kp, orbx_keypoint *__restrict__ out_kps,
-                                             uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap)
+                                             uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap, int nimg)
 {
     constexpr int RP = 48, HR = 44, BP = 40; // LDS pitches: raw bytes, row-pass u16 (stored column-major, 44 rows per column), blurred bytes
     __shared__ __align__(16) uint8_t raw[43 * RP + 16];
     __shared__ __align__(16) uint16_t hb[40 * HR];
     uint8_t *bl = raw; // the blurred patch overwrites the raw one (dead after the row pass): 5.5 KB per wave, 29 waves/CU
-    const int slot = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (linear id % 8, speed only): XCD x walks the images x, x + 8, x + 16, ...
+    // one after the other, so the patches its waves fetch at any time come from one or two images (1.4 MB of pyramid each)
+    // instead of from every image in flight on the chip: the per-XCD L2 (4 MB) then holds them
+    const int lane = threadIdx.x;
+    int slot, b;
+    {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
+        const unsigned per = (unsigned)g->kp_total, grp = seq / per;
+        slot = (int)(seq - grp * per);
+        b = (int)(grp * 8u + xcd);
+        if (b >= nimg) return;
+    }
     int l = 0;
     while (l + 1 < g->nlevels && slot >= g->lv[l + 1].kp_off) l++;
     const LevelGeom &L = g->lv[l];
@@ -1343,8 +1354,8 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
                            tree_tab_in_lds(G) ? nullptr : e->d_tree_tab, (long long)align_up(tree_tab_bytes(G), 256));
     orbx_prof_end(e, s);
     orbx_prof_begin(e, ORBX_STAGE_DESC, s);
-    hipLaunchKernelGGL(k_desc, dim3(G.kp_total, batch), dim3(64), 0, s, e->d_geom, pr, e->d_lvl_cnt, e->d_lvl_kp,
-                       (orbx_keypoint *)d_kps, (uint8_t *)d_desc, (int *)d_n_out, cap);
+    hipLaunchKernelGGL(k_desc, dim3(G.kp_total, (batch + 7) / 8 * 8), dim3(64), 0, s, e->d_geom, pr, e->d_lvl_cnt, e->d_lvl_kp,
+                       (orbx_keypoint *)d_kps, (uint8_t *)d_desc, (int *)d_n_out, cap, batch);
     orbx_prof_end(e, s);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
