@@ -265,7 +265,7 @@ __device__ unsigned long long g_desc_stamp[4096 * 8]; // same for k_desc
 // 64-byte pitch (rows r, r + 2 on the same banks) the byte reads of the score network ran 3.4x the bank-conflict cycles.
 template <int P, int SP>
 __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *__restrict__ cells, PyrRef pr,
-                                             int *__restrict__ cell_cnt, uint32_t *__restrict__ cand)
+                                             int *__restrict__ cell_cnt, uint32_t *__restrict__ cand, uint32_t *__restrict__ cand_prim)
 {
     constexpr int DWR = P / 4;      // dwords per tile row = lanes per row of one direct load
     constexpr int RPL = 64 / DWR;   // whole tile rows per direct load (lanes >= RPL * DWR stay idle)
@@ -351,6 +351,7 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
     const unsigned vmask = lr < rpi ? (0x80808080u >> (8 * (4 - nvalid))) : 0u;
     const int bm_sh = 4 * (gq & 7);
     uint32_t *slot = cand + (long long)b * fa.cand_total + rec.cand_slot;
+    uint32_t *prim = cand_prim + ((long long)b * fa.total_cells + cell) * ORBX_CAND_PRIM;   // the first 16 candidates: dense, 64 B per cell
     int th_cur = ini_th, nsurv = 0;
     for (int pass = 0; pass < 2; pass++) {
         // ---- 2. SWAR pretest.  With s = t + 1 and x7 = x >> 1 per byte: x < c - t  ==>  x7 <= c7 - s7 (dark) and
@@ -436,13 +437,13 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
         while (lo) {
             const int px = __builtin_ctz(lo);
             lo &= lo - 1;
-            if (o < rec.cand_cap) slot[o] = (uint32_t)(X0 + px) | ((uint32_t)Y << 12) | ((uint32_t)srow[px] << 24);
+            if (o < rec.cand_cap) (o < ORBX_CAND_PRIM ? prim : slot)[o] = (uint32_t)(X0 + px) | ((uint32_t)Y << 12) | ((uint32_t)srow[px] << 24);
             o++;
         }
         while (hi) {
             const int px = 32 + __builtin_ctz(hi);
             hi &= hi - 1;
-            if (o < rec.cand_cap) slot[o] = (uint32_t)(X0 + px) | ((uint32_t)Y << 12) | ((uint32_t)srow[px] << 24);
+            if (o < rec.cand_cap) (o < ORBX_CAND_PRIM ? prim : slot)[o] = (uint32_t)(X0 + px) | ((uint32_t)Y << 12) | ((uint32_t)srow[px] << 24);
             o++;
         }
         if (lane == 0) *my_cnt = min(total, rec.cand_cap);
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const i
                                               const uint32_t *__restrict__ cand, uint32_t *__restrict__ g_pts,
                                               uint16_t *__restrict__ g_nid, int *__restrict__ lvl_cnt,
                                               uint32_t *__restrict__ lvl_kp, int lds_pts_cap, int *__restrict__ err_flag,
-                                              unsigned char *__restrict__ g_tab, long long g_tab_stride)
+                                              unsigned char *__restrict__ g_tab, long long g_tab_stride, const uint32_t *__restrict__ cand_prim)
 {
     constexpr int NB = ORBX_NODE_BITS, NMASK = (1 << NB) - 1;
     // x = image, y = level: workgroups are dealt to the 8 XCDs by linear id % 8, so every XCD gets the same mix of
@@ -547,7 +548,8 @@ __global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const i
         for (int c = tid; c < L.n_cells; c += NT) {
             const int beg = cellpref[c], end = c + 1 < L.n_cells ? cellpref[c + 1] : n;
             const uint32_t *s = src + (long long)c * L.cand_cap;
-            for (int e = 0; e < end - beg; e++) pts[beg + e] = s[e];
+            const uint32_t *pr = cand_prim + ((long long)b * g->total_cells + L.cell_base + c) * ORBX_CAND_PRIM;
+            for (int e = 0; e < end - beg; e++) pts[beg + e] = e < ORBX_CAND_PRIM ? pr[e] : s[e];
         }
     }
     // ---- roots (src/ORBextractor.cc:627-705)
@@ -1126,6 +1128,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
     if ((rc = ensure(&e->d_pyr, &e->pyr_cap, (size_t)G.pyr_bytes * B))) return rc;
     if ((rc = ensure(&e->d_cell_cnt, &e->cell_cnt_cap, (size_t)G.total_cells * B * 4))) return rc;
     if ((rc = ensure(&e->d_cand, &e->cand_cap, (size_t)G.cand_total * B * 4))) return rc;
+    if ((rc = ensure(&e->d_cand_prim, &e->cand_prim_cap, (size_t)G.total_cells * B * ORBX_CAND_PRIM * 4))) return rc;
     {
         size_t need = (size_t)G.cand_total * B;
         if (need > e->tree_cap || !e->d_tree_pts) {
@@ -1237,7 +1240,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *e)
     if (e->stream) hipStreamSynchronize(e->stream);
     for (auto &ev : e->prof_ev) { if (ev.owns_a && ev.a) hipEventDestroy(ev.a); if (ev.b) hipEventDestroy(ev.b); }
     for (auto ev : e->prof_pool) hipEventDestroy(ev);
-    void *ptrs[] = { e->d_tree_tab, e->d_cells, e->d_geom, e->d_tabs, e->d_pyr, e->d_stage_in, e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid,
+    void *ptrs[] = { e->d_cand_prim, e->d_tree_tab, e->d_cells, e->d_geom, e->d_tabs, e->d_pyr, e->d_stage_in, e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid,
                      e->d_lvl_cnt, e->d_lvl_kp, e->d_out_kps, e->d_out_desc, e->d_out_n, e->d_out_ur, e->d_out_depth, e->d_st_dist, e->d_st_entries };
     for (void *p : ptrs) if (p) hipFree(p);
     for (void *p : e->scratch) if (p) hipFree(p);
@@ -1336,10 +1339,10 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
         fa.bm_rows = G.fast_bm_rows; fa.ini_th = e->ini_th; fa.min_th = e->min_th; fa.cand_total = G.cand_total;
         const dim3 grid((G.total_cells + 8 * FAST_XG - 1) / (8 * FAST_XG) * (8 * FAST_XG), batch);
         if (G.fast_small)
-            hipLaunchKernelGGL((k_fast<48, 40>), grid, dim3(64), G.fast_lds_bytes, s, fa, e->d_cells, pr, e->d_cell_cnt, e->d_cand);
+            hipLaunchKernelGGL((k_fast<48, 40>), grid, dim3(64), G.fast_lds_bytes, s, fa, e->d_cells, pr, e->d_cell_cnt, e->d_cand, e->d_cand_prim);
         else
             hipLaunchKernelGGL((k_fast<ORBX_TILE_PITCH, ORBX_SCORE_PITCH>), grid, dim3(64), G.fast_lds_bytes, s, fa, e->d_cells, pr, e->d_cell_cnt,
-                               e->d_cand);
+                               e->d_cand, e->d_cand_prim);
     }
     orbx_prof_end(e, s);
     int *err_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;
@@ -1347,11 +1350,11 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
     if (batch * G.nlevels >= 256)
         hipLaunchKernelGGL(k_tree<256>, dim3(batch, G.nlevels), dim3(256), tree_lds_bytes(G, lds_pts_cap(G)), s, e->d_geom,
                            e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, lds_pts_cap(G), err_flag,
-                           tree_tab_in_lds(G) ? nullptr : e->d_tree_tab, (long long)align_up(tree_tab_bytes(G), 256));
+                           tree_tab_in_lds(G) ? nullptr : e->d_tree_tab, (long long)align_up(tree_tab_bytes(G), 256), e->d_cand_prim);
     else    // fewer workgroups than CUs: 1024 threads each shorten the per-workgroup chain (a single stereo frame: 51 -> ~30 us)
         hipLaunchKernelGGL(k_tree<1024>, dim3(batch, G.nlevels), dim3(1024), tree_lds_bytes(G, lds_pts_cap(G)), s, e->d_geom,
                            e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, lds_pts_cap(G), err_flag,
-                           tree_tab_in_lds(G) ? nullptr : e->d_tree_tab, (long long)align_up(tree_tab_bytes(G), 256));
+                           tree_tab_in_lds(G) ? nullptr : e->d_tree_tab, (long long)align_up(tree_tab_bytes(G), 256), e->d_cand_prim);
     orbx_prof_end(e, s);
     orbx_prof_begin(e, ORBX_STAGE_DESC, s);
     hipLaunchKernelGGL(k_desc, dim3(G.kp_total, (batch + 7) / 8 * 8), dim3(64), 0, s, e->d_geom, pr, e->d_lvl_cnt, e->d_lvl_kp,
@@ -1852,11 +1855,13 @@ extern "C" int orbx_debug_candidates(orbx_extractor *e, int image_index, int lev
     std::vector<uint32_t> slots((size_t)L.n_cells * L.cand_cap);
     ORBX_HIP(hipMemcpy(cnt.data(), e->d_cell_cnt + (size_t)image_index * G.total_cells + L.cell_base, sizeof(int) * L.n_cells, hipMemcpyDeviceToHost));
     ORBX_HIP(hipMemcpy(slots.data(), e->d_cand + (size_t)image_index * G.cand_total + L.cand_off, slots.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> prim((size_t)L.n_cells * ORBX_CAND_PRIM);
+    ORBX_HIP(hipMemcpy(prim.data(), e->d_cand_prim + ((size_t)image_index * G.total_cells + L.cell_base) * ORBX_CAND_PRIM, prim.size() * 4, hipMemcpyDeviceToHost));
     int k = 0;
     for (int c = 0; c < L.n_cells; c++)
         for (int i = 0; i < cnt[c]; i++, k++)
             if (k < cap && x && y && resp) {
-                const uint32_t p = slots[(size_t)c * L.cand_cap + i];
+                const uint32_t p = i < ORBX_CAND_PRIM ? prim[(size_t)c * ORBX_CAND_PRIM + i] : slots[(size_t)c * L.cand_cap + i];
                 x[k] = p & 0xFFF; y[k] = (p >> 12) & 0xFFF; resp[k] = p >> 24;
             }
     *n = k;

@@ -13,6 +13,7 @@
 #define ORBX_SCORE_PITCH 64   // LDS pitch of a FAST cell score tile (detect side <= 59 + 2)
 #define ORBX_MAX_DIM 4096     // packed candidate = x | y<<12 | score<<24
 #define ORBX_NODE_BITS 14     // quadtree node id bits inside the per-point label
+#define ORBX_CAND_PRIM 16      // a cell's first candidates live in a dense 64-byte record (cells contiguous); only the overflow uses its big slot block
 
 // Geometry of one pyramid level for one image size (host computes, device reads).
 struct LevelGeom {
@@ -92,6 +93,7 @@ struct orbx_extractor {
     uint8_t *d_stage_in; size_t stage_in_cap; // host-API input staging (level 0)
     int *d_cell_cnt; size_t cell_cnt_cap;
     uint32_t *d_cand; size_t cand_cap;
+    uint32_t *d_cand_prim; size_t cand_prim_cap;   // [max_batch][total_cells][ORBX_CAND_PRIM]
     uint32_t *d_tree_pts; uint16_t *d_tree_nid; size_t tree_cap; // overflow scratch of the quadtree
     unsigned char *d_tree_tab; size_t tree_tab_cap; // quadtree node tables of configurations whose tables exceed the LDS (else unused)
     int *d_lvl_cnt;                        // [max_batch][nlevels]
