@@ -79,43 +79,45 @@ __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, in
         a0[i] = q.y;
         a1[i] = q.z;
     }
-    // the 16 output rows' vertical table entries (source row, b0, b1): wave-uniform, fetched up front as scalars so that
-    // no scalar-memory wait sits between the LDS reads below (the table buffer is padded for the last tile's overread)
-    short4 qy[RS_TH];
+    // Per SOURCE row of the tile (wave-uniform, fetched up front as scalars so that no scalar-memory wait sits between the LDS
+    // reads below): which output row is complete once this source row has been interpolated, and its vertical weights
+    // (host table `tab_s`: (y | same << 13 | two << 14, b0, b1, 0) or y = -1; the buffer is padded for the overread).
+    const int16_t *ts = tabs + D.tab_s + 4 * sy_min;
+    short4 qs[RS_ROWS];
 #pragma unroll
-    for (int j = 0; j < RS_TH; j++) qy[j] = *reinterpret_cast<const short4 *>(ty + 4 * (y_t + j));
+    for (int k = 0; k < RS_ROWS; k++) qs[k] = *reinterpret_cast<const short4 *>(ts + 4 * k);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the direct loads have landed in LDS
     __syncthreads();
-    // running LDS addresses of the lane's four source bytes in the NEXT source row to interpolate
     const uint8_t *p00 = src_t + o0[0], *p01 = src_t + o1[0], *p10 = src_t + o0[1], *p11 = src_t + o1[1];
-#define STEP() do { hp0 = hc0; hp1 = hc1; hc0 = (p00[0] * a0[0] + p01[0] * a1[0]) >> 4; hc1 = (p10[0] * a0[1] + p11[0] * a1[1]) >> 4; \
-                    p00 += RS_PITCH; p01 += RS_PITCH; p10 += RS_PITCH; p11 += RS_PITCH; k++; } while (0)
-    const int s_h = S.h, d_w = D.w, d_pitch = D.pitch;   // scalars: not reloaded behind the stores
-    int k = 0;                                  // source rows interpolated so far (wave-uniform)
-    int hp0 = 0, hp1 = 0, hc0 = 0, hc1 = 0;     // (t >> 4) of source rows k - 2 and k - 1
-    uint8_t *drow = dst + (long long)y_t * D.pitch + x2;
+    const int d_w = D.w, d_pitch = D.pitch;     // scalars: not reloaded behind the stores
+    int hp0 = 0, hp1 = 0, hc0 = 0, hc1 = 0;     // (t >> 4) of source rows k - 1 and k
+    uint8_t *dcol = dst + x2;
+    // the weights are non-negative and each pair sums to 2048 (+-1 by rounding), so v stays inside [0, 255]:
+    // ((2049 * (255 * 2049 >> 4)) >> 16) + 2 >> 2 == 255 -- cv::resize's saturate_cast never fires for INTER_LINEAR
+#define EMIT(Y, B0, B1, HA0, HA1) do { \
+        const int v0 = ((((B0) * (HA0)) >> 16) + (((B1) * hc0) >> 16) + 2) >> 2, v1 = ((((B0) * (HA1)) >> 16) + (((B1) * hc1) >> 16) + 2) >> 2; \
+        if (x2 < d_w) *reinterpret_cast<uint16_t *>(dcol + (long long)(Y) * d_pitch) = (uint16_t)(v0 | (v1 << 8)); } while (0)
 #pragma unroll
-    for (int j = 0; j < RS_TH; j++) {
-        if (y_t + j <= y_last) {                // wave-uniform (every lane of the tile has the same rows)
-            const int sy0 = __builtin_amdgcn_readfirstlane((int)qy[j].x), b0 = __builtin_amdgcn_readfirstlane((int)qy[j].y),
-                      b1 = __builtin_amdgcn_readfirstlane((int)qy[j].z);
-            const int ra = sy0 - sy_min, rb = min(sy0 + 1, s_h - 1) - sy_min;
-            // one or two new source rows per output row (none at the bottom clamp); the trip count is wave-uniform and the
-            // tile only fits the LDS carve for scale factors below 1.375, so two explicit steps cover it (the loop is a guard)
-            if (k <= rb) STEP();
-            if (k <= rb) STEP();
-            while (k <= rb) STEP();
-            // rows (ra, rb) = (k - 2, k - 1), or both k - 1 at the bottom clamp
-            const int ha0 = ra == rb ? hc0 : hp0, ha1 = ra == rb ? hc1 : hp1;
-            // the weights are non-negative and each pair sums to 2048 (+-1 by rounding), so v stays inside [0, 255]:
-            // ((2049 * (255 * 2049 >> 4)) >> 16) + 2 >> 2 == 255 -- cv::resize's saturate_cast never fires for INTER_LINEAR
-            const int v0 = (((b0 * ha0) >> 16) + ((b1 * hc0) >> 16) + 2) >> 2;
-            const int v1 = (((b0 * ha1) >> 16) + ((b1 * hc1) >> 16) + 2) >> 2;
-            if (x2 < d_w) *reinterpret_cast<uint16_t *>(drow) = (uint16_t)(v0 | (v1 << 8));
-            drow += d_pitch;
+    for (int k = 0; k < RS_ROWS; k++) {         // fully unrolled: every LDS offset below is an immediate
+        if (k < nrows) {                        // wave-uniform
+            hp0 = hc0; hp1 = hc1;
+            hc0 = (p00[k * RS_PITCH] * a0[0] + p01[k * RS_PITCH] * a1[0]) >> 4;
+            hc1 = (p10[k * RS_PITCH] * a0[1] + p11[k * RS_PITCH] * a1[1]) >> 4;
+            const int e = __builtin_amdgcn_readfirstlane((int)qs[k].x);
+            if (e >= 0) {
+                const int y = e & 0xFFF;
+                if (y >= y_t && y <= y_last) {  // (the row above the tile can end on the tile's first source row)
+                    const int b0 = __builtin_amdgcn_readfirstlane((int)qs[k].y), b1 = __builtin_amdgcn_readfirstlane((int)qs[k].z);
+                    if (e & 0x2000) EMIT(y, b0, b1, hc0, hc1);          // bottom clamp: both source rows are this one
+                    else EMIT(y, b0, b1, hp0, hp1);
+                }
+                // two output rows end on the clamped last source row when consecutive levels have equal heights: the second one
+                // is y + 1 with both rows = this one and the clamp weights (2048, 0)
+                if ((e & 0x4000) && y + 1 >= y_t && y + 1 <= y_last) EMIT(y + 1, 2048, 0, hc0, hc1);
+            }
         }
     }
-#undef STEP
+#undef EMIT
 }
 
 // Fallback for scale factors whose source rectangle does not fit the LDS tile of k_resize
@@ -1041,6 +1043,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
             G.pyr_bytes += (long long)L.pitch * L.h;
             L.tab_x = (int)tab_units; tab_units += 4 * (size_t)L.w;   // int16 units, multiples of 4: 8-byte aligned quads
             L.tab_y = (int)tab_units; tab_units += 4 * (size_t)L.h;
+            L.tab_s = (int)tab_units; tab_units += 4 * (size_t)G.lv[l - 1].h;   // per SOURCE row: the output row it completes
         }
         if (L.n_cells > G.max_cells_level) G.max_cells_level = L.n_cells;
         if (L.node_cap > G.max_node_cap) G.max_node_cap = L.node_cap;
@@ -1069,12 +1072,25 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         G.fast_lds_bytes = G.fast_lds_bm + 2 * G.fast_bm_rows * 8;
     }
     // resize tables
-    std::vector<int16_t> tabs(tab_units + 4 * RS_TH);   // + one tile's rows: k_resize prefetches 16 vertical entries per tile
+    std::vector<int16_t> tabs(tab_units + 4 * RS_ROWS);   // + one tile's source rows: k_resize prefetches RS_ROWS entries per tile
+    std::vector<char> emit_ok(e->nlevels, 1);
     for (int l = 1; l < e->nlevels; l++) {
         LevelGeom &L = G.lv[l];
         const LevelGeom &S = G.lv[l - 1];
         linear_tables(S.w, L.w, &tabs[L.tab_x]);
         linear_tables(S.h, L.h, &tabs[L.tab_y]);
+        // emit table of k_resize: source row sy -> the output row y whose LOWER source row min(sy0 + 1, S.h - 1) is sy
+        int16_t *ts = &tabs[L.tab_s];
+        const int16_t *ty = &tabs[L.tab_y];
+        for (int sy = 0; sy < S.h; sy++) { ts[4 * sy] = -1; ts[4 * sy + 1] = ts[4 * sy + 2] = ts[4 * sy + 3] = 0; }
+        for (int y = 0; y < L.h; y++) {
+            const int sy0 = ty[4 * y], rb = sy0 + 1 < S.h - 1 ? sy0 + 1 : S.h - 1, same = sy0 == rb;
+            if (ts[4 * rb] < 0) {
+                ts[4 * rb] = (int16_t)(y | (same ? 0x2000 : 0)); ts[4 * rb + 1] = ty[4 * y + 1]; ts[4 * rb + 2] = ty[4 * y + 2];
+            } else if (same && (ts[4 * rb] & 0xFFF) == y - 1 && !(ts[4 * rb] & 0x6000) && ty[4 * y + 1] == 2048 && ty[4 * y + 2] == 0) {
+                ts[4 * rb] |= 0x4000;       // second row on the clamped last source row
+            } else emit_ok[l] = 0;          // not a down-scaling table: such a level takes k_resize_direct
+        }
     }
     for (int l = 1; l < e->nlevels; l++) { // does every output tile's source rectangle fit k_resize's LDS tile?
         LevelGeom &L = G.lv[l];
@@ -1091,7 +1107,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
             const int smax = ty[4 * yl] + 1 < S.h - 1 ? ty[4 * yl] + 1 : S.h - 1;
             if (smax - ty[4 * y0] + 1 > RS_ROWS) ok = false;
         }
-        L.resize_lds = (S.w == 2 * L.w && S.h == 2 * L.h) ? 2 : ok ? 1 : 0;   // 2: area-average kernel path (k_resize_direct)
+        L.resize_lds = (S.w == 2 * L.w && S.h == 2 * L.h) ? 2 : (ok && emit_ok[l] && L.h < 4096) ? 1 : 0;   // 2: area-average kernel path (k_resize_direct)
     }
     std::vector<CellRec> cells(G.total_cells);
     for (int l = 0; l < e->nlevels; l++) {
