@@ -20,25 +20,28 @@ __constant__ int c_gauss[7];              // 8-bit fixed point 7-tap sigma=2 ker
 // ================================================================ K1: pyramid level (E2)
 // cv::resize INTER_LINEAR 8UC1 from level l-1 to level l.  Coefficient tables are
 // computed on the host with the reference's float/double arithmetic; the kernel is pure integer.
-// A one-wave workgroup produces a 128x16 output tile, lane = two adjacent output columns, all 16 rows:
-//  * the source rectangle (<= 156 x 22) goes to LDS with direct loads (global_load_lds_dword, one per source row,
+// A one-wave workgroup produces a 256x16 output tile, lane = four adjacent output columns, all 16 rows:
+//  * the source rectangle (<= 311 x 22) goes to LDS with direct loads (global_load_lds_dword, two per source row,
 //    any byte alignment, no VGPR round trip, no address arithmetic per element);
 //  * the loop runs over SOURCE rows (fully unrolled: every LDS offset is an immediate): the horizontal interpolation
 //    of a source row is computed once and serves the (up to two) output rows it belongs to -- at scale 1.2 that is
 //    1.33 instead of 2 horizontal passes per output row; an output row is emitted as soon as its lower source row
-//    is done.  Which output row that is depends only on the tile (every lane has the same rows): scalar control flow.
+//    is done.  Which output row that is comes from a host table indexed by source row and depends only on the tile (every
+//    lane has the same rows): scalar control flow -- about 500 scalar instructions per tile whatever its width, which
+//    is why a lane takes four columns (with two the kernel was bound by the scalar unit, not by the vector ALUs).
 // One-wave workgroups need no barrier partners and drift apart in time, so loads of one tile overlap arithmetic of
 // another on the same CU.
-#define RS_TW 128
+#define RS_PX 4      // output columns per lane
+#define RS_TW (64 * RS_PX)
 #define RS_TH 16
-#define RS_NT 64     // threads per workgroup = RS_TW / 2: one wave
-#define RS_PITCH 176 // LDS bytes per staged source row (>= 1.2 * RS_TW + 2 + 3, dwords: 44 lanes of a direct load)
+#define RS_NT 64     // threads per workgroup: one wave
+#define RS_PITCH 320 // LDS bytes per staged source row (>= 1.2 * RS_TW + 2 + 3; 80 dwords: the 64 + 16 lanes of two direct loads)
 #define RS_ROWS 22
 
 __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, int l, PyrRef pr,
                                                 uint8_t *__restrict__ pyr_w, const int16_t *__restrict__ tabs)
 {
-    __shared__ __align__(16) uint8_t src_t[RS_ROWS * RS_PITCH + 96];   // + the idle lanes' span of the last row's load
+    __shared__ __align__(16) uint8_t src_t[RS_ROWS * RS_PITCH];
     const LevelGeom &D = g->lv[l];
     const LevelGeom &S = g->lv[l - 1];
     const int b = blockIdx.z, lane = threadIdx.x;
@@ -52,26 +55,31 @@ __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, in
     const int sy_min = __builtin_amdgcn_readfirstlane((int)ty[4 * y_t]), sy_max = min(__builtin_amdgcn_readfirstlane((int)ty[4 * y_last]) + 1, S.h - 1);
     const int nrows = sy_max - sy_min + 1;
     {
-        // dwords that lie wholly inside the source row are fetched by direct loads; the <= 3 bytes a right-edge tile still
-        // needs behind them are fetched as bytes (a dword there could reach past the caller's last image row)
+        // dwords that lie wholly inside the source row are fetched by direct loads (lanes 0..63 -> dwords 0..63, then lanes
+        // 0..15 -> dwords 64..79); the <= 3 bytes a right-edge tile still needs behind them are fetched as bytes (a dword
+        // there could reach past the caller's last image row)
         const int need = sx_max - sx_min + 1, nfull = min((need + 3) >> 2, (S.w - sx_min) >> 2), tail = max(need - 4 * nfull, 0);
         const uint8_t *s0 = src + (long long)sy_min * spitch + sx_min;
         if (lane < nfull)
             for (int r = 0; r < nrows; r++)
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(s0 + (long long)r * spitch + 4 * lane),
                                                  reinterpret_cast<uint32_t *>(src_t + r * RS_PITCH), 4, 0, 0);
+        if (lane + 64 < nfull)
+            for (int r = 0; r < nrows; r++)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(s0 + (long long)r * spitch + 4 * (lane + 64)),
+                                                 reinterpret_cast<uint32_t *>(src_t + r * RS_PITCH + 256), 4, 0, 0);
         if (tail)
             for (int i = lane; i < nrows * tail; i += RS_NT) {
                 const int r = i / tail, c = 4 * nfull + (i - r * tail);
                 src_t[r * RS_PITCH + c] = s0[(long long)r * spitch + c];
             }
     }
-    // the lane's two output columns: source offsets inside the tile and the 11-bit weights
-    const int x2 = x_t + 2 * lane;
-    int o0[2], o1[2], a0[2], a1[2];
+    // the lane's output columns: source offsets inside the tile and the 11-bit weights
+    const int x4 = x_t + RS_PX * lane;
+    int o0[RS_PX], o1[RS_PX], a0[RS_PX], a1[RS_PX];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int x = min(x2 + i, D.w - 1);
+    for (int i = 0; i < RS_PX; i++) {
+        const int x = min(x4 + i, D.w - 1);
         const short4 q = *reinterpret_cast<const short4 *>(tx + 4 * x); // (ofs, a0, a1, 0)
         const int sx0 = q.x;
         o0[i] = sx0 - sx_min;
@@ -88,32 +96,36 @@ __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, in
     for (int k = 0; k < RS_ROWS; k++) qs[k] = *reinterpret_cast<const short4 *>(ts + 4 * k);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the direct loads have landed in LDS
     __syncthreads();
-    const uint8_t *p00 = src_t + o0[0], *p01 = src_t + o1[0], *p10 = src_t + o0[1], *p11 = src_t + o1[1];
     const int d_w = D.w, d_pitch = D.pitch;     // scalars: not reloaded behind the stores
-    int hp0 = 0, hp1 = 0, hc0 = 0, hc1 = 0;     // (t >> 4) of source rows k - 1 and k
-    uint8_t *dcol = dst + x2;
+    int hp[RS_PX], hc[RS_PX];                   // (t >> 4) of source rows k - 1 and k
+#pragma unroll
+    for (int i = 0; i < RS_PX; i++) hp[i] = hc[i] = 0;
+    uint8_t *dcol = dst + x4;
     // the weights are non-negative and each pair sums to 2048 (+-1 by rounding), so v stays inside [0, 255]:
     // ((2049 * (255 * 2049 >> 4)) >> 16) + 2 >> 2 == 255 -- cv::resize's saturate_cast never fires for INTER_LINEAR
-#define EMIT(Y, B0, B1, HA0, HA1) do { \
-        const int v0 = ((((B0) * (HA0)) >> 16) + (((B1) * hc0) >> 16) + 2) >> 2, v1 = ((((B0) * (HA1)) >> 16) + (((B1) * hc1) >> 16) + 2) >> 2; \
-        if (x2 < d_w) *reinterpret_cast<uint16_t *>(dcol + (long long)(Y) * d_pitch) = (uint16_t)(v0 | (v1 << 8)); } while (0)
+#define EMIT(Y, B0, B1, HA) do { \
+        uint32_t out_ = 0; \
+        _Pragma("unroll") for (int i = 0; i < RS_PX; i++) out_ |= (uint32_t)(((((B0) * (HA)[i]) >> 16) + (((B1) * hc[i]) >> 16) + 2) >> 2) << (8 * i); \
+        if (x4 < d_w) *reinterpret_cast<uint32_t *>(dcol + (long long)(Y) * d_pitch) = out_; } while (0)
 #pragma unroll
     for (int k = 0; k < RS_ROWS; k++) {         // fully unrolled: every LDS offset below is an immediate
         if (k < nrows) {                        // wave-uniform
-            hp0 = hc0; hp1 = hc1;
-            hc0 = (p00[k * RS_PITCH] * a0[0] + p01[k * RS_PITCH] * a1[0]) >> 4;
-            hc1 = (p10[k * RS_PITCH] * a0[1] + p11[k * RS_PITCH] * a1[1]) >> 4;
+#pragma unroll
+            for (int i = 0; i < RS_PX; i++) {
+                hp[i] = hc[i];
+                hc[i] = (src_t[k * RS_PITCH + o0[i]] * a0[i] + src_t[k * RS_PITCH + o1[i]] * a1[i]) >> 4;
+            }
             const int e = __builtin_amdgcn_readfirstlane((int)qs[k].x);
             if (e >= 0) {
                 const int y = e & 0xFFF;
                 if (y >= y_t && y <= y_last) {  // (the row above the tile can end on the tile's first source row)
                     const int b0 = __builtin_amdgcn_readfirstlane((int)qs[k].y), b1 = __builtin_amdgcn_readfirstlane((int)qs[k].z);
-                    if (e & 0x2000) EMIT(y, b0, b1, hc0, hc1);          // bottom clamp: both source rows are this one
-                    else EMIT(y, b0, b1, hp0, hp1);
+                    if (e & 0x2000) EMIT(y, b0, b1, hc);                // bottom clamp: both source rows are this one
+                    else EMIT(y, b0, b1, hp);
                 }
                 // two output rows end on the clamped last source row when consecutive levels have equal heights: the second one
                 // is y + 1 with both rows = this one and the clamp weights (2048, 0)
-                if ((e & 0x4000) && y + 1 >= y_t && y + 1 <= y_last) EMIT(y + 1, 2048, 0, hc0, hc1);
+                if ((e & 0x4000) && y + 1 >= y_t && y + 1 <= y_last) EMIT(y + 1, 2048, 0, hc);
             }
         }
     }
