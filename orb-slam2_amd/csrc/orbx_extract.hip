@@ -333,15 +333,15 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
     {
         const int lr0 = lane / DWR, lc = lane - lr0 * DWR;
         const int ndw = (tw + xo + 3) >> 2;             // dwords per row that hold cell pixels (<= 17)
-        const uint8_t *src = img + (long long)ini_y * pitch + (ini_x - xo) + (lr0 * pitch + 4 * lc);
+        // scalar row base + one 32-bit lane offset: the row groups advance on the scalar unit, no 64-bit vector adds per load
+        const uint8_t *base = img + (long long)ini_y * pitch + (ini_x - xo);
+        const unsigned voff = (unsigned)(lr0 * pitch + 4 * lc);
         const int full = th / RPL;
         if (lc < ndw && lr0 < RPL) {
-            for (int k = 0; k < full; k++)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(src + (long long)k * RPL * pitch),
-                                                 reinterpret_cast<uint32_t *>(tile + RPL * P * k), 4, 0, 0);
+            for (int k = 0; k < full; k++, base += (long long)RPL * pitch)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(base + voff), reinterpret_cast<uint32_t *>(tile + RPL * P * k), 4, 0, 0);
             if (full * RPL + lr0 < th)                  // the last, partial group of rows never reads below the cell
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(src + (long long)full * RPL * pitch),
-                                                 reinterpret_cast<uint32_t *>(tile + RPL * P * full), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(base + voff), reinterpret_cast<uint32_t *>(tile + RPL * P * full), 4, 0, 0);
         }
     }
     {   // meanwhile: zero score tile (1-px zero rim included) and both bitmaps
