@@ -457,6 +457,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in stage_ms.items()}}
+    if stereo:   # every stage of the step against the same HBM roof: algorithmic bytes of the stage / its time per step
+        roofline["stage_hbm_frac"] = {k: round(algorithmic_bytes(k if k != "stereo_cut" else "cut", NI, B, nkp_avg) / max(v / args.steps, 1e-9) / 1e6 / HBM_PEAK_GBS, 4)
+                                      for k, v in stage_ms.items() if v > 0}
     if bow_models:
         roofline["byte_models"] = bow_models
     im = load_issue_model()
