@@ -41,7 +41,7 @@ __constant__ int c_gauss[7];              // 8-bit fixed point 7-tap sigma=2 ker
 __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, int l, PyrRef pr,
                                                 uint8_t *__restrict__ pyr_w, const int16_t *__restrict__ tabs)
 {
-    __shared__ __align__(16) uint8_t src_t[RS_ROWS * RS_PITCH];
+    __shared__ __align__(16) uint8_t src_t[(RS_ROWS + 2) * RS_PITCH];   // + the rows the last three-row load may cover
     const LevelGeom &D = g->lv[l];
     const LevelGeom &S = g->lv[l - 1];
     const int b = blockIdx.z, lane = threadIdx.x;
@@ -55,22 +55,21 @@ __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, in
     const int sy_min = __builtin_amdgcn_readfirstlane((int)ty[4 * y_t]), sy_max = min(__builtin_amdgcn_readfirstlane((int)ty[4 * y_last]) + 1, S.h - 1);
     const int nrows = sy_max - sy_min + 1;
     {
-        // dwords that lie wholly inside the source row are fetched by direct loads (lanes 0..63 -> dwords 0..63, then lanes
-        // 0..15 -> dwords 64..79); the <= 3 bytes a right-edge tile still needs behind them are fetched as bytes (a dword
-        // there could reach past the caller's last image row)
-        const int need = sx_max - sx_min + 1, nfull = min((need + 3) >> 2, (S.w - sx_min) >> 2), tail = max(need - 4 * nfull, 0);
+        // 16-byte pieces that lie wholly inside the source row are fetched by direct loads (global_load_lds_dwordx4: 1 KB per wave
+        // instruction, any byte alignment): lane = (row lane / 20, piece lane % 20) of three whole rows per load -- the LDS pitch
+        // of 320 bytes is exactly twenty pieces.  The < 16 bytes a right-edge tile still needs behind the last whole piece are
+        // fetched as bytes (a piece there could reach past the caller's last image row).
+        const int need = sx_max - sx_min + 1, nfull = min((need + 15) >> 4, (S.w - sx_min) >> 4), tail = max(need - 16 * nfull, 0);
         const uint8_t *s0 = src + (long long)sy_min * spitch + sx_min;
-        if (lane < nfull)
-            for (int r = 0; r < nrows; r++)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(s0 + (long long)r * spitch + 4 * lane),
-                                                 reinterpret_cast<uint32_t *>(src_t + r * RS_PITCH), 4, 0, 0);
-        if (lane + 64 < nfull)
-            for (int r = 0; r < nrows; r++)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(s0 + (long long)r * spitch + 4 * (lane + 64)),
-                                                 reinterpret_cast<uint32_t *>(src_t + r * RS_PITCH + 256), 4, 0, 0);
+        const int lr = lane / 20, lc = lane - lr * 20;
+        if (lr < 3 && lc < nfull)
+            for (int r = 0; r < nrows; r += 3)
+                if (r + lr < nrows)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(s0 + (long long)(r + lr) * spitch + 16 * lc),
+                                                     reinterpret_cast<uint32_t *>(src_t + r * RS_PITCH), 16, 0, 0);
         if (tail)
             for (int i = lane; i < nrows * tail; i += RS_NT) {
-                const int r = i / tail, c = 4 * nfull + (i - r * tail);
+                const int r = i / tail, c = 16 * nfull + (i - r * tail);
                 src_t[r * RS_PITCH + c] = s0[(long long)r * spitch + c];
             }
     }
@@ -103,9 +102,11 @@ __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, in
     uint8_t *dcol = dst + x4;
     // the weights are non-negative and each pair sums to 2048 (+-1 by rounding), so v stays inside [0, 255]:
     // ((2049 * (255 * 2049 >> 4)) >> 16) + 2 >> 2 == 255 -- cv::resize's saturate_cast never fires for INTER_LINEAR
+    // (b * h) >> 16 as the high half of (b << 16) * h: one multiply, no shift (b <= 2049, h < 2^15: the product stays below 2^42)
 #define EMIT(Y, B0, B1, HA) do { \
+        const unsigned w0_ = (unsigned)(B0) << 16, w1_ = (unsigned)(B1) << 16; \
         uint32_t out_ = 0; \
-        _Pragma("unroll") for (int i = 0; i < RS_PX; i++) out_ |= (uint32_t)(((((B0) * (HA)[i]) >> 16) + (((B1) * hc[i]) >> 16) + 2) >> 2) << (8 * i); \
+        _Pragma("unroll") for (int i = 0; i < RS_PX; i++) out_ |= ((__umulhi(w0_, (unsigned)(HA)[i]) + __umulhi(w1_, (unsigned)hc[i]) + 2u) >> 2) << (8 * i); \
         if (x4 < d_w) *reinterpret_cast<uint32_t *>(dcol + (long long)(Y) * d_pitch) = out_; } while (0)
 #pragma unroll
     for (int k = 0; k < RS_ROWS; k++) {         // fully unrolled: every LDS offset below is an immediate
@@ -118,14 +119,14 @@ __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, in
             const int e = __builtin_amdgcn_readfirstlane((int)qs[k].x);
             if (e >= 0) {
                 const int y = e & 0xFFF;
-                if (y >= y_t && y <= y_last) {  // (the row above the tile can end on the tile's first source row)
+                if ((y >> 4) == (int)blockIdx.y) {  // RS_TH = 16 rows per tile (the row above the tile can end on the tile's first source row)
                     const int b0 = __builtin_amdgcn_readfirstlane((int)qs[k].y), b1 = __builtin_amdgcn_readfirstlane((int)qs[k].z);
                     if (e & 0x2000) EMIT(y, b0, b1, hc);                // bottom clamp: both source rows are this one
                     else EMIT(y, b0, b1, hp);
                 }
                 // two output rows end on the clamped last source row when consecutive levels have equal heights: the second one
                 // is y + 1 with both rows = this one and the clamp weights (2048, 0)
-                if ((e & 0x4000) && y + 1 >= y_t && y + 1 <= y_last) EMIT(y + 1, 2048, 0, hc);
+                if ((e & 0x4000) && ((y + 1) >> 4) == (int)blockIdx.y) EMIT(y + 1, 2048, 0, hc);
             }
         }
     }
@@ -755,16 +756,16 @@ __global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const i
 // One wave per keypoint.  The 43x43 unblurred patch is staged in LDS with BORDER_REFLECT_101 at
 // the image edge (the reference blurs a clone of the level, src/ORBextractor.cc:1312-1314), the
 // intensity centroid is taken on it (IC_Angle, :83-111), the 7x7 sigma=2 fixed-point Gaussian is
-// applied to the patch only (never materialising the blurred level), and the 256 steered pairs are
-// compared with one ballot per 64 pairs (computeOrbDescriptor, :116-157).
+// applied to the patch only (never materialising the blurred level; its row pass on the whole patch, its
+// column pass only at the 512 steered sample positions), and the 256 pairs are compared with one ballot
+// per 64 pairs (computeOrbDescriptor, :116-157).
 __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef pr, const int *__restrict__ lvl_cnt,
                                              const uint32_t *__restrict__ lvl_kp, orbx_keypoint *__restrict__ out_kps,
                                              uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap, int nimg)
 {
-    constexpr int RP = 48, HR = 44, BP = 40; // LDS pitches: raw bytes, row-pass u16 (stored column-major, 44 rows per column), blurred bytes
+    constexpr int RP = 48, HR = 44; // LDS pitches: raw bytes, row-pass u16 (stored column-major, 44 rows per column)
     __shared__ __align__(16) uint8_t raw[43 * RP + 16];
     __shared__ __align__(16) uint16_t hb[40 * HR];
-    uint8_t *bl = raw; // the blurred patch overwrites the raw one (dead after the row pass): 5.5 KB per wave, 29 waves/CU
     // Workgroups are dealt round-robin over the 8 XCDs (linear id % 8, speed only): XCD x walks the images x, x + 8, x + 16, ...
     // one after the other, so the patches its waves fetch at any time come from one or two images (1.4 MB of pyramid each)
     // instead of from every image in flight on the chip: the per-XCD L2 (4 MB) then holds them
@@ -883,36 +884,28 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     }
     __syncthreads();
     DSTAMP(2);
-    // ---- column pass: lane = column; its 44 row-pass values arrive as 22 packed pairs (a[2m], a[2m+1]); the pairs at odd
-    // offsets are one v_alignbit each; an output is four v_dot2_u32_u16 against the packed symmetric taps
-    // (g0,g1)(g2,g3)(g2,g1)(g0,0) with the rounding constant as the first accumulator.  Row 43 is padding: it only
-    // ever meets the zero tap.
-    if (lane < 37) {
-        typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
-        unsigned E[22], O[21];
-        const uint32_t *col = reinterpret_cast<const uint32_t *>(hb + lane * HR);
-#pragma unroll
-        for (int m = 0; m < 22; m++) E[m] = col[m];
-#pragma unroll
-        for (int m = 0; m < 21; m++) O[m] = __builtin_amdgcn_alignbit(E[m + 1], E[m], 16);
-        const unsigned g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];
-        const u16x2v G01 = __builtin_bit_cast(u16x2v, g0 | (g1 << 16)), G23 = __builtin_bit_cast(u16x2v, g2 | (g3 << 16)),
-                     G21 = __builtin_bit_cast(u16x2v, g2 | (g1 << 16)), G0 = __builtin_bit_cast(u16x2v, g0);
-#pragma unroll
-        for (int r = 0; r < 37; r++) {
-            const int m = r >> 1;
-            const unsigned p0 = (r & 1) ? O[m] : E[m], p1 = (r & 1) ? O[m + 1] : E[m + 1], p2 = (r & 1) ? O[m + 2] : E[m + 2],
-                           p3 = (r & 1) ? O[m + 3] : E[m + 3];
-            unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p0), G01, 1u << 15, false); // sums stay below 2^25
-            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p1), G23, acc, false);
-            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p2), G21, acc, false);
-            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, p3), G0, acc, false);
-            const unsigned v = acc >> 16;
-            bl[r * BP + lane] = (uint8_t)(v > 255u ? 255u : v);
-        }
-    }
-    __syncthreads();
-    DSTAMP(3);
+    // ---- column pass ONLY at the 512 sampled positions (8 per lane) instead of on all 37 x 37: the seven row-pass values of
+    // a sample are contiguous in its column (column-major hb), fetched as four aligned dwords and realigned by the row parity
+    // with one v_alignbit each (shift in a register); an output is four v_dot2_u32_u16 against the packed symmetric taps
+    // (g0,g1)(g2,g3)(g2,g1)(g0,0) with the rounding constant as the first accumulator.  Row 43 is padding: it only ever
+    // meets the zero tap.  ~14 instructions per sample, 112 per lane, against 211 for the full column pass on 37 lanes.
+    typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
+    const unsigned g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];
+    const u16x2v G01 = __builtin_bit_cast(u16x2v, g0 | (g1 << 16)), G23 = __builtin_bit_cast(u16x2v, g2 | (g3 << 16)),
+                 G21 = __builtin_bit_cast(u16x2v, g2 | (g1 << 16)), G0 = __builtin_bit_cast(u16x2v, g0);
+    const uint32_t *hb32 = reinterpret_cast<const uint32_t *>(hb);
+    auto blurred = [&](int row, int col) -> unsigned {   // blurred patch (row, col), 0..36 each
+        const unsigned i16 = (unsigned)(col * HR + row);
+        const uint32_t *d = hb32 + (i16 >> 1);
+        const unsigned sh = (i16 & 1u) << 4;
+        const unsigned D0 = d[0], D1 = d[1], D2 = d[2], D3 = d[3];
+        unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, __builtin_amdgcn_alignbit(D1, D0, sh)), G01, 1u << 15, false); // sums stay below 2^25
+        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, __builtin_amdgcn_alignbit(D2, D1, sh)), G23, acc, false);
+        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, __builtin_amdgcn_alignbit(D3, D2, sh)), G21, acc, false);
+        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, D3 >> sh), G0, acc, false);
+        const unsigned v = acc >> 16;
+        return v > 255u ? 255u : v;
+    };
     const float a = cs, bb = sn;
     unsigned long long words[4];
 #pragma unroll
@@ -927,7 +920,7 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
         const f32x2 R0 = f32x2{ x0, x0 } * BA + f32x2{ y0, y0 } * AnB, R1 = f32x2{ x1, x1 } * BA + f32x2{ y1, y1 } * AnB;
         const int r0 = dev_cv_round(R0.x), q0 = dev_cv_round(R0.y);
         const int r1 = dev_cv_round(R1.x), q1 = dev_cv_round(R1.y);
-        const int t0 = bl[(18 + r0) * BP + 18 + q0], t1 = bl[(18 + r1) * BP + 18 + q1];
+        const unsigned t0 = blurred(18 + r0, 18 + q0), t1 = blurred(18 + r1, 18 + q1);
         words[jj] = __ballot(t0 < t1);
     }
     if (lane == 0) {
