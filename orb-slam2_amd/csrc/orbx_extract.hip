@@ -864,20 +864,23 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     const float factor_pi = (float)(3.14159265358979323846 / 180.f);
     float sn, cs;
     dev_sincos(angle * factor_pi, &sn, &cs);
-    // ---- row pass: 4 outputs per item from 4 aligned dwords, v_dot4_u32_u8 against the packed taps
-    const unsigned T0 = (unsigned)c_gauss[0] | ((unsigned)c_gauss[1] << 8) | ((unsigned)c_gauss[2] << 16) | ((unsigned)c_gauss[3] << 24);
-    const unsigned T1 = (unsigned)c_gauss[4] | ((unsigned)c_gauss[5] << 8) | ((unsigned)c_gauss[6] << 16);
+    // ---- row pass: 4 outputs per item from 3 aligned dwords.  Output k needs bytes k .. k + 6: instead of shifting the data
+    // (v_alignbyte) the TAPS are shifted -- ten constant tap words, v_dot4_u32_u8 against each dword an output touches
+    const unsigned g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];   // symmetric: g4 = g2, g5 = g1, g6 = g0
+    const unsigned TA0 = g0 | g1 << 8 | g2 << 16 | g3 << 24, TB0 = g2 | g1 << 8 | g0 << 16;
+    const unsigned TA1 = g0 << 8 | g1 << 16 | g2 << 24, TB1 = g3 | g2 << 8 | g1 << 16 | g0 << 24;
+    const unsigned TA2 = g0 << 16 | g1 << 24, TB2 = g2 | g3 << 8 | g2 << 16 | g1 << 24, TC2 = g0;
+    const unsigned TA3 = g0 << 24, TB3 = g1 | g2 << 8 | g3 << 16 | g2 << 24, TC3 = g1 | g0 << 8;
 #pragma unroll
     for (int i = lane; i < 43 * 10; i += 64) {
         const int r = i / 10, gq = i - r * 10;
         const uint32_t *d = reinterpret_cast<const uint32_t *>(raw + r * RP) + gq;
         const unsigned W0 = d[0], W1 = d[1], W2 = d[2]; // the 10 bytes an item needs (4 outputs + 6 taps) start dword-aligned
         unsigned o[4];
-        o[0] = __builtin_amdgcn_udot4(W0, T0, __builtin_amdgcn_udot4(W1, T1, 0u, false), false);
-#pragma unroll
-        for (int k = 1; k < 4; k++)
-            o[k] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, k), T0,
-                                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, k), T1, 0u, false), false);
+        o[0] = __builtin_amdgcn_udot4(W0, TA0, __builtin_amdgcn_udot4(W1, TB0, 0u, false), false);
+        o[1] = __builtin_amdgcn_udot4(W0, TA1, __builtin_amdgcn_udot4(W1, TB1, 0u, false), false);
+        o[2] = __builtin_amdgcn_udot4(W0, TA2, __builtin_amdgcn_udot4(W1, TB2, __builtin_amdgcn_udot4(W2, TC2, 0u, false), false), false);
+        o[3] = __builtin_amdgcn_udot4(W0, TA3, __builtin_amdgcn_udot4(W1, TB3, __builtin_amdgcn_udot4(W2, TC3, 0u, false), false), false);
         // column-major: the column pass then reads vertically adjacent values as packed pairs
 #pragma unroll
         for (int k = 0; k < 4; k++) hb[(4 * gq + k) * HR + r] = (uint16_t)o[k];
@@ -890,7 +893,6 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     // (g0,g1)(g2,g3)(g2,g1)(g0,0) with the rounding constant as the first accumulator.  Row 43 is padding: it only ever
     // meets the zero tap.  ~14 instructions per sample, 112 per lane, against 211 for the full column pass on 37 lanes.
     typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
-    const unsigned g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];
     const u16x2v G01 = __builtin_bit_cast(u16x2v, g0 | (g1 << 16)), G23 = __builtin_bit_cast(u16x2v, g2 | (g3 << 16)),
                  G21 = __builtin_bit_cast(u16x2v, g2 | (g1 << 16)), G0 = __builtin_bit_cast(u16x2v, g0);
     const uint32_t *hb32 = reinterpret_cast<const uint32_t *>(hb);
