@@ -818,14 +818,15 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
         // nine direct loads (global_load_lds_dword: any byte alignment, no VGPR round trip, no ds_write), all in flight together.
         // Lane = (row lane/12, dword lane%12) of a 5-row band (60 lanes), band k covers rows 5k..5k+4 and lands at raw + 240 k + 4 lane:
         // row-major with the 48-byte pitch.
+        // scalar band base + one 32-bit lane offset: the bands advance on the scalar unit (a 64-bit vector multiply-add per load otherwise)
         const int lr = lane / 12, lc = lane - lr * 12;
-        const uint8_t *lsrc = src + (long long)lr * pitch + 4 * lc;
+        const unsigned voff = (unsigned)(lr * pitch + 4 * lc);
         if (lane < 60) {
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(lsrc + (long long)(5 * k) * pitch), reinterpret_cast<uint32_t *>(raw + 240 * k), 4, 0, 0);
+            for (int k = 0; k < 8; k++, src += 5 * (long long)pitch)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(src + voff), reinterpret_cast<uint32_t *>(raw + 240 * k), 4, 0, 0);
             if (lr < 3)   // rows 40..42
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(lsrc + (long long)40 * pitch), reinterpret_cast<uint32_t *>(raw + 240 * 8), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(src + voff), reinterpret_cast<uint32_t *>(raw + 240 * 8), 4, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else { // image edge (BORDER_REFLECT_101 of the cloned level, :1312-1314)
@@ -889,22 +890,25 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     DSTAMP(2);
     // ---- column pass ONLY at the 512 sampled positions (8 per lane) instead of on all 37 x 37: the seven row-pass values of
     // a sample are contiguous in its column (column-major hb), fetched as four aligned dwords and realigned by the row parity
-    // with one v_alignbit each (shift in a register); an output is four v_dot2_u32_u16 against the packed symmetric taps
-    // (g0,g1)(g2,g3)(g2,g1)(g0,0) with the rounding constant as the first accumulator.  Row 43 is padding: it only ever
-    // meets the zero tap.  ~14 instructions per sample, 112 per lane, against 211 for the full column pass on 37 lanes.
+    // with one v_alignbit each (shift in a register; one misaligned ds_read_b128 instead returns the right bytes on gfx950 but ran
+    // the kernel 36 % slower); an output is four v_dot2_u32_u16 against the packed symmetric taps (g0,g1)(g2,g3)(g2,g1)(g0,0)
+    // with the rounding constant as the first accumulator.  Row 43 is padding: it only ever meets the zero tap.
     typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
     const u16x2v G01 = __builtin_bit_cast(u16x2v, g0 | (g1 << 16)), G23 = __builtin_bit_cast(u16x2v, g2 | (g3 << 16)),
                  G21 = __builtin_bit_cast(u16x2v, g2 | (g1 << 16)), G0 = __builtin_bit_cast(u16x2v, g0);
-    const uint32_t *hb32 = reinterpret_cast<const uint32_t *>(hb);
-    auto blurred = [&](int row, int col) -> unsigned {   // blurred patch (row, col), 0..36 each
-        const unsigned i16 = (unsigned)(col * HR + row);
-        const uint32_t *d = hb32 + (i16 >> 1);
-        const unsigned sh = (i16 & 1u) << 4;
+    // Rounding: cvRound(v) = round-half-even = the low bits of v + 1.5 * 2^23 (|v| < 2^22; one packed add for both coordinates,
+    // no v_rndne / v_cvt).  With rb = bits(row + M), qb = bits(col + M): 44 * (low 24 bits of qb) + rb is the u16 index of
+    // (18 + col, 18 + row) in hb plus a constant.
+    const float MAGIC = 12582912.f;   // 0x4B400000
+    auto blurred = [&](unsigned rb, unsigned qb) -> unsigned {
+        const unsigned i16 = __umul24(qb, (unsigned)HR) + rb - (0x400000u * HR + 0x4B400000u) + 18u * (HR + 1);
+        const unsigned ba = i16 << 1, sh = ba << 3;   // v_alignbit / v_lshrrev use the low 5 bits of the shift: 16 * (row parity)
+        const uint32_t *d = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(hb) + (ba & ~3u));
         const unsigned D0 = d[0], D1 = d[1], D2 = d[2], D3 = d[3];
         unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, __builtin_amdgcn_alignbit(D1, D0, sh)), G01, 1u << 15, false); // sums stay below 2^25
         acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, __builtin_amdgcn_alignbit(D2, D1, sh)), G23, acc, false);
         acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, __builtin_amdgcn_alignbit(D3, D2, sh)), G21, acc, false);
-        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, D3 >> sh), G0, acc, false);
+        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2v, D3 >> (sh & 31u)), G0, acc, false);
         const unsigned v = acc >> 16;
         return v > 255u ? 255u : v;
     };
@@ -918,11 +922,9 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
         // (x*b + y*a, x*a - y*b) as two packed fp32 multiplies and one packed add (v_pk_mul_f32 / v_pk_add_f32 round each
         // component like the scalar forms; y*(-b) == -(y*b) exactly, so the subtraction is unchanged)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x2 BA = { bb, a }, AnB = { a, -bb };
-        const f32x2 R0 = f32x2{ x0, x0 } * BA + f32x2{ y0, y0 } * AnB, R1 = f32x2{ x1, x1 } * BA + f32x2{ y1, y1 } * AnB;
-        const int r0 = dev_cv_round(R0.x), q0 = dev_cv_round(R0.y);
-        const int r1 = dev_cv_round(R1.x), q1 = dev_cv_round(R1.y);
-        const unsigned t0 = blurred(18 + r0, 18 + q0), t1 = blurred(18 + r1, 18 + q1);
+        const f32x2 BA = { bb, a }, AnB = { a, -bb }, MM = { MAGIC, MAGIC };
+        const f32x2 R0 = (f32x2{ x0, x0 } * BA + f32x2{ y0, y0 } * AnB) + MM, R1 = (f32x2{ x1, x1 } * BA + f32x2{ y1, y1 } * AnB) + MM;
+        const unsigned t0 = blurred(__float_as_uint(R0.x), __float_as_uint(R0.y)), t1 = blurred(__float_as_uint(R1.x), __float_as_uint(R1.y));
         words[jj] = __ballot(t0 < t1);
     }
     if (lane == 0) {
