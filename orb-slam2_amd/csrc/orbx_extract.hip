@@ -872,19 +872,26 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     const unsigned TA1 = g0 << 8 | g1 << 16 | g2 << 24, TB1 = g3 | g2 << 8 | g1 << 16 | g0 << 24;
     const unsigned TA2 = g0 << 16 | g1 << 24, TB2 = g2 | g3 << 8 | g2 << 16 | g1 << 24, TC2 = g0;
     const unsigned TA3 = g0 << 24, TB3 = g1 | g2 << 8 | g3 << 16 | g2 << 24, TC3 = g1 | g0 << 8;
+    // lane = (row r_lo = lane / 10 of a band of six rows, group gq = lane % 10), eight bands: every LDS address of the pass is
+    // the lane's base plus an immediate (no per-item index arithmetic); the last band holds row 42 only
+    if (lane < 60) {
+        const int r_lo = lane / 10, gq = lane - r_lo * 10;
+        const uint32_t *d0 = reinterpret_cast<const uint32_t *>(raw + r_lo * RP) + gq;
+        uint16_t *w0 = hb + (4 * gq) * HR + r_lo;   // column-major: the column pass reads vertically adjacent values as packed pairs
 #pragma unroll
-    for (int i = lane; i < 43 * 10; i += 64) {
-        const int r = i / 10, gq = i - r * 10;
-        const uint32_t *d = reinterpret_cast<const uint32_t *>(raw + r * RP) + gq;
-        const unsigned W0 = d[0], W1 = d[1], W2 = d[2]; // the 10 bytes an item needs (4 outputs + 6 taps) start dword-aligned
-        unsigned o[4];
-        o[0] = __builtin_amdgcn_udot4(W0, TA0, __builtin_amdgcn_udot4(W1, TB0, 0u, false), false);
-        o[1] = __builtin_amdgcn_udot4(W0, TA1, __builtin_amdgcn_udot4(W1, TB1, 0u, false), false);
-        o[2] = __builtin_amdgcn_udot4(W0, TA2, __builtin_amdgcn_udot4(W1, TB2, __builtin_amdgcn_udot4(W2, TC2, 0u, false), false), false);
-        o[3] = __builtin_amdgcn_udot4(W0, TA3, __builtin_amdgcn_udot4(W1, TB3, __builtin_amdgcn_udot4(W2, TC3, 0u, false), false), false);
-        // column-major: the column pass then reads vertically adjacent values as packed pairs
+        for (int it = 0; it < 8; it++) {
+            if (it < 7 || r_lo == 0) {
+                const uint32_t *d = d0 + it * 6 * (RP / 4);
+                const unsigned W0 = d[0], W1 = d[1], W2 = d[2]; // the 10 bytes an item needs (4 outputs + 6 taps) start dword-aligned
+                unsigned o[4];
+                o[0] = __builtin_amdgcn_udot4(W0, TA0, __builtin_amdgcn_udot4(W1, TB0, 0u, false), false);
+                o[1] = __builtin_amdgcn_udot4(W0, TA1, __builtin_amdgcn_udot4(W1, TB1, 0u, false), false);
+                o[2] = __builtin_amdgcn_udot4(W0, TA2, __builtin_amdgcn_udot4(W1, TB2, __builtin_amdgcn_udot4(W2, TC2, 0u, false), false), false);
+                o[3] = __builtin_amdgcn_udot4(W0, TA3, __builtin_amdgcn_udot4(W1, TB3, __builtin_amdgcn_udot4(W2, TC3, 0u, false), false), false);
 #pragma unroll
-        for (int k = 0; k < 4; k++) hb[(4 * gq + k) * HR + r] = (uint16_t)o[k];
+                for (int k = 0; k < 4; k++) w0[k * HR + 6 * it] = (uint16_t)o[k];
+            }
+        }
     }
     __syncthreads();
     DSTAMP(2);
