@@ -135,16 +135,13 @@ __device__ __forceinline__ float dev_fast_atan2(float y, float x)
     const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
     const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
     const float eps = (float)2.2204460492503131e-16;
-    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
-    if (ax >= ay) {
-        c = ay / (ax + eps);
-        c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = ax / (ay + eps);
-        c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
+    // one division and one polynomial for both octant cases: min / (max + eps) is the quotient either branch of the
+    // reference forms (ax >= ay: ay / (ax + eps), else ax / (ay + eps)); same operations on the same values
+    const float ax = fabsf(x), ay = fabsf(y);
+    const bool steep = !(ax >= ay);
+    const float c = (steep ? ax : ay) / ((steep ? ay : ax) + eps), c2 = c * c;
+    const float pl = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    float a = steep ? 90.f - pl : pl;
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
     return a;
