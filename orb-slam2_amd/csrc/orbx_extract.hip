@@ -763,9 +763,12 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
                                              const uint32_t *__restrict__ lvl_kp, orbx_keypoint *__restrict__ out_kps,
                                              uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap, int nimg)
 {
-    constexpr int RP = 48, HR = 44; // LDS pitches: raw bytes, row-pass u16 (stored column-major, 44 rows per column)
+    // LDS pitches: raw bytes (11 dwords per row), row-pass u16 (column-major, 43 rows per column, 37 columns).  1908 + 3188 bytes
+    // round to 5120 = 160 KB / 32: the CU holds its maximum of 32 waves (the kernel is latency bound: with 5600 bytes, 29 waves
+    // per CU, it ran 3 % slower; every KB more costs 7 %)
+    constexpr int RP = 44, HR = 43;
     __shared__ __align__(16) uint8_t raw[43 * RP + 16];
-    __shared__ __align__(16) uint16_t hb[40 * HR];
+    __shared__ __align__(4) uint16_t hb[37 * HR + 3];   // + the zero-tap row "43" of the last column, read as part of a dword
     // Workgroups are dealt round-robin over the 8 XCDs (linear id % 8, speed only): XCD x walks the images x, x + 8, x + 16, ...
     // one after the other, so the patches its waves fetch at any time come from one or two images (1.4 MB of pyramid each)
     // instead of from every image in flight on the chip: the per-XCD L2 (4 MB) then holds them
@@ -813,20 +816,20 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     // so the realignment shifts below are immediates and the row pass reads three dwords per item instead of four)
     constexpr int xo = 0;
     const int x0a = x - 21;
-    if (x >= 21 && x + 21 < L.w && y >= 21 && y + 21 < L.h && x0a + 48 <= pitch) {
+    if (x >= 21 && x + 21 < L.w && y >= 21 && y + 21 < L.h && x0a + RP <= pitch) {
         const uint8_t *src = img + (long long)(y - 21) * pitch + x0a;
         // nine direct loads (global_load_lds_dword: any byte alignment, no VGPR round trip, no ds_write), all in flight together.
-        // Lane = (row lane/12, dword lane%12) of a 5-row band (60 lanes), band k covers rows 5k..5k+4 and lands at raw + 240 k + 4 lane:
-        // row-major with the 48-byte pitch.
+        // Lane = (row lane/11, dword lane%11) of a 5-row band (55 lanes), band k covers rows 5k..5k+4 and lands at raw + 220 k + 4 lane:
+        // row-major with the 44-byte pitch.
         // scalar band base + one 32-bit lane offset: the bands advance on the scalar unit (a 64-bit vector multiply-add per load otherwise)
-        const int lr = lane / 12, lc = lane - lr * 12;
+        const int lr = lane / 11, lc = lane - lr * 11;
         const unsigned voff = (unsigned)(lr * pitch + 4 * lc);
-        if (lane < 60) {
+        if (lane < 55) {
 #pragma unroll
             for (int k = 0; k < 8; k++, src += 5 * (long long)pitch)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(src + voff), reinterpret_cast<uint32_t *>(raw + 240 * k), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(src + voff), reinterpret_cast<uint32_t *>(raw + 5 * RP * k), 4, 0, 0);
             if (lr < 3)   // rows 40..42
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(src + voff), reinterpret_cast<uint32_t *>(raw + 240 * 8), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(src + voff), reinterpret_cast<uint32_t *>(raw + 5 * RP * 8), 4, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else { // image edge (BORDER_REFLECT_101 of the cloned level, :1312-1314)
@@ -888,8 +891,11 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
                 o[1] = __builtin_amdgcn_udot4(W0, TA1, __builtin_amdgcn_udot4(W1, TB1, 0u, false), false);
                 o[2] = __builtin_amdgcn_udot4(W0, TA2, __builtin_amdgcn_udot4(W1, TB2, __builtin_amdgcn_udot4(W2, TC2, 0u, false), false), false);
                 o[3] = __builtin_amdgcn_udot4(W0, TA3, __builtin_amdgcn_udot4(W1, TB3, __builtin_amdgcn_udot4(W2, TC3, 0u, false), false), false);
+                w0[6 * it] = (uint16_t)o[0];
+                if (gq < 9) {   // the tenth group only owns column 36
 #pragma unroll
-                for (int k = 0; k < 4; k++) w0[k * HR + 6 * it] = (uint16_t)o[k];
+                    for (int k = 1; k < 4; k++) w0[k * HR + 6 * it] = (uint16_t)o[k];
+                }
             }
         }
     }
