@@ -541,7 +541,7 @@ __global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const i
     __shared__ int s_w[NT / 64];
     __shared__ int s_acc;
 
-    int *out_cnt = lvl_cnt + (long long)b * g->nlevels + l;
+    int *out_cnt = lvl_cnt + (long long)b * ORBX_MAX_LEVELS + l;
     // ---- gather this level's candidates (cell-row-major, in-cell row-major)
     const int *ccnt = cell_cnt + (long long)b * g->total_cells + L.cell_base;
     for (int c = tid; c < L.n_cells; c += NT) cellpref[c] = ccnt[c];
@@ -759,7 +759,18 @@ __global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const i
 // applied to the patch only (never materialising the blurred level; its row pass on the whole patch, its
 // column pass only at the 512 steered sample positions), and the 256 pairs are compared with one ballot
 // per 64 pairs (computeOrbDescriptor, :116-157).
-__global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef pr, const int *__restrict__ lvl_cnt,
+// Launch constants of k_desc by value (kernel-argument segment, scalar loads that depend on nothing): the level of a slot is
+// found by comparing against kp_off[] in registers, and only then one dependent fetch (the level's record) remains before the
+// patch address is known.  Fetching them through the Geom pointer was a chain of dependent scalar loads at the start of every
+// wave, during which the wave already holds its LDS.
+struct DescLevel { int w, h, pitch, kp_off; long long pyr_off; float scale; int patch_size; };
+struct DescArgs {
+    int nlevels, kp_total;
+    int kp_off[ORBX_MAX_LEVELS];      // first staging slot of level i; INT_MAX for i >= nlevels
+    DescLevel lv[ORBX_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(64) void k_desc(const DescArgs da, PyrRef pr, const int *__restrict__ lvl_cnt,
                                              const uint32_t *__restrict__ lvl_kp, orbx_keypoint *__restrict__ out_kps,
                                              uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap, int nimg)
 {
@@ -773,25 +784,22 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     // one after the other, so the patches its waves fetch at any time come from one or two images (1.4 MB of pyramid each)
     // instead of from every image in flight on the chip: the per-XCD L2 (4 MB) then holds them
     const int lane = threadIdx.x;
-    int slot, b;
-    {
-        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
-        const unsigned per = (unsigned)g->kp_total, grp = seq / per;
-        slot = (int)(seq - grp * per);
-        b = (int)(grp * 8u + xcd);
-        if (b >= nimg) return;
-    }
+    // grid = (8 * kp_total, ceil(images / 8)): blockIdx.x = 8 * slot + XCD, blockIdx.y = group of eight images; the linear
+    // workgroup id (dispatch order) then has the XCD in its low three bits and the slot running fastest within an XCD
+    const int slot = (int)(blockIdx.x >> 3), b = (int)(blockIdx.y * 8u + (blockIdx.x & 7u));
+    if (b >= nimg) return;
     int l = 0;
-    while (l + 1 < g->nlevels && slot >= g->lv[l + 1].kp_off) l++;
-    const LevelGeom &L = g->lv[l];
-    const int *lc = lvl_cnt + (long long)b * g->nlevels;
+#pragma unroll
+    for (int i = 1; i < ORBX_MAX_LEVELS; i++) l += slot >= da.kp_off[i];
+    const DescLevel L = da.lv[l];
+    const int *lc = lvl_cnt + (long long)b * ORBX_MAX_LEVELS;   // rows of ORBX_MAX_LEVELS counts, zero beyond nlevels
     // the slot's packed keypoint is fetched together with the level counts (its address does not depend on them):
     // one global round trip less on the critical path of every wave; slots past the level's count hold stale data
     // that is never used
 #ifdef ORBX_DIAG
     unsigned long long _t_prev = __builtin_amdgcn_s_memtime();
 #endif
-    const uint32_t p = lvl_kp[(long long)b * g->kp_total + slot];
+    const uint32_t p = lvl_kp[(long long)b * da.kp_total + slot];
     // the lane's four pattern words (lane-indexed constant data = vector loads) are requested here, with the first
     // memory round trip, not in the sampling phase where they would cost a round trip of their own
     uint32_t pat4[4];
@@ -799,15 +807,16 @@ __global__ __launch_bounds__(64) void k_desc(const Geom *__restrict__ g, PyrRef 
     for (int jj = 0; jj < 4; jj++) pat4[jj] = c_pat4[lane + 64 * jj];
     const uint4 omask = c_omask[lane];
     int off = 0, total = 0;
-    for (int i = 0; i < g->nlevels; i++) { const int c = lc[i]; if (i < l) off += c; total += c; }
+#pragma unroll
+    for (int i = 0; i < ORBX_MAX_LEVELS; i++) { const int c = lc[i]; off += i < l ? c : 0; total += c; }
     if (slot == 0 && lane == 0) out_n[b] = total < cap ? total : cap;
     const int j = slot - L.kp_off;
     if (j >= lc[l]) return;
     const int idx = off + j;
     if (idx >= cap) return;
     const int x = p & 0xFFF, y = (p >> 12) & 0xFFF, resp = p >> 24;
-    int pitch;
-    const uint8_t *img = orbx_level_ptr(pr, L, l, b, &pitch);
+    const int pitch = l == 0 ? pr.img0_pitch : L.pitch;
+    const uint8_t *img = l == 0 ? pr.img0 + (long long)b * pr.img0_stride : pr.pyr + (long long)b * pr.pyr_stride + L.pyr_off;
 #ifdef ORBX_DIAG
     asm volatile("" :: "v"(x), "s"(pitch));
     DSTAMP(5); // prologue: level search, level counts, packed keypoint
@@ -1261,12 +1270,12 @@ extern "C" int orbx_extractor_create(orbx_extractor **out, int nfeatures, float 
     if (he != hipSuccess) { orbx_set_error("hipStreamCreate failed: %s", hipGetErrorString(he)); delete e; return ORBX_E_HIP; }
     int rc = upload_constants(e);
     if (rc == ORBX_OK && hipMalloc((void **)&e->d_geom, sizeof(Geom)) != hipSuccess) { orbx_set_error("hipMalloc failed"); rc = ORBX_E_HIP; }
-    if (rc == ORBX_OK && hipMalloc((void **)&e->d_lvl_cnt, sizeof(int) * (size_t)max_batch * nlevels + 16) != hipSuccess) { orbx_set_error("hipMalloc failed"); rc = ORBX_E_HIP; }
+    if (rc == ORBX_OK && hipMalloc((void **)&e->d_lvl_cnt, sizeof(int) * (size_t)max_batch * ORBX_MAX_LEVELS + 16) != hipSuccess) { orbx_set_error("hipMalloc failed"); rc = ORBX_E_HIP; }
     if (rc == ORBX_OK && hipHostMalloc((void **)&e->h_flag, 64, hipHostMallocDefault) != hipSuccess) { orbx_set_error("hipHostMalloc failed"); rc = ORBX_E_HIP; }
     if (rc != ORBX_OK) { orbx_extractor_destroy(e); return rc; }
     *e->h_flag = 0;
     // last int of d_lvl_cnt is the kernel error flag
-    hipMemset(e->d_lvl_cnt, 0, sizeof(int) * (size_t)max_batch * nlevels + 16);
+    hipMemset(e->d_lvl_cnt, 0, sizeof(int) * (size_t)max_batch * ORBX_MAX_LEVELS + 16);
     *out = e;
     return ORBX_OK;
 }
@@ -1383,7 +1392,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
                                e->d_cand, e->d_cand_prim);
     }
     orbx_prof_end(e, s);
-    int *err_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;
+    int *err_flag = e->d_lvl_cnt + (size_t)e->max_batch * ORBX_MAX_LEVELS;
     orbx_prof_begin(e, ORBX_STAGE_TREE, s);
     if (batch * G.nlevels >= 256)
         hipLaunchKernelGGL(k_tree<256>, dim3(batch, G.nlevels), dim3(256), tree_lds_bytes(G, lds_pts_cap(G)), s, e->d_geom,
@@ -1395,7 +1404,18 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
                            tree_tab_in_lds(G) ? nullptr : e->d_tree_tab, (long long)align_up(tree_tab_bytes(G), 256), e->d_cand_prim);
     orbx_prof_end(e, s);
     orbx_prof_begin(e, ORBX_STAGE_DESC, s);
-    hipLaunchKernelGGL(k_desc, dim3(G.kp_total, (batch + 7) / 8 * 8), dim3(64), 0, s, e->d_geom, pr, e->d_lvl_cnt, e->d_lvl_kp,
+    DescArgs da;
+    memset(&da, 0, sizeof da);
+    da.nlevels = G.nlevels; da.kp_total = G.kp_total;
+    for (int i = 0; i < ORBX_MAX_LEVELS; i++) {
+        da.kp_off[i] = i < G.nlevels ? G.lv[i].kp_off : INT_MAX;
+        if (i < G.nlevels) {
+            const LevelGeom &L = G.lv[i];
+            da.lv[i].w = L.w; da.lv[i].h = L.h; da.lv[i].pitch = L.pitch; da.lv[i].kp_off = L.kp_off; da.lv[i].pyr_off = L.pyr_off;
+            da.lv[i].scale = L.scale; da.lv[i].patch_size = L.patch_size;
+        }
+    }
+    hipLaunchKernelGGL(k_desc, dim3(8 * G.kp_total, (batch + 7) / 8), dim3(64), 0, s, da, pr, e->d_lvl_cnt, e->d_lvl_kp,
                        (orbx_keypoint *)d_kps, (uint8_t *)d_desc, (int *)d_n_out, cap, batch);
     orbx_prof_end(e, s);
     ORBX_HIP(hipGetLastError());
@@ -1408,7 +1428,7 @@ extern "C" int orbx_sync(orbx_extractor *e, void *stream)
     ORBX_HIP(hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     // the kernel error flag rides the same stream into pinned memory: one synchronisation, no blocking pageable copy
-    int *d_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;
+    int *d_flag = e->d_lvl_cnt + (size_t)e->max_batch * ORBX_MAX_LEVELS;
     ORBX_HIP(hipMemcpyAsync(e->h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
     ORBX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), s)); // the error belongs to the work synchronised here, not to later frames
     ORBX_HIP(hipStreamSynchronize(s));
@@ -1766,7 +1786,7 @@ static int pipe_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t
         if (rc) return rc;
     }
     // the kernel error flag of this frame travels with its counts; cleared for the next frame on the same (in-order) stream
-    int *d_flag = e->d_lvl_cnt + (size_t)e->max_batch * e->nlevels;
+    int *d_flag = e->d_lvl_cnt + (size_t)e->max_batch * ORBX_MAX_LEVELS;
     ORBX_HIP(hipMemcpyAsync(dn + 2, d_flag, sizeof(int), hipMemcpyDeviceToDevice, e->stream));
     ORBX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), e->stream));
     ORBX_HIP(hipEventRecord(s.ev_done, e->stream));
@@ -1875,7 +1895,7 @@ extern "C" int orbx_debug_level_counts(orbx_extractor *e, int image_index, int32
     if (!e || !counts || image_index < 0 || image_index >= e->last_batch) { orbx_set_error("bad argument"); return ORBX_E_INVALID; }
     ORBX_HIP(hipSetDevice(e->device));
     ORBX_HIP(hipStreamSynchronize(e->stream));
-    ORBX_HIP(hipMemcpy(counts, e->d_lvl_cnt + (size_t)image_index * e->nlevels, sizeof(int) * e->nlevels, hipMemcpyDeviceToHost));
+    ORBX_HIP(hipMemcpy(counts, e->d_lvl_cnt + (size_t)image_index * ORBX_MAX_LEVELS, sizeof(int) * e->nlevels, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
 
