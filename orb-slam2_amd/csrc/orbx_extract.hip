@@ -396,39 +396,69 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
         }
         __syncthreads();
         STAMP(1);
-        // ---- 3. bitmap -> ordered list of (py << 6 | px): lane = row, exclusive prefix of the row populations
-        int nlist;
-        {
-            unsigned lo = 0, hi = 0;
-            if (lane < dh) { const uint2 m = *reinterpret_cast<const uint2 *>(bm + 2 * lane); lo = m.x; hi = m.y; }
-            const int cnt = __popc(lo) + __popc(hi);
-            const int incl = wave_incl_scan(cnt);
-            nlist = __builtin_amdgcn_readlane(incl, 63);
-            uint16_t *lp = list + (incl - cnt);
-            const unsigned base = (unsigned)lane << 6;
-            while (lo) { *lp++ = (uint16_t)(base | (unsigned)__builtin_ctz(lo)); lo &= lo - 1; }
-            while (hi) { *lp++ = (uint16_t)(base | 32u | (unsigned)__builtin_ctz(hi)); hi &= hi - 1; }
-        }
-        __syncthreads();
+        // ---- 3. bitmap -> ordered list of (py << 6 | px): lane = row, exclusive prefix of the row populations.  The list holds
+        // ORBX_FAST_LIST_CAP entries (LDS is what limits the waves per CU, and a textured cell lists ~130 of its ~1000 pixels);
+        // a cell with more candidates takes them in rounds of that many: all scores first, then the maxima
+        unsigned c_lo = 0, c_hi = 0;
+        if (lane < dh) { const uint2 m = *reinterpret_cast<const uint2 *>(bm + 2 * lane); c_lo = m.x; c_hi = m.y; }
+        const int c_cnt = __popc(c_lo) + __popc(c_hi);
+        const int c_incl = wave_incl_scan(c_cnt);
+        const int nlist = __builtin_amdgcn_readlane(c_incl, 63);
+        const unsigned rowbits = (unsigned)lane << 6;
         // ---- 4. full score on the compacted pixels (dense lanes); entries ascend in (py, px)
-        for (int i = lane; i < nlist; i += 64) {
-            const int e = list[i], py = e >> 6, px = e & 63;
-            sc[(py + 1) * SP + px + 1] = (uint8_t)fast_score_full<P>(t0 + py * P + px, th_cur);
-        }
-        __syncthreads();
-        STAMP(2);
+        auto score_entries = [&](int n) {
+            for (int i = lane; i < n; i += 64) {
+                const int e = list[i], py = e >> 6, px = e & 63;
+                sc[(py + 1) * SP + px + 1] = (uint8_t)fast_score_full<P>(t0 + py * P + px, th_cur);
+            }
+        };
         // ---- 5. strict 3x3 maximum on the same list (only listed pixels can score > 0) -> survivor bitmap
-        for (int i0 = 0; i0 < nlist; i0 += 64) {
-            const int i = i0 + lane;
-            const int e = list[min(i, nlist - 1)], py = e >> 6, px = e & 63;
-            const uint8_t *c = sc + (py + 1) * SP + px + 1;
-            const int s = c[0];
-            const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)c[-SP - 1], (int)c[-SP])),
-                               max(max((int)c[-SP + 1], (int)c[SP - 1]), max((int)c[SP], (int)c[SP + 1])));
-            const bool is_max = (i < nlist) & (s > nb);   // s > nb >= 0 implies a corner at th_cur
-            atomicOr(sv + 2 * py + (px >> 5), is_max ? 1u << (px & 31) : 0u);
+        auto mark_maxima = [&](int n) {
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
+                const int e = list[min(i, n - 1)], py = e >> 6, px = e & 63;
+                const uint8_t *c = sc + (py + 1) * SP + px + 1;
+                const int s = c[0];
+                const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)c[-SP - 1], (int)c[-SP])),
+                                   max(max((int)c[-SP + 1], (int)c[SP - 1]), max((int)c[SP], (int)c[SP + 1])));
+                const bool is_max = (i < n) & (s > nb);   // s > nb >= 0 implies a corner at th_cur
+                atomicOr(sv + 2 * py + (px >> 5), is_max ? 1u << (px & 31) : 0u);
+            }
+        };
+        if (nlist <= ORBX_FAST_LIST_CAP) {
+            {
+                unsigned lo = c_lo, hi = c_hi;
+                uint16_t *lp = list + (c_incl - c_cnt);
+                while (lo) { *lp++ = (uint16_t)(rowbits | (unsigned)__builtin_ctz(lo)); lo &= lo - 1; }
+                while (hi) { *lp++ = (uint16_t)(rowbits | 32u | (unsigned)__builtin_ctz(hi)); hi &= hi - 1; }
+            }
+            __syncthreads();
+            score_entries(nlist);
+            __syncthreads();
+            STAMP(2);
+            mark_maxima(nlist);
+            __syncthreads();
+        } else {
+            auto list_round = [&](int base) {   // the candidates of rank base .. base + CAP - 1
+                unsigned lo = c_lo, hi = c_hi;
+                int r = c_incl - c_cnt - base;
+                while (lo) { if ((unsigned)r < (unsigned)ORBX_FAST_LIST_CAP) list[r] = (uint16_t)(rowbits | (unsigned)__builtin_ctz(lo)); r++; lo &= lo - 1; }
+                while (hi) { if ((unsigned)r < (unsigned)ORBX_FAST_LIST_CAP) list[r] = (uint16_t)(rowbits | 32u | (unsigned)__builtin_ctz(hi)); r++; hi &= hi - 1; }
+            };
+            for (int base = 0; base < nlist; base += ORBX_FAST_LIST_CAP) {
+                list_round(base);
+                __syncthreads();
+                score_entries(min(ORBX_FAST_LIST_CAP, nlist - base));
+                __syncthreads();
+            }
+            STAMP(2);
+            for (int base = 0; base < nlist; base += ORBX_FAST_LIST_CAP) {
+                list_round(base);
+                __syncthreads();
+                mark_maxima(min(ORBX_FAST_LIST_CAP, nlist - base));
+                __syncthreads();
+            }
         }
-        __syncthreads();
         STAMP(3);
         {
             unsigned lo = 0, hi = 0;
@@ -1096,9 +1126,11 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         // tile rows: the cell, the whole rows of the last direct load, and the row overrun of the last pretest iteration
         // (up to 7 rows of at least 8 groups) plus its S neighbour three rows further down
         // (row dh - 1 + 8 of the pretest reads its S neighbour at tile row th + 7)
-        G.fast_lds_sc = (int)align_up((size_t)(max_th + 8) * tp + 8, 16);
+        // The overrun rows are only ever READ (their flags land in bitmap rows nobody looks at), so they need no storage of their
+        // own: they alias whatever follows the tile (score tile and list, always more than 8 rows' worth).
+        G.fast_lds_sc = (int)align_up((size_t)max_th * tp + 8, 16);
         G.fast_lds_list = G.fast_lds_sc + (int)align_up((size_t)(max_dh + 2) * sp, 16);
-        G.fast_lds_bm = G.fast_lds_list + (int)align_up((size_t)max_npx * 2 + 16, 16);
+        G.fast_lds_bm = G.fast_lds_list + (int)align_up((size_t)std::min(max_npx, ORBX_FAST_LIST_CAP) * 2 + 16, 16);
         G.fast_bm_rows = (max_dh + 9 + 1) & ~1;          // even: the two bitmaps are zeroed as one run of 16-byte stores
         G.fast_lds_bytes = G.fast_lds_bm + 2 * G.fast_bm_rows * 8;
     }

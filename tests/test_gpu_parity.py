@@ -157,9 +157,11 @@ def test_tables_match_oracle(pkg, oracle):
     assert (ex.GetFeaturesPerLevel() == orc.features_per_level()).all()
 
 
-@pytest.mark.parametrize("kind", ["flat", "low_contrast", "noise", "checker", "dense_corners"])
+@pytest.mark.parametrize("kind", ["flat", "low_contrast", "noise", "checker", "checker1", "dense_corners"])
 def test_extract_edge_images(pkg, oracle, kind):
-    """empty-ish / degenerate inputs: no corners, minThFAST fallback everywhere, saturated corner density"""
+    """empty-ish / degenerate inputs: no corners, minThFAST fallback everywhere, saturated corner density.  "checker1" (every
+    pixel passes k_fast's pretest, none is a corner) and "dense_corners" (binary noise: more than half of a cell's pixels are
+    pretest candidates) overflow k_fast's candidate list (ORBX_FAST_LIST_CAP) and take the multi-round path"""
     w, h = 400, 300
     rng = np.random.default_rng(7)
     if kind == "flat":
@@ -171,6 +173,9 @@ def test_extract_edge_images(pkg, oracle, kind):
     elif kind == "checker":
         yy, xx = np.mgrid[0:h, 0:w]
         img = (((xx // 6 + yy // 6) & 1) * 200 + 20).astype(np.uint8)
+    elif kind == "checker1":
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = (((xx + yy) & 1) * 255).astype(np.uint8)
     else:
         img = rng.integers(0, 2, (h, w), dtype=np.uint8) * 255
     ex = _extractor(pkg, 800, w, h)
