@@ -33,33 +33,54 @@ __constant__ int c_gauss[7];              // 8-bit fixed point 7-tap sigma=2 ker
 // another on the same CU.
 #define RS_PX 4      // output columns per lane
 #define RS_TW (64 * RS_PX)
-#define RS_TH 16
+#ifndef RS_TH_LOG2
+#define RS_TH_LOG2 3
+#endif
+#define RS_TH (1 << RS_TH_LOG2)
 #define RS_NT 64     // threads per workgroup: one wave
 #define RS_PITCH 320 // LDS bytes per staged source row (>= 1.2 * RS_TW + 2 + 3; 80 dwords: the 64 + 16 lanes of two direct loads)
-#define RS_ROWS 22
+#define RS_ROWS (RS_TH == 16 ? 22 : 12)   // source rows of a tile at scale 1.2: ceil(1.2 * RS_TH) + 2
 
-__global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, int l, PyrRef pr,
+// Launch constants by value, and everything a tile needs to start its loads in ONE record per tile row / tile column (host
+// tables): the wave's first dependent fetch is already the last one before the direct loads (it used to walk kernel arguments
+// -> geometry -> coefficient tables -> emit table, holding its LDS all the while).
+struct ResizeArgs {
+    int d_w, d_pitch, s_w, s_pitch, s_level0;
+    int tab_x, tab_tx, tab_ty;          // int16 units into the table buffer
+    long long d_off, s_off;             // byte offsets of the two levels inside one image's pyramid block
+};
+#define RS_TY_REC (4 + 4 * RS_ROWS)     // tile-row record, int16 units: (first source row, source rows, 0, 0), then RS_ROWS x (e, b0, b1, 0)
+
+__global__ __launch_bounds__(RS_NT) void k_resize(const ResizeArgs A, PyrRef pr,
                                                 uint8_t *__restrict__ pyr_w, const int16_t *__restrict__ tabs)
 {
-    __shared__ __align__(16) uint8_t src_t[(RS_ROWS + 2) * RS_PITCH];   // + the rows the last three-row load may cover
-    const LevelGeom &D = g->lv[l];
-    const LevelGeom &S = g->lv[l - 1];
+    __shared__ __align__(16) uint8_t src_t[RS_ROWS * RS_PITCH];
     const int b = blockIdx.z, lane = threadIdx.x;
-    const int x_t = blockIdx.x * RS_TW, y_t = blockIdx.y * RS_TH;
-    int spitch;
-    const uint8_t *src = orbx_level_ptr(pr, S, l - 1, b, &spitch);
-    uint8_t *dst = pyr_w + (long long)b * pr.pyr_stride + D.pyr_off;
-    const int16_t *tx = tabs + D.tab_x, *ty = tabs + D.tab_y;
-    const int x_last = min(x_t + RS_TW, D.w) - 1, y_last = min(y_t + RS_TH, D.h) - 1;
-    const int sx_min = tx[4 * x_t], sx_max = min(tx[4 * x_last] + 1, S.w - 1);
-    const int sy_min = __builtin_amdgcn_readfirstlane((int)ty[4 * y_t]), sy_max = min(__builtin_amdgcn_readfirstlane((int)ty[4 * y_last]) + 1, S.h - 1);
-    const int nrows = sy_max - sy_min + 1;
+    const int x_t = blockIdx.x * RS_TW;
+    const int spitch = A.s_level0 ? pr.img0_pitch : A.s_pitch;
+    const uint8_t *src = A.s_level0 ? pr.img0 + (long long)b * pr.img0_stride : pr.pyr + (long long)b * pr.pyr_stride + A.s_off;
+    uint8_t *dst = pyr_w + (long long)b * pr.pyr_stride + A.d_off;
+    const int16_t *tx = tabs + A.tab_x;
+    const int16_t *ry = tabs + A.tab_ty + (int)blockIdx.y * RS_TY_REC, *rx = tabs + A.tab_tx + 4 * (int)blockIdx.x;
+    const int sy_min = __builtin_amdgcn_readfirstlane((int)ry[0]), nrows = __builtin_amdgcn_readfirstlane((int)ry[1]);
+    const int sx_min = __builtin_amdgcn_readfirstlane((int)rx[0]), nfull = __builtin_amdgcn_readfirstlane((int)rx[1]),
+              tail = __builtin_amdgcn_readfirstlane((int)rx[2]);
+    // Per SOURCE row of the tile (wave-uniform scalars): which output row is complete once this source row has been
+    // interpolated, and its vertical weights: (y | skip << 12 | same << 13 | two << 14, b0, b1, 0), or e = -1 for none;
+    // rows of other tiles are already filtered out by the host
+    short4 qs[RS_ROWS];
+#pragma unroll
+    for (int k = 0; k < RS_ROWS; k++) qs[k] = *reinterpret_cast<const short4 *>(ry + 4 + 4 * k);
+    // the lane's output columns: source offsets and the 11-bit weights (requested before the tile loads: independent of them)
+    const int x4 = x_t + RS_PX * lane;
+    short4 qx[RS_PX];
+#pragma unroll
+    for (int i = 0; i < RS_PX; i++) qx[i] = *reinterpret_cast<const short4 *>(tx + 4 * min(x4 + i, A.d_w - 1)); // (ofs, a0, a1, 0)
     {
         // 16-byte pieces that lie wholly inside the source row are fetched by direct loads (global_load_lds_dwordx4: 1 KB per wave
         // instruction, any byte alignment): lane = (row lane / 20, piece lane % 20) of three whole rows per load -- the LDS pitch
         // of 320 bytes is exactly twenty pieces.  The < 16 bytes a right-edge tile still needs behind the last whole piece are
         // fetched as bytes (a piece there could reach past the caller's last image row).
-        const int need = sx_max - sx_min + 1, nfull = min((need + 15) >> 4, (S.w - sx_min) >> 4), tail = max(need - 16 * nfull, 0);
         const uint8_t *s0 = src + (long long)sy_min * spitch + sx_min;
         const int lr = lane / 20, lc = lane - lr * 20;
         if (lr < 3 && lc < nfull)
@@ -73,29 +94,18 @@ __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, in
                 src_t[r * RS_PITCH + c] = s0[(long long)r * spitch + c];
             }
     }
-    // the lane's output columns: source offsets inside the tile and the 11-bit weights
-    const int x4 = x_t + RS_PX * lane;
     int o0[RS_PX], o1[RS_PX], a0[RS_PX], a1[RS_PX];
 #pragma unroll
     for (int i = 0; i < RS_PX; i++) {
-        const int x = min(x4 + i, D.w - 1);
-        const short4 q = *reinterpret_cast<const short4 *>(tx + 4 * x); // (ofs, a0, a1, 0)
-        const int sx0 = q.x;
+        const int sx0 = qx[i].x;
         o0[i] = sx0 - sx_min;
-        o1[i] = min(sx0 + 1, S.w - 1) - sx_min;
-        a0[i] = q.y;
-        a1[i] = q.z;
+        o1[i] = min(sx0 + 1, A.s_w - 1) - sx_min;
+        a0[i] = qx[i].y;
+        a1[i] = qx[i].z;
     }
-    // Per SOURCE row of the tile (wave-uniform, fetched up front as scalars so that no scalar-memory wait sits between the LDS
-    // reads below): which output row is complete once this source row has been interpolated, and its vertical weights
-    // (host table `tab_s`: (y | same << 13 | two << 14, b0, b1, 0) or y = -1; the buffer is padded for the overread).
-    const int16_t *ts = tabs + D.tab_s + 4 * sy_min;
-    short4 qs[RS_ROWS];
-#pragma unroll
-    for (int k = 0; k < RS_ROWS; k++) qs[k] = *reinterpret_cast<const short4 *>(ts + 4 * k);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the direct loads have landed in LDS
     __syncthreads();
-    const int d_w = D.w, d_pitch = D.pitch;     // scalars: not reloaded behind the stores
+    const int d_w = A.d_w, d_pitch = A.d_pitch;
     int hp[RS_PX], hc[RS_PX];                   // (t >> 4) of source rows k - 1 and k
 #pragma unroll
     for (int i = 0; i < RS_PX; i++) hp[i] = hc[i] = 0;
@@ -119,14 +129,14 @@ __global__ __launch_bounds__(RS_NT) void k_resize(const Geom *__restrict__ g, in
             const int e = __builtin_amdgcn_readfirstlane((int)qs[k].x);
             if (e >= 0) {
                 const int y = e & 0xFFF;
-                if ((y >> 4) == (int)blockIdx.y) {  // RS_TH = 16 rows per tile (the row above the tile can end on the tile's first source row)
+                if (!(e & 0x1000)) {
                     const int b0 = __builtin_amdgcn_readfirstlane((int)qs[k].y), b1 = __builtin_amdgcn_readfirstlane((int)qs[k].z);
                     if (e & 0x2000) EMIT(y, b0, b1, hc);                // bottom clamp: both source rows are this one
                     else EMIT(y, b0, b1, hp);
                 }
                 // two output rows end on the clamped last source row when consecutive levels have equal heights: the second one
                 // is y + 1 with both rows = this one and the clamp weights (2048, 0)
-                if ((e & 0x4000) && ((y + 1) >> 4) == (int)blockIdx.y) EMIT(y + 1, 2048, 0, hc);
+                if (e & 0x4000) EMIT(y + 1, 2048, 0, hc);
             }
         }
     }
@@ -1104,7 +1114,9 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
             G.pyr_bytes += (long long)L.pitch * L.h;
             L.tab_x = (int)tab_units; tab_units += 4 * (size_t)L.w;   // int16 units, multiples of 4: 8-byte aligned quads
             L.tab_y = (int)tab_units; tab_units += 4 * (size_t)L.h;
-            L.tab_s = (int)tab_units; tab_units += 4 * (size_t)G.lv[l - 1].h;   // per SOURCE row: the output row it completes
+            // k_resize's per-tile records: one per tile row (first source row, count, emit entries), one per tile column
+            L.tab_ty = (int)tab_units; tab_units += (size_t)RS_TY_REC * ((L.h + RS_TH - 1) / RS_TH);
+            L.tab_tx = (int)tab_units; tab_units += 4 * (size_t)((L.w + RS_TW - 1) / RS_TW);
         }
         if (L.n_cells > G.max_cells_level) G.max_cells_level = L.n_cells;
         if (L.node_cap > G.max_node_cap) G.max_node_cap = L.node_cap;
@@ -1135,17 +1147,20 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         G.fast_lds_bytes = G.fast_lds_bm + 2 * G.fast_bm_rows * 8;
     }
     // resize tables
-    std::vector<int16_t> tabs(tab_units + 4 * RS_ROWS);   // + one tile's source rows: k_resize prefetches RS_ROWS entries per tile
+    std::vector<int16_t> tabs(tab_units);
     std::vector<char> emit_ok(e->nlevels, 1);
+    std::vector<std::vector<int16_t>> emit(e->nlevels);
     for (int l = 1; l < e->nlevels; l++) {
         LevelGeom &L = G.lv[l];
         const LevelGeom &S = G.lv[l - 1];
         linear_tables(S.w, L.w, &tabs[L.tab_x]);
         linear_tables(S.h, L.h, &tabs[L.tab_y]);
-        // emit table of k_resize: source row sy -> the output row y whose LOWER source row min(sy0 + 1, S.h - 1) is sy
-        int16_t *ts = &tabs[L.tab_s];
+        // emit table of k_resize: source row sy -> the output row y whose LOWER source row min(sy0 + 1, S.h - 1) is sy:
+        // (y | same << 13 | two << 14, b0, b1, 0), y = -1 for none
+        emit[l].assign(4 * (size_t)S.h, 0);
+        int16_t *ts = emit[l].data();
         const int16_t *ty = &tabs[L.tab_y];
-        for (int sy = 0; sy < S.h; sy++) { ts[4 * sy] = -1; ts[4 * sy + 1] = ts[4 * sy + 2] = ts[4 * sy + 3] = 0; }
+        for (int sy = 0; sy < S.h; sy++) ts[4 * sy] = -1;
         for (int y = 0; y < L.h; y++) {
             const int sy0 = ty[4 * y], rb = sy0 + 1 < S.h - 1 ? sy0 + 1 : S.h - 1, same = sy0 == rb;
             if (ts[4 * rb] < 0) {
@@ -1171,6 +1186,31 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
             if (smax - ty[4 * y0] + 1 > RS_ROWS) ok = false;
         }
         L.resize_lds = (S.w == 2 * L.w && S.h == 2 * L.h) ? 2 : (ok && emit_ok[l] && L.h < 4096) ? 1 : 0;   // 2: area-average kernel path (k_resize_direct)
+        if (L.resize_lds != 1) continue;
+        // per-tile records (see k_resize): everything a tile needs before its loads, in one fetch
+        for (int by = 0, y0 = 0; y0 < L.h; by++, y0 += RS_TH) {
+            int16_t *r = &tabs[L.tab_ty + (size_t)by * RS_TY_REC];
+            const int yl = (y0 + RS_TH < L.h ? y0 + RS_TH : L.h) - 1;
+            const int sy_min = ty[4 * y0], sy_max = ty[4 * yl] + 1 < S.h - 1 ? ty[4 * yl] + 1 : S.h - 1, nrows = sy_max - sy_min + 1;
+            r[0] = (int16_t)sy_min; r[1] = (int16_t)nrows; r[2] = r[3] = 0;
+            for (int k = 0; k < RS_ROWS; k++) {
+                int16_t *q = r + 4 + 4 * k;
+                q[0] = -1; q[1] = q[2] = q[3] = 0;
+                if (k >= nrows) continue;
+                const int16_t *t = &emit[l][4 * (size_t)(sy_min + k)];
+                if (t[0] < 0) continue;
+                const int y = t[0] & 0xFFF, in1 = y >= y0 && y <= yl, in2 = (t[0] & 0x4000) && y + 1 >= y0 && y + 1 <= yl;
+                if (!in1 && !in2) continue;
+                q[0] = (int16_t)(y | (t[0] & 0x2000) | (in1 ? 0 : 0x1000) | (in2 ? 0x4000 : 0)); q[1] = t[1]; q[2] = t[2];
+            }
+        }
+        for (int bx = 0, x0 = 0; x0 < L.w; bx++, x0 += RS_TW) {
+            int16_t *r = &tabs[L.tab_tx + 4 * (size_t)bx];
+            const int xl = (x0 + RS_TW < L.w ? x0 + RS_TW : L.w) - 1;
+            const int sx_min = tx[4 * x0], sx_max = tx[4 * xl] + 1 < S.w - 1 ? tx[4 * xl] + 1 : S.w - 1, need = sx_max - sx_min + 1;
+            const int nfull = std::min((need + 15) >> 4, (S.w - sx_min) >> 4), tail = std::max(need - 16 * nfull, 0);
+            r[0] = (int16_t)sx_min; r[1] = (int16_t)nfull; r[2] = (int16_t)tail; r[3] = 0;
+        }
     }
     std::vector<CellRec> cells(G.total_cells);
     for (int l = 0; l < e->nlevels; l++) {
@@ -1404,8 +1444,14 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
         const LevelGeom &L = G.lv[l];
         orbx_prof_begin(e, ORBX_STAGE_RESIZE, s);
         if (L.resize_lds == 1)
+        {
+            const LevelGeom &S = G.lv[l - 1];
+            ResizeArgs ra;
+            ra.d_w = L.w; ra.d_pitch = L.pitch; ra.s_w = S.w; ra.s_pitch = S.pitch; ra.s_level0 = l == 1;
+            ra.tab_x = L.tab_x; ra.tab_tx = L.tab_tx; ra.tab_ty = L.tab_ty; ra.d_off = L.pyr_off; ra.s_off = S.pyr_off;
             hipLaunchKernelGGL(k_resize, dim3((L.w + RS_TW - 1) / RS_TW, (L.h + RS_TH - 1) / RS_TH, batch), dim3(RS_NT), 0, s,
-                               e->d_geom, l, pr, e->d_pyr, e->d_tabs);
+                               ra, pr, e->d_pyr, e->d_tabs);
+        }
         else
             hipLaunchKernelGGL(k_resize_direct, dim3((L.pitch / 4 + 63) / 64, (L.h + 3) / 4, batch), dim3(256), 0, s,
                                e->d_geom, l, pr, e->d_pyr, e->d_tabs);

@@ -32,7 +32,7 @@ struct LevelGeom {
     float scale;            // mvScaleFactor[level]
     int patch_size;         // (int)(31*scale)
     int tab_x, tab_y;       // offsets (int16 units) of the resize tables [ofs|c0|c1] x 3*w / 3*h
-    int tab_s;              // offset of k_resize's per-source-row emit table [y|flags, b0, b1, 0] x (previous level's h)
+    int tab_tx, tab_ty;     // offsets of k_resize's per-tile-column / per-tile-row records
     int resize_lds;         // 1: k_resize's LDS tile fits this level's scale, 0: k_resize_direct, 2: exact 2x -> area average (k_resize_direct)
 };
 
