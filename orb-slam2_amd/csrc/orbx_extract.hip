@@ -377,6 +377,12 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
     const int bm_sh = 4 * (gq & 7);
     uint32_t *slot = cand + (long long)b * fa.cand_total + rec.cand_slot;
     uint32_t *prim = cand_prim + ((long long)b * fa.total_cells + cell) * ORBX_CAND_PRIM;   // the first 16 candidates: dense, 64 B per cell
+    // Bitmap rows are walked with one lane per SEGMENT: a whole row (64 bits, low word then high word), or -- when the detect
+    // area is at most 32 x 32, most cells of a 30-px grid -- half a 32-bit row word: the bit loops below run as long as the
+    // fullest segment, and half rows are half as full
+    const bool half_mode = dh <= 32 && dw <= 32;
+    const int brow = half_mode ? lane >> 1 : lane;
+    const unsigned bsh = half_mode ? 16u * (lane & 1) : 0u;
     int th_cur = ini_th, nsurv = 0;
     for (int pass = 0; pass < 2; pass++) {
         // ---- 2. SWAR pretest.  With s = t + 1 and x7 = x >> 1 per byte: x < c - t  ==>  x7 <= c7 - s7 (dark) and
@@ -406,15 +412,15 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
         }
         __syncthreads();
         STAMP(1);
-        // ---- 3. bitmap -> ordered list of (py << 6 | px): lane = row, exclusive prefix of the row populations.  The list holds
+        // ---- 3. bitmap -> ordered list of (py << 6 | px): lane = segment, exclusive prefix of the segment populations.  The list holds
         // ORBX_FAST_LIST_CAP entries (LDS is what limits the waves per CU, and a textured cell lists ~130 of its ~1000 pixels);
         // a cell with more candidates takes them in rounds of that many: all scores first, then the maxima
         unsigned c_lo = 0, c_hi = 0;
-        if (lane < dh) { const uint2 m = *reinterpret_cast<const uint2 *>(bm + 2 * lane); c_lo = m.x; c_hi = m.y; }
+        if (brow < dh) { const uint2 m = *reinterpret_cast<const uint2 *>(bm + 2 * brow); c_lo = half_mode ? (m.x >> bsh) & 0xFFFFu : m.x; c_hi = half_mode ? 0u : m.y; }
         const int c_cnt = __popc(c_lo) + __popc(c_hi);
         const int c_incl = wave_incl_scan(c_cnt);
         const int nlist = __builtin_amdgcn_readlane(c_incl, 63);
-        const unsigned rowbits = (unsigned)lane << 6;
+        const unsigned rowbits = ((unsigned)brow << 6) | bsh;
         // ---- 4. full score on the compacted pixels (dense lanes); entries ascend in (py, px)
         auto score_entries = [&](int n) {
             for (int i = lane; i < n; i += 64) {
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
         STAMP(3);
         {
             unsigned lo = 0, hi = 0;
-            if (lane < dh) { const uint2 m = *reinterpret_cast<const uint2 *>(sv + 2 * lane); lo = m.x; hi = m.y; }
+            if (brow < dh) { const uint2 m = *reinterpret_cast<const uint2 *>(sv + 2 * brow); lo = half_mode ? (m.x >> bsh) & 0xFFFFu : m.x; hi = half_mode ? 0u : m.y; }
             nsurv = __popc(lo) + __popc(hi);
         }
         // the cell falls back to minThFAST only if iniThFAST kept nothing (:991-995); pretest, scores and bitmaps of the
@@ -480,15 +486,15 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
         if (__builtin_amdgcn_readfirstlane(__any(nsurv != 0)) || th_cur == min_th) break;
         th_cur = min_th;
     }
-    // ---- ordered (row-major) emission into the cell's candidate slots: lane = row
+    // ---- ordered (row-major) emission into the cell's candidate slots: lane = bitmap segment (row, or half a row)
     {
         unsigned lo = 0, hi = 0;
-        if (lane < dh) { const uint2 m = *reinterpret_cast<const uint2 *>(sv + 2 * lane); lo = m.x; hi = m.y; }
+        if (brow < dh) { const uint2 m = *reinterpret_cast<const uint2 *>(sv + 2 * brow); lo = half_mode ? (m.x >> bsh) & 0xFFFFu : m.x; hi = half_mode ? 0u : m.y; }
         const int incl = wave_incl_scan(nsurv);
         const int total = __builtin_amdgcn_readlane(incl, 63);
         int o = incl - nsurv;
-        const int Y = ini_y + 3 + lane - ORBX_MIN_BORDER, X0 = ini_x + 3 - ORBX_MIN_BORDER;
-        const uint8_t *srow = sc + (lane + 1) * SP + 1;
+        const int Y = ini_y + 3 + brow - ORBX_MIN_BORDER, X0 = ini_x + 3 - ORBX_MIN_BORDER + (int)bsh;
+        const uint8_t *srow = sc + (brow + 1) * SP + 1 + bsh;
         while (lo) {
             const int px = __builtin_ctz(lo);
             lo &= lo - 1;
