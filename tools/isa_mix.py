@@ -55,8 +55,8 @@ def kernel_bodies(asm):
 
 
 def pretty(mangled):
-    m = re.match(r"_Z\d+(k_[a-z_0-9]+?)(?:I|P|v|$)", mangled)
-    base = m.group(1) if m else mangled
+    m = re.match(r"_Z(\d+)", mangled)     # Itanium mangling: the name's length precedes it
+    base = mangled[m.end():m.end() + int(m.group(1))] if m else mangled
     t = re.search(r"ILi(\d+)ELi(\d+)EE", mangled)
     return base + (f"<{t.group(1)},{t.group(2)}>" if t else "")
 

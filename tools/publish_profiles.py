@@ -28,7 +28,7 @@ for name, out in (("bench_default.json", f"{tag}_z_bench_default.json"), ("bench
         json.dump(last_json_line(p), open(os.path.join(dst, out), "w"), indent=1)
 stats = glob.glob(os.path.join(src, "prof", "*", "*kernel_stats.csv"))
 if stats:
-    shutil.copy(stats[0], os.path.join(dst, f"{tag}_z_kernel_stats.csv"))
+    shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, f"{tag}_z_kernel_stats.csv"))   # the newest run
 tr = os.path.join(ROOT, "gpurun_out", f"{tag}_traffic.json")
 if os.path.exists(tr):
     shutil.copy(tr, os.path.join(dst, f"{tag}_traffic.json"))
