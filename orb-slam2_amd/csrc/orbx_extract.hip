@@ -550,14 +550,17 @@ extern __shared__ __align__(16) unsigned char tree_smem[];
 
 // NT threads per workgroup: 256 for batches (many (level, image) workgroups co-resident per CU), 1024 when a launch has
 // fewer workgroups than the chip has CUs (a single frame: the longest workgroup's latency chain IS the kernel time)
-template <int NT>
-__global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const int *__restrict__ cell_cnt,
+// TAB_LDS: node tables in LDS (every ORB-SLAM2 configuration) -- a compile-time fact, so that their accesses are ds_ instructions
+// and LDS atomics; behind a pointer chosen at run time they were FLAT instructions (300 per wave through the vector-memory path).
+template <int NT, bool TAB_LDS>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tree(const Geom *__restrict__ g, const int *__restrict__ cell_cnt,
                                               const uint32_t *__restrict__ cand, uint32_t *__restrict__ g_pts,
                                               uint16_t *__restrict__ g_nid, int *__restrict__ lvl_cnt,
                                               uint32_t *__restrict__ lvl_kp, int lds_pts_cap, int *__restrict__ err_flag,
-                                              unsigned char *__restrict__ g_tab, long long g_tab_stride, const uint32_t *__restrict__ cand_prim)
+                                              unsigned char *__restrict__ g_tab, long long g_tab_stride, const uint32_t *__restrict__ cand_prim, int reg_pts)
 {
     constexpr int NB = ORBX_NODE_BITS, NMASK = (1 << NB) - 1;
+    constexpr int RP = ORBX_TREE_REG_PTS / NT;   // points per thread in the register form
     // x = image, y = level: workgroups are dealt to the 8 XCDs by linear id % 8, so every XCD gets the same mix of
     // levels (x = level would put all level-0 trees, the longest barrier chains, on one XCD), heaviest level first
     const int l = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
@@ -568,7 +571,8 @@ __global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const i
     // id: __syncthreads orders the workgroup's own global stores and loads, the same code runs on either memory)
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     const size_t tab_bytes = (size_t)cap * 76;
-    unsigned char *tab = g_tab ? g_tab + (size_t)wg * (size_t)g_tab_stride : tree_smem;
+    unsigned char *tab;
+    if constexpr (TAB_LDS) tab = tree_smem; else tab = g_tab + (size_t)wg * (size_t)g_tab_stride;
     int *cnt = reinterpret_cast<int *>(tab);
     int *cnt_n = cnt + cap;
     uint2 *box = reinterpret_cast<uint2 *>(cnt_n + cap);
@@ -580,8 +584,10 @@ __global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const i
     int *a3 = a2 + cap;                             // unsplit flags -> ranks
     int *a4 = a3 + cap;                             // phase-2 gains
     int *ncarr = a4 + cap;                          // non-empty children per node (0 = not split)
-    int *cellpref = g_tab ? reinterpret_cast<int *>(tree_smem) : ncarr + cap;   // [max_cells_level + 4], always LDS
-    (void)tab_bytes;
+    // [max_cells_level + 4], always LDS; in the register form it sits behind the staging area the gather uses (which aliases the
+    // node tables: they are not live yet)
+    int *cellpref = !TAB_LDS ? reinterpret_cast<int *>(tree_smem)
+                             : reinterpret_cast<int *>(tree_smem + (reg_pts && tab_bytes < (size_t)ORBX_TREE_REG_PTS * 4 ? (size_t)ORBX_TREE_REG_PTS * 4 : tab_bytes));
     uint32_t *lpts = reinterpret_cast<uint32_t *>(cellpref + ((g->max_cells_level + 4) & ~3));
     uint16_t *lnid = reinterpret_cast<uint16_t *>(lpts + lds_pts_cap);
     __shared__ int s_w[NT / 64];
@@ -597,9 +603,20 @@ __global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const i
         if (tid == 0) *out_cnt = 0;
         return;
     }
+    // Points never move (a point keeps the list position of its leaf as a label), and every pass over them is
+    // `for (i = tid; i < n; i += NT)`: with n <= ORBX_TREE_REG_PTS thread tid simply KEEPS its points i = tid + NT * k and their
+    // labels in registers -- no LDS for them at all (they were half of the workgroup's LDS, and LDS is what limits the
+    // (level, image) workgroups per CU: 4 -> 8), and no LDS round trip per point and sweep.  Bigger levels fall back to arrays
+    // (LDS up to lds_pts_cap, else the HBM scratch).
+    const bool in_regs = reg_pts && n <= ORBX_TREE_REG_PTS;
+    uint32_t rp[RP];
+    unsigned rn[RP];
+#pragma unroll
+    for (int k = 0; k < RP; k++) { rp[k] = 0; rn[k] = 0; }
     uint32_t *pts;
     uint16_t *nid;
-    if (n <= lds_pts_cap) { pts = lpts; nid = lnid; }
+    if (in_regs) { pts = reinterpret_cast<uint32_t *>(tree_smem); nid = nullptr; }   // staging for the gather only
+    else if (n <= lds_pts_cap) { pts = lpts; nid = lnid; }
     else {
         pts = g_pts + (long long)b * g->cand_total + L.cand_off;
         nid = g_nid + (long long)b * g->cand_total + L.cand_off;
@@ -613,16 +630,32 @@ __global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const i
             for (int e = 0; e < end - beg; e++) pts[beg + e] = e < ORBX_CAND_PRIM ? pr[e] : s[e];
         }
     }
+    if (in_regs) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RP; k++) { const int i = tid + NT * k; if (i < n) rp[k] = reinterpret_cast<const uint32_t *>(tree_smem)[i]; }
+        __syncthreads();        // the staging area becomes the node tables
+    }
+    // one pass over the points: BODY sees the index i, the packed point p and its label nd (read / write)
+#define FOR_POINTS(...) do { \
+        if (in_regs) { \
+            _Pragma("unroll") for (int k_ = 0; k_ < RP; k_++) { \
+                const int i = tid + NT * k_; \
+                if (i < n) { const uint32_t p = rp[k_]; unsigned nd = rn[k_]; __VA_ARGS__; rn[k_] = nd; } \
+            } \
+        } else { \
+            for (int i = tid; i < n; i += NT) { const uint32_t p = pts[i]; unsigned nd = nid[i]; __VA_ARGS__; nid[i] = (uint16_t)nd; } \
+        } } while (0)
     // ---- roots (src/ORBextractor.cc:627-705)
     const int N = L.quota;
     for (int k = tid; k < L.n_ini; k += NT) cc[k] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += NT) {
-        int r = (int)((float)(pts[i] & 0xFFF) / L.hx);
+    FOR_POINTS({
+        int r = (int)((float)(p & 0xFFF) / L.hx);
         r = r < 0 ? 0 : r >= L.n_ini ? L.n_ini - 1 : r;
         atomicAdd(&cc[r], 1);
-        nid[i] = (uint16_t)r;
-    }
+        nd = (unsigned)r;
+    });
     __syncthreads();
     for (int k = tid; k < L.n_ini; k += NT) a1[k] = cc[k] > 0;
     __syncthreads();
@@ -634,7 +667,7 @@ __global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const i
             box[id] = make_uint2(x0 | (x1 << 16), 0u | ((unsigned)L.tree_h << 16));
             cnt[id] = cc[k];
         }
-    for (int i = tid; i < n; i += NT) nid[i] = (uint16_t)a1[nid[i]];
+    FOR_POINTS({ nd = (unsigned)a1[nd]; });
     __syncthreads();
 
     // ---- sweeps.  Invariant at the top of the loop: cc[0..4m) holds the child counts of the current
@@ -653,10 +686,7 @@ __global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const i
     };
     for (int k = tid; k < 4 * m; k += NT) cc[k] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += NT) {
-        const int id = nid[i];
-        nid[i] = (uint16_t)(id | (classify(id, pts[i], cnt, box, cc) << NB));
-    }
+    FOR_POINTS({ const int id = (int)nd; nd = (unsigned)(id | (classify(id, p, cnt, box, cc) << NB)); });
     bool phase2 = false;
     for (;;) {
         const int prev = m;
@@ -764,19 +794,16 @@ __global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const i
         const bool done = m >= N || m == prev;                     // :803-806, :883-884
         if (!phase2 && !done && m + 3 * n_to_expand > N) phase2 = true; // :814
         if (done) {
-            for (int i = tid; i < n; i += NT) {
-                const int v = nid[i];
-                nid[i] = (uint16_t)cc[(v & NMASK) * 4 + (v >> NB)];
-            }
+            FOR_POINTS({ const int v = (int)nd; nd = (unsigned)cc[(v & NMASK) * 4 + (v >> NB)]; });
             __syncthreads();
             break;
         }
         // ---- relabel fused with the next sweep's classification (one pass over the points)
-        for (int i = tid; i < n; i += NT) {
-            const int v = nid[i];
+        FOR_POINTS({
+            const int v = (int)nd;
             const int id = cc[(v & NMASK) * 4 + (v >> NB)];
-            nid[i] = (uint16_t)(id | (classify(id, pts[i], cnt_n, box_n, cc_n) << NB));
-        }
+            nd = (unsigned)(id | (classify(id, p, cnt_n, box_n, cc_n) << NB));
+        });
         { int *t = cnt; cnt = cnt_n; cnt_n = t; }
         { uint2 *t = box; box = box_n; box_n = t; }
         { int *t = cc; cc = cc_n; cc_n = t; }
@@ -786,15 +813,25 @@ __global__ __launch_bounds__(NT) void k_tree(const Geom *__restrict__ g, const i
     unsigned *best = reinterpret_cast<unsigned *>(cc);
     for (int k = tid; k < m; k += NT) best[k] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += NT)
-        atomicMax(&best[nid[i] & NMASK], ((pts[i] >> 24) << 24) | (0xFFFFFFu - (unsigned)i));
+    FOR_POINTS({ atomicMax(&best[nd & NMASK], ((p >> 24) << 24) | (0xFFFFFFu - (unsigned)i)); });
     __syncthreads();
     uint32_t *okp = lvl_kp + (long long)b * g->kp_total + L.kp_off;
-    for (int k = tid; k < m; k += NT) {
-        const uint32_t p = pts[0xFFFFFFu - (best[k] & 0xFFFFFFu)];
-        const unsigned x = (p & 0xFFF) + ORBX_MIN_BORDER, y = ((p >> 12) & 0xFFF) + ORBX_MIN_BORDER;
-        if (k < L.kp_cap) okp[k] = x | (y << 12) | (p & 0xFF000000u);
+    if (in_regs) {      // the winner of a leaf is written by the thread that holds it
+        FOR_POINTS({
+            const int k = (int)(nd & NMASK);
+            if ((best[k] & 0xFFFFFFu) == 0xFFFFFFu - (unsigned)i && k < L.kp_cap) {
+                const unsigned x = (p & 0xFFF) + ORBX_MIN_BORDER, y = ((p >> 12) & 0xFFF) + ORBX_MIN_BORDER;
+                okp[k] = x | (y << 12) | (p & 0xFF000000u);
+            }
+        });
+    } else {
+        for (int k = tid; k < m; k += NT) {
+            const uint32_t p = pts[0xFFFFFFu - (best[k] & 0xFFFFFFu)];
+            const unsigned x = (p & 0xFFF) + ORBX_MIN_BORDER, y = ((p >> 12) & 0xFFF) + ORBX_MIN_BORDER;
+            if (k < L.kp_cap) okp[k] = x | (y << 12) | (p & 0xFF000000u);
+        }
     }
+#undef FOR_POINTS
     if (tid == 0) *out_cnt = min(m, L.kp_cap);
 }
 
@@ -1067,6 +1104,17 @@ static int lds_pts_cap(const Geom &G)
     return c;
 }
 
+// Register form of k_tree (points and labels in VGPRs, see the kernel): for image sizes whose levels normally hold at most
+// ORBX_TREE_REG_PTS candidates (the same P_0/160 rule) and node tables that fit the LDS; bigger levels of such an image go to the
+// HBM scratch.  The workgroup's LDS is then the node tables (which double as the gather's staging area) + the cell prefix array.
+static bool tree_reg_mode(const Geom &G) { return tree_tab_in_lds(G) && lds_pts_cap(G) <= ORBX_TREE_REG_PTS; }
+static int tree_launch_pts_cap(const Geom &G) { return tree_reg_mode(G) ? 0 : lds_pts_cap(G); }
+static size_t tree_launch_lds(const Geom &G)
+{
+    if (!tree_reg_mode(G)) return tree_lds_bytes(G, lds_pts_cap(G));
+    return std::max(tree_tab_bytes(G), (size_t)ORBX_TREE_REG_PTS * 4) + tree_fixed_lds(G);
+}
+
 int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
 {
     if (e->geom.w == w && e->geom.h == h) return ORBX_OK;
@@ -1237,7 +1285,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
             c.cand_slot = L.cand_off + (long long)ci * L.cand_cap;
         }
     }
-    if (tree_lds_bytes(G, lds_pts_cap(G)) > kTreeLdsLimit) {
+    if (tree_launch_lds(G) > kTreeLdsLimit) {
         orbx_set_error("internal: %d FAST cells per level do not fit the quadtree kernel's LDS", G.max_cells_level);
         return ORBX_E_INVALID;
     }
@@ -1270,10 +1318,11 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
     ORBX_HIP(hipMemcpy(e->d_tabs, tabs.data(), tabs.size() * 2, hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(e->d_cells, cells.data(), cells.size() * sizeof(CellRec), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(e->d_geom, &G, sizeof G, hipMemcpyHostToDevice));
-    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)tree_lds_bytes(G, lds_pts_cap(G))));
-    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)tree_lds_bytes(G, lds_pts_cap(G))));
+    {
+        const void *kt[4] = { reinterpret_cast<const void *>(k_tree<256, true>), reinterpret_cast<const void *>(k_tree<256, false>),
+                              reinterpret_cast<const void *>(k_tree<1024, true>), reinterpret_cast<const void *>(k_tree<1024, false>) };
+        for (const void *f : kt) ORBX_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tree_launch_lds(G)));
+    }
     e->geom = G;
     return ORBX_OK;
 }
@@ -1478,14 +1527,17 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
     orbx_prof_end(e, s);
     int *err_flag = e->d_lvl_cnt + (size_t)e->max_batch * ORBX_MAX_LEVELS;
     orbx_prof_begin(e, ORBX_STAGE_TREE, s);
-    if (batch * G.nlevels >= 256)
-        hipLaunchKernelGGL(k_tree<256>, dim3(batch, G.nlevels), dim3(256), tree_lds_bytes(G, lds_pts_cap(G)), s, e->d_geom,
-                           e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, lds_pts_cap(G), err_flag,
-                           tree_tab_in_lds(G) ? nullptr : e->d_tree_tab, (long long)align_up(tree_tab_bytes(G), 256), e->d_cand_prim);
-    else    // fewer workgroups than CUs: 1024 threads each shorten the per-workgroup chain (a single stereo frame: 51 -> ~30 us)
-        hipLaunchKernelGGL(k_tree<1024>, dim3(batch, G.nlevels), dim3(1024), tree_lds_bytes(G, lds_pts_cap(G)), s, e->d_geom,
-                           e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, lds_pts_cap(G), err_flag,
-                           tree_tab_in_lds(G) ? nullptr : e->d_tree_tab, (long long)align_up(tree_tab_bytes(G), 256), e->d_cand_prim);
+    {
+        // 256 threads for batches (many (level, image) workgroups co-resident per CU); fewer workgroups than CUs: 1024 threads
+        // each shorten the per-workgroup chain (a single stereo frame: 51 -> ~30 us)
+        const bool big = batch * G.nlevels < 256, lds = tree_tab_in_lds(G);
+        void (*kern)(const Geom *, const int *, const uint32_t *, uint32_t *, uint16_t *, int *, uint32_t *, int, int *, unsigned char *, long long,
+                     const uint32_t *, int) =
+            big ? (lds ? k_tree<1024, true> : k_tree<1024, false>) : (lds ? k_tree<256, true> : k_tree<256, false>);
+        hipLaunchKernelGGL(kern, dim3(batch, G.nlevels), dim3(big ? 1024 : 256), tree_launch_lds(G), s, e->d_geom,
+                           e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid, e->d_lvl_cnt, e->d_lvl_kp, tree_launch_pts_cap(G), err_flag,
+                           lds ? nullptr : e->d_tree_tab, (long long)align_up(tree_tab_bytes(G), 256), e->d_cand_prim, tree_reg_mode(G) ? 1 : 0);
+    }
     orbx_prof_end(e, s);
     orbx_prof_begin(e, ORBX_STAGE_DESC, s);
     DescArgs da;
