@@ -626,8 +626,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         for (int c = tid; c < L.n_cells; c += NT) {
             const int beg = cellpref[c], end = c + 1 < L.n_cells ? cellpref[c + 1] : n;
             const uint32_t *s = src + (long long)c * L.cand_cap;
-            const uint32_t *pr = cand_prim + ((long long)b * g->total_cells + L.cell_base + c) * ORBX_CAND_PRIM;
-            for (int e = 0; e < end - beg; e++) pts[beg + e] = e < ORBX_CAND_PRIM ? pr[e] : s[e];
+            // the cell's dense 64-byte record as four independent 16-byte loads (an element-wise loop was a chain of dependent
+            // load -> store round trips, as long as the fullest cell); only the rare entries beyond it walk the slot block
+            const uint4 *pr = reinterpret_cast<const uint4 *>(cand_prim + ((long long)b * g->total_cells + L.cell_base + c) * ORBX_CAND_PRIM);
+            const int cn = end - beg;
+            if (cn > 0) {
+                static_assert(ORBX_CAND_PRIM == 16, "four uint4 per record");
+                const uint4 q0 = pr[0], q1 = pr[1], q2 = pr[2], q3 = pr[3];
+                const uint32_t v[16] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
+#pragma unroll
+                for (int e = 0; e < 16; e++) if (e < cn) pts[beg + e] = v[e];
+                for (int e = 16; e < cn; e++) pts[beg + e] = s[e];
+            }
         }
     }
     if (in_regs) {
