@@ -951,9 +951,16 @@ __global__ __launch_bounds__(64) void k_desc(const DescArgs da, PyrRef pr, const
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else { // image edge (BORDER_REFLECT_101 of the cloned level, :1312-1314)
-        for (int e = lane; e < 43 * 43; e += 64) {
-            const int r = e / 43, c = e - r * 43;
-            raw[r * RP + c] = img[(long long)reflect101(y - 21 + r, L.h) * pitch + reflect101(x - 21 + c, L.w)];
+        // lane = patch column (its reflected source column computed once), rows walked on the scalar unit, eight byte loads in
+        // flight: ~2 vector instructions per row (an element-wise walk with a division and two reflections per byte cost more
+        // than the whole rest of the keypoint, for the ~6 % of the keypoints that lie within 21 px of an image edge)
+        const int cx = reflect101(x - 21 + min(lane, 42), L.w);
+        if (lane < 43) {
+#pragma unroll 8
+            for (int r = 0; r < 43; r++) {
+                const int ry = reflect101(y - 21 + r, L.h);
+                raw[r * RP + lane] = img[(long long)ry * pitch + cx];
+            }
         }
     }
     DSTAMP(6); // patch loads issued and consumed (the last LDS stores may still be in flight)
