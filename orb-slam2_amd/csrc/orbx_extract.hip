@@ -569,7 +569,7 @@ extern __shared__ __align__(16) unsigned char tree_smem[];
 // TAB_LDS: node tables in LDS (every ORB-SLAM2 configuration) -- a compile-time fact, so that their accesses are ds_ instructions
 // and LDS atomics; behind a pointer chosen at run time they were FLAT instructions (300 per wave through the vector-memory path).
 template <int NT, bool TAB_LDS>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tree(const Geom *__restrict__ g, const int *__restrict__ cell_cnt,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_tree(const Geom *__restrict__ g, const int *__restrict__ cell_cnt,
                                               const uint32_t *__restrict__ cand, uint32_t *__restrict__ g_pts,
                                               uint16_t *__restrict__ g_nid, int *__restrict__ lvl_cnt,
                                               uint32_t *__restrict__ lvl_kp, int lds_pts_cap, int *__restrict__ err_flag,
