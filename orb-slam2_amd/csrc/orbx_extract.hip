@@ -275,13 +275,16 @@ struct FastArgs {
 #ifdef ORBX_DIAG
 __device__ unsigned long long g_fast_stamp[4096 * 8]; // diagnostic build only: summed phase cycles of k_fast, 4096 slots
 __device__ unsigned long long g_desc_stamp[4096 * 8]; // same for k_desc
+__device__ unsigned long long g_tree_stamp[4096 * 8]; // same for the level-0 workgroups of k_tree (slot 6 = phase-2 sweeps, 7 = workgroups)
 #define STAMP_TO(arr, k) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
     if (threadIdx.x == 0) atomicAdd(&arr[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + (k)], _t - _t_prev); _t_prev = _t; } while (0)
 #define STAMP(k) STAMP_TO(g_fast_stamp, k)
 #define DSTAMP(k) STAMP_TO(g_desc_stamp, k)
+#define TSTAMP(k) do { if (blockIdx.y == 0) STAMP_TO(g_tree_stamp, k); } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #define DSTAMP(k) do { } while (0)
+#define TSTAMP(k) do { } while (0)
 #endif
 
 // P / SP = LDS pitches of the pixel tile and the score tile: (48, 40) when every cell of the pyramid is at most 38 px wide
@@ -542,6 +545,16 @@ extern "C" int orbx_diag_desc_stamps(unsigned long long *out, int reset)
     return ORBX_OK;
 }
 
+extern "C" int orbx_diag_tree_stamps(unsigned long long *out, int reset)
+{
+    ORBX_HIP(hipDeviceSynchronize());
+    static unsigned long long h[4096 * 8];
+    ORBX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tree_stamp), sizeof h));
+    for (int k = 0; k < 8; k++) { out[k] = 0; for (int i = 0; i < 4096; i++) out[k] += h[i * 8 + k]; }
+    if (reset) { memset(h, 0, sizeof h); ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tree_stamp), h, sizeof h)); }
+    return ORBX_OK;
+}
+
 extern "C" int orbx_diag_fast_stamps(unsigned long long *out, int reset)
 {
     ORBX_HIP(hipDeviceSynchronize());
@@ -610,6 +623,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
     __shared__ int s_acc;
 
     int *out_cnt = lvl_cnt + (long long)b * ORBX_MAX_LEVELS + l;
+#ifdef ORBX_DIAG
+    unsigned long long _t_prev = __builtin_amdgcn_s_memtime();
+#endif
     // ---- gather this level's candidates (cell-row-major, in-cell row-major)
     const int *ccnt = cell_cnt + (long long)b * g->total_cells + L.cell_base;
     for (int c = tid; c < L.n_cells; c += NT) cellpref[c] = ccnt[c];
@@ -672,6 +688,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         } else { \
             for (int i = tid; i < n; i += NT) { const uint32_t p = pts[i]; unsigned nd = nid[i]; __VA_ARGS__; nid[i] = (uint16_t)nd; } \
         } } while (0)
+    TSTAMP(0);  // cell counts, prefix, gather
     // ---- roots (src/ORBextractor.cc:627-705)
     const int N = L.quota;
     for (int k = tid; k < L.n_ini; k += NT) cc[k] = 0;
@@ -714,6 +731,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
     __syncthreads();
     FOR_POINTS({ const int id = (int)nd; nd = (unsigned)(id | (classify(id, p, cnt, box, cc) << NB)); });
     bool phase2 = false;
+    TSTAMP(1);  // roots + first classification
     for (;;) {
         const int prev = m;
         __syncthreads();
@@ -783,6 +801,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
             if (tid == 0) { atomicExch(err_flag, 1); *out_cnt = 0; }
             return;
         }
+        TSTAMP(2);  // order / scans of the sweep
+#ifdef ORBX_DIAG
+        if (phase2 && blockIdx.y == 0 && tid == 0) atomicAdd(&g_tree_stamp[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + 6], 1ull);
+#endif
         // ---- apply: build the next table, turn cc into child positions, zero the next table's counters
         int expand_local = 0;
         for (int k = tid; k < m; k += NT) {
@@ -824,6 +846,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
             __syncthreads();
             break;
         }
+        TSTAMP(3);  // apply
         // ---- relabel fused with the next sweep's classification (one pass over the points)
         FOR_POINTS({
             const int v = (int)nd;
@@ -833,6 +856,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         { int *t = cnt; cnt = cnt_n; cnt_n = t; }
         { uint2 *t = box; box = box_n; box_n = t; }
         { int *t = cc; cc = cc_n; cc_n = t; }
+        TSTAMP(4);  // relabel + classify
     }
 
     // ---- one keypoint per leaf: max response, first in list order wins ties (:895-912)
@@ -858,6 +882,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         }
     }
 #undef FOR_POINTS
+    TSTAMP(5);  // final relabel, best per leaf, output
+#ifdef ORBX_DIAG
+    if (blockIdx.y == 0 && tid == 0) atomicAdd(&g_tree_stamp[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + 7], 1ull);
+#endif
     if (tid == 0) *out_cnt = min(m, L.kp_cap);
 }
 

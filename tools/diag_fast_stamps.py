@@ -34,7 +34,17 @@ for _ in range(5): step()
 ex.sync()
 L.orbx_diag_desc_stamps(out,1)
 w=out[7]
-names=["sync after load","orient","rowpass","colpass","sample+store","prologue (levels, counts, kp)","patch load"]
+names=["sync after load","orient","sincos + rowpass","(unused)","sample+store","prologue (levels, counts, kp)","patch load"]
 tot=sum(out[i] for i in range(7))
 print("k_desc waves",w, "avg cycles/wave", tot/w)
 for i in (5,6,0,1,2,3,4): print(f"  {names[i]:30s} {out[i]/w:9.1f} cycles  {100*out[i]/tot:5.1f}%")
+
+L.orbx_diag_tree_stamps(out,1)
+for _ in range(5): step()
+ex.sync()
+L.orbx_diag_tree_stamps(out,1)
+w=out[7]
+names=["counts + prefix + gather","roots + first classification","sweep: order / scans","sweep: apply","sweep: relabel + classify","final relabel, best per leaf, output"]
+tot=sum(out[i] for i in range(6))
+print("k_tree level-0 workgroups",w, "avg cycles (s_memtime, 100 MHz) per workgroup", tot/w, "phase-2 sweeps per workgroup", out[6]/w)
+for i,nm in enumerate(names): print(f"  {nm:40s} {out[i]/w:9.1f}  {100*out[i]/tot:5.1f}%")
