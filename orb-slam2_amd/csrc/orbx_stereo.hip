@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_stereo_prep(const Geom *__restrict__ g,
     }
 }
 
-__global__ __launch_bounds__(256) void k_stereo(const Geom *__restrict__ g, PyrRef prL, PyrRef prR, int img_l0, int img_r0,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_stereo(const Geom *__restrict__ g, PyrRef prL, PyrRef prR, int img_l0, int img_r0,
                                                 const orbx_keypoint *__restrict__ kL, const uint32_t *__restrict__ dL,
                                                 const int *__restrict__ nL, const orbx_keypoint *__restrict__ kR,
                                                 const uint32_t *__restrict__ dR, const int *__restrict__ nR, int cap,
