@@ -380,6 +380,9 @@ enum { ORBX_STAGE_RESIZE = 0, ORBX_STAGE_FAST = 1, ORBX_STAGE_TREE = 2, ORBX_STA
        ORBX_STAGE_STEREO = 4, ORBX_STAGE_STEREO_CUT = 5, ORBX_STAGE_COUNT = 6 };
 /* enable: record HIP events around every kernel launch of this handle (on the launch stream) */
 int orbx_profile_enable(orbx_extractor *e, int enable);
+/* Which stages record events while profiling is enabled: bit ORBX_STAGE_* (default: all).  An event between two kernels costs a
+ * few microseconds of idle GPU (barrier packet), so a throughput measurement selects only the kernel it needs the duration of. */
+int orbx_profile_stages(orbx_extractor *e, unsigned stage_mask);
 /* synchronises, then returns accumulated kernel time (ms) and launch count per stage since the
  * last reset; arrays of ORBX_STAGE_COUNT entries */
 int orbx_profile_read(orbx_extractor *e, float *ms, int *launches, int reset);

@@ -52,6 +52,7 @@ static hipEvent_t prof_new_event(orbx_extractor *e)
 void orbx_prof_begin(orbx_extractor *e, int stage, hipStream_t s)
 {
     if (!e->prof) return;
+    if (!((e->prof_mask >> stage) & 1u)) { e->prof_chain = false; return; }    // stage not selected: its launches break the event chain
     ProfEvent ev;
     ev.stage = stage;
     ev.b = nullptr;
@@ -82,6 +83,14 @@ extern "C" int orbx_profile_enable(orbx_extractor *e, int enable)
 {
     if (!e) { orbx_set_error("null extractor"); return ORBX_E_INVALID; }
     e->prof = enable != 0;
+    e->prof_chain = false;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_profile_stages(orbx_extractor *e, unsigned stage_mask)
+{
+    if (!e) { orbx_set_error("null extractor"); return ORBX_E_INVALID; }
+    e->prof_mask = stage_mask;
     e->prof_chain = false;
     return ORBX_OK;
 }

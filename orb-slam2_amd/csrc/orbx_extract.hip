@@ -1435,6 +1435,7 @@ extern "C" int orbx_extractor_create(orbx_extractor **out, int nfeatures, float 
     }
     ORBX_HIP(hipSetDevice(device));
     orbx_extractor *e = new orbx_extractor();
+    e->prof_mask = ~0u;
     e->device = device; e->nfeatures = nfeatures; e->nlevels = nlevels; e->ini_th = ini_th; e->min_th = min_th;
     e->scale_factor = scale_factor; e->max_w = max_w; e->max_h = max_h; e->max_batch = max_batch;
     // src/ORBextractor.cc:436-461

@@ -117,7 +117,7 @@ struct orbx_extractor {
     // state of the most recent extract
     const uint8_t *last_img0; size_t last_img_stride, last_pitch; int last_batch;
     // profiling
-    bool prof, prof_chain; hipStream_t prof_last_stream; std::vector<ProfEvent> prof_ev; std::vector<hipEvent_t> prof_pool;
+    bool prof, prof_chain; unsigned prof_mask; hipStream_t prof_last_stream; std::vector<ProfEvent> prof_ev; std::vector<hipEvent_t> prof_pool;
     float prof_ms[ORBX_STAGE_COUNT]; int prof_n[ORBX_STAGE_COUNT];
 };
 

@@ -119,6 +119,7 @@ def lib():
                                       vp, vp, i, f, vp, ip]
     L.orbx_distinctive_descriptors.argtypes = [i, vp, vp, i, vp]
     L.orbx_profile_enable.argtypes = [vp, i]
+    L.orbx_profile_stages.argtypes = [vp, C.c_uint]
     L.orbx_profile_read.argtypes = [vp, vp, vp, i]
     L.orbx_debug_candidates.argtypes = [vp, i, i, vp, vp, vp, i, ip]
     L.orbx_debug_level_counts.argtypes = [vp, i, vp]
@@ -377,6 +378,10 @@ class ORBextractor:
 
     def profile_enable(self, on=True):
         _check(self._L.orbx_profile_enable(self._h, int(on)))
+
+    def profile_stages(self, mask=0xFFFFFFFF):
+        """which stages record events while profiling is on (bit = ORBX_STAGE_*; default all)"""
+        _check(self._L.orbx_profile_stages(self._h, int(mask) & 0xFFFFFFFF))
 
     def profile_read(self, reset=True):
         ms = np.zeros(len(STAGES), np.float32); n = np.zeros(len(STAGES), np.int32)
