@@ -309,12 +309,12 @@ def test_stereo_no_matches(pkg, oracle):
 
 # ------------------------------------------------------------------------------- BoW matchers
 
-def _bow_sets(pkg, oracle, seed, n_kf=3, flip=0.05):
+def _bow_sets(pkg, oracle, seed, n_kf=3, flip=0.05, vocab_k=10):
     rng = np.random.Generator(np.random.PCG64(seed))
     img = synth.image(seed, 752, 480)
     ex = _extractor(pkg, 1000, 752, 480)
     k, d = ex(img)
-    voc = synth.Vocab2(seed + 1); voc.seed_from(d, rng)
+    voc = synth.Vocab2(seed + 1, k=vocab_k); voc.seed_from(d, rng)
 
     def mk(desc, kp, flag):
         ids, off, feat = voc.feature_vector(desc)
@@ -329,6 +329,27 @@ def _bow_sets(pkg, oracle, seed, n_kf=3, flip=0.05):
         kk["angle"] = (kk["angle"] + rng.normal(0, 4 + 20 * i, len(kk)).astype(np.float32)) % np.float32(360)
         kfs.append(mk(dk, kk, (rng.random(len(d)) < 0.6).astype(np.uint8)))
     return frame, kfs, ex
+
+
+def test_search_by_bow_many_nodes(pkg, oracle):
+    """a k = 30 vocabulary: several hundred distinct nodes per feature vector, so the table kernel walks several chunks of BOW_CHUNK (256)
+    nodes per pair (ORB-SLAM2's level-4 nodes give <= 100); both kernel forms, both search flavours"""
+    frame, kfs, _ = _bow_sets(pkg, oracle, 83, vocab_k=30)
+    assert len(frame["node_id"]) > 260 and all(len(kf["node_id"]) > 260 for kf in kfs)
+    m = pkg.ORBmatcher(0.75, True)
+    for form in ("wave", "table"):
+        pkg.orbx.debug_set_bow_form(form)
+        try:
+            for i, kf in enumerate(kfs):
+                got, n = m.SearchByBoW(kf, frame)
+                exp, en = oracle.search_by_bow_kf_f(kf, frame, 0.75, True)
+                assert n == en and (got == exp).all(), f"form {form} kf {i}"
+            b = dict(kfs[1]); b["kind"] = "keyframe"
+            got, n = m.SearchByBoW(kfs[0], b)
+            exp, en = oracle.search_by_bow_kf_kf(kfs[0], b, 0.75, True)
+            assert n == en and (got == exp).all(), f"form {form} kf-kf"
+        finally:
+            pkg.orbx.debug_set_bow_form("auto")
 
 
 @pytest.mark.parametrize("ratio,ori", [(0.7, True), (0.75, True), (0.9, False)])
