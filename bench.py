@@ -407,7 +407,7 @@ def main():
     prof_on[0] = True
     ex.profile_stages(0xFFFFFFFF)
     ex.profile_enable(True)
-    n_prof = max(2, min(5, args.steps))
+    n_prof = max(2, min(10, args.steps))
     for _ in range(n_prof):
         step()
     local_sync()

@@ -907,6 +907,8 @@ struct DescArgs {
     DescLevel lv[ORBX_MAX_LEVELS];
 };
 
+// NL = 8 or ORBX_MAX_LEVELS: the level search and the count sums below are unrolled over NL levels (ORB-SLAM2 uses 8)
+template <int NL>
 __global__ __launch_bounds__(64) void k_desc(const DescArgs da, PyrRef pr, const int *__restrict__ lvl_cnt,
                                              const uint32_t *__restrict__ lvl_kp, orbx_keypoint *__restrict__ out_kps,
                                              uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap, int nimg)
@@ -927,7 +929,7 @@ __global__ __launch_bounds__(64) void k_desc(const DescArgs da, PyrRef pr, const
     if (b >= nimg) return;
     int l = 0;
 #pragma unroll
-    for (int i = 1; i < ORBX_MAX_LEVELS; i++) l += slot >= da.kp_off[i];
+    for (int i = 1; i < NL; i++) l += slot >= da.kp_off[i];
     const DescLevel L = da.lv[l];
     const int *lc = lvl_cnt + (long long)b * ORBX_MAX_LEVELS;   // rows of ORBX_MAX_LEVELS counts, zero beyond nlevels
     // the slot's packed keypoint is fetched together with the level counts (its address does not depend on them):
@@ -945,7 +947,7 @@ __global__ __launch_bounds__(64) void k_desc(const DescArgs da, PyrRef pr, const
     const uint4 omask = c_omask[lane];
     int off = 0, total = 0;
 #pragma unroll
-    for (int i = 0; i < ORBX_MAX_LEVELS; i++) { const int c = lc[i]; off += i < l ? c : 0; total += c; }
+    for (int i = 0; i < NL; i++) { const int c = lc[i]; off += i < l ? c : 0; total += c; }
     if (slot == 0 && lane == 0) out_n[b] = total < cap ? total : cap;
     const int j = slot - L.kp_off;
     if (j >= lc[l]) return;
@@ -1613,7 +1615,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
             da.lv[i].scale = L.scale; da.lv[i].patch_size = L.patch_size;
         }
     }
-    hipLaunchKernelGGL(k_desc, dim3(8 * G.kp_total, (batch + 7) / 8), dim3(64), 0, s, da, pr, e->d_lvl_cnt, e->d_lvl_kp,
+    hipLaunchKernelGGL((G.nlevels <= 8 ? k_desc<8> : k_desc<ORBX_MAX_LEVELS>), dim3(8 * G.kp_total, (batch + 7) / 8), dim3(64), 0, s, da, pr, e->d_lvl_cnt, e->d_lvl_kp,
                        (orbx_keypoint *)d_kps, (uint8_t *)d_desc, (int *)d_n_out, cap, batch);
     orbx_prof_end(e, s);
     ORBX_HIP(hipGetLastError());
