@@ -20,17 +20,18 @@ __constant__ int c_gauss[7];              // 8-bit fixed point 7-tap sigma=2 ker
 // ================================================================ K1: pyramid level (E2)
 // cv::resize INTER_LINEAR 8UC1 from level l-1 to level l.  Coefficient tables are
 // computed on the host with the reference's float/double arithmetic; the kernel is pure integer.
-// A one-wave workgroup produces a 256x16 output tile, lane = four adjacent output columns, all 16 rows:
-//  * the source rectangle (<= 311 x 22) goes to LDS with direct loads (global_load_lds_dword, two per source row,
-//    any byte alignment, no VGPR round trip, no address arithmetic per element);
+// A one-wave workgroup produces a 256 x RS_TH (8) output tile, lane = four adjacent output columns, all rows:
+//  * the source rectangle (<= 311 x 12) goes to LDS with direct loads (global_load_lds_dwordx4: three whole source rows per
+//    instruction, any byte alignment, no VGPR round trip, no address arithmetic per element); 3840 bytes of LDS per wave =
+//    the CU's maximum of 32 waves (the kernel is latency bound: 16-row tiles, 21 waves per CU, were 3 % slower);
 //  * the loop runs over SOURCE rows (fully unrolled: every LDS offset is an immediate): the horizontal interpolation
 //    of a source row is computed once and serves the (up to two) output rows it belongs to -- at scale 1.2 that is
 //    1.33 instead of 2 horizontal passes per output row; an output row is emitted as soon as its lower source row
-//    is done.  Which output row that is comes from a host table indexed by source row and depends only on the tile (every
-//    lane has the same rows): scalar control flow -- about 500 scalar instructions per tile whatever its width, which
-//    is why a lane takes four columns (with two the kernel was bound by the scalar unit, not by the vector ALUs).
+//    is done.  Which output row that is comes from the tile row's host record and depends only on the tile (every lane has the
+//    same rows): scalar control flow -- a few hundred scalar instructions per tile whatever its width, which is why a lane
+//    takes four columns (with two the kernel was bound by the scalar unit, not by the vector ALUs).
 // One-wave workgroups need no barrier partners and drift apart in time, so loads of one tile overlap arithmetic of
-// another on the same CU.
+// another on the same CU (a 16-wave workgroup walking all levels of an image with barriers between them was no faster).
 #define RS_PX 4      // output columns per lane
 #define RS_TW (64 * RS_PX)
 #ifndef RS_TH_LOG2
@@ -38,7 +39,7 @@ __constant__ int c_gauss[7];              // 8-bit fixed point 7-tap sigma=2 ker
 #endif
 #define RS_TH (1 << RS_TH_LOG2)
 #define RS_NT 64     // threads per workgroup: one wave
-#define RS_PITCH 320 // LDS bytes per staged source row (>= 1.2 * RS_TW + 2 + 3; 80 dwords: the 64 + 16 lanes of two direct loads)
+#define RS_PITCH 320 // LDS bytes per staged source row (>= 1.2 * RS_TW + 2 + 3): twenty 16-byte pieces, three rows per direct load
 #define RS_ROWS (RS_TH == 16 ? 22 : 12)   // source rows of a tile at scale 1.2: ceil(1.2 * RS_TH) + 2
 
 // Launch constants by value, and everything a tile needs to start its loads in ONE record per tile row / tile column (host
