@@ -607,3 +607,28 @@ def test_extract_pipelined_mono_and_mixed(pkg, oracle):
     assert k.tobytes() == ok.tobytes() and d.tobytes() == od.tobytes()
     k, d = ex.extract_wait(t4); ok, od = orc.extract(small)
     assert k.tobytes() == ok.tobytes() and d.tobytes() == od.tobytes()
+
+
+def test_profile_stage_selection(pkg):
+    """orbx_profile_enable / orbx_profile_stages: events are recorded for the selected stages only, one launch each per call
+    (seven k_resize launches), and the outputs do not depend on profiling"""
+    w, h = 640, 480
+    img = synth.image(5, w, h)
+    ex = _extractor(pkg, 800, w, h)
+    k0, d0 = ex(img)
+    ex.profile_read(reset=True)
+    ex.profile_enable(True)
+    k1, d1 = ex(img)
+    ex.profile_enable(False)
+    prof = ex.profile_read(reset=True)
+    assert k1.tobytes() == k0.tobytes() and (d1 == d0).all()
+    assert prof["resize"][1] == 7 and prof["fast"][1] == 1 and prof["tree"][1] == 1 and prof["desc"][1] == 1
+    assert all(prof[s][0] > 0 for s in ("resize", "fast", "tree", "desc"))
+    ex.profile_stages(1 << pkg.orbx.STAGES.index("fast"))
+    ex.profile_enable(True)
+    ex(img); ex(img)
+    ex.profile_enable(False)
+    prof = ex.profile_read(reset=True)
+    ex.profile_stages()
+    assert prof["fast"][1] == 2 and prof["fast"][0] > 0
+    assert all(prof[s][1] == 0 for s in ("resize", "tree", "desc", "stereo", "stereo_cut"))
