@@ -234,6 +234,44 @@ int orbx_search_for_triangulation(int device, const orbx_featset *k1, const orbx
                                   const float *scale_factors2, const float *level_sigma2_2, int nlevels2,
                                   int only_stereo, int check_orientation, int32_t *pairs, int cap, int *npairs);
 
+/* The loops the reference runs these searches in, as ONE call (one launch, one PCIe round trip):
+ * LoopClosing::ComputeSim3 calls SearchByBoW(mpCurrentKF, pKF, ...) per loop candidate (src/LoopClosing.cc:293-323):
+ * k1 against k2s[0..n2): match12[n2][k1->n], nmatches[n2]. */
+int orbx_search_by_bow_kf_kf_batch(int device, const orbx_featset *k1, const orbx_featset *k2s, int n2,
+                                   float nnratio, int check_orientation, int32_t *match12, int *nmatches);
+/* LocalMapping::CreateNewMapPoints calls SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, ...) per neighbour keyframe
+ * (src/LocalMapping.cc:241-309): k1 against k2s[0..n2), each with its own F12s[i][9] and epipole epipoles[i][2]; one set of
+ * per-level tables (all keyframes of a map share one extractor).  pairs[n2][2*cap], npairs[n2]; ORBX_E_CAPACITY if any
+ * list is longer than cap (the first cap entries of each are written). */
+int orbx_search_for_triangulation_batch(int device, const orbx_featset *k1, const orbx_featset *k2s, int n2,
+                                        const float *F12s, const float *epipoles,
+                                        const float *scale_factors2, const float *level_sigma2_2, int nlevels2,
+                                        int only_stereo, int check_orientation, int32_t *pairs, int cap, int *npairs);
+
+/* ---- resident keyframes --------------------------------------------------------------------------
+ * A keyframe's descriptors (KeyFrame::mDescriptors), FeatureVector (mFeatVec) and keypoint attributes (mvKeysUn, mvuRight)
+ * never change once the keyframe exists (src/KeyFrame.cc:29-60); what changes is which features hold map points.  orbx_kf
+ * keeps the immutable part in HBM in FeatureVector order (made once per keyframe, e.g. from the KeyFrame constructor; a
+ * Frame can be uploaded the same way for the per-frame searches); the searches below then take the map-point flags per
+ * call and move only those, the node intersection and the results over PCIe.  fs->flag is ignored by orbx_kf_create;
+ * x / y / octave / u_right may be NULL for a set that is only used in SearchByBoW.
+ * flag arrays are per FEATURE ([n] of that keyframe), with the meaning of the host-pointer call they mirror. */
+typedef struct orbx_kf orbx_kf;
+int orbx_kf_create(int device, const orbx_featset *fs, orbx_kf **out);
+void orbx_kf_destroy(orbx_kf *k);
+int orbx_kf_size(const orbx_kf *k);
+/* SearchByBoW(pKF, F): kf_flag as orbx_search_by_bow_kf_f's kf->flag; match_f[f's n] */
+int orbx_kf_search_by_bow_kf_f(const orbx_kf *kf, const uint8_t *kf_flag, const orbx_kf *f,
+                               float nnratio, int check_orientation, int32_t *match_f, int *nmatches);
+/* SearchByBoW(pKF1, pKF2) for n2 candidates: match12[n2][k1's n], nmatches[n2] */
+int orbx_kf_search_by_bow_kf_kf(const orbx_kf *k1, const uint8_t *flag1, const orbx_kf *const *k2s, const uint8_t *const *flags2, int n2,
+                                float nnratio, int check_orientation, int32_t *match12, int *nmatches);
+/* SearchForTriangulation for n2 neighbours; flag1 / flags2 (or flags2[i]) may be NULL = no feature has a map point */
+int orbx_kf_search_for_triangulation(const orbx_kf *k1, const uint8_t *flag1, const orbx_kf *const *k2s, const uint8_t *const *flags2, int n2,
+                                     const float *F12s, const float *epipoles,
+                                     const float *scale_factors2, const float *level_sigma2_2, int nlevels2,
+                                     int only_stereo, int check_orientation, int32_t *pairs, int cap, int *npairs);
+
 /* ---- Frame::ComputeBoW (src/Frame.cc:459-466) --------------------------- */
 
 /* DBoW2 vocabulary tree resident in HBM.  Arrays describe nodes 1..N in id order exactly as
@@ -396,6 +434,9 @@ int orbx_debug_level_counts(orbx_extractor *e, int image_index, int32_t *counts 
  * (LDS distance table + row fixpoint); a call picks by problem size.  form = 1 / 2 forces the wave / table form for
  * every later call of the process, 0 restores the automatic choice.  Both forms return identical matches. */
 int orbx_debug_set_bow_form(int form);
+/* host phases of the calling thread's most recent per-call matcher search (orbx_match.hip), microseconds:
+ * [0] prepare (node intersection, participation bytes, packing), [1] launch, [2] wait for the kernel's ticket, [3] copy-out */
+int orbx_debug_match_timing(double *out4);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ The directory name contains a '-', so load it with importlib (see tests/conftest
 """
 from . import orbx, streams
 from .orbx import (OrbxError, KP_DTYPE, lib, lib_path, ORBextractor, ORBmatcher, ComputeStereoMatches,
-                   FeatSet, make_featset, STAGES, BowDatabase, BowFrames, ORBVocabulary, ComputeDistinctiveDescriptors, Rectifier, UndistortKeyPoints)
+                   FeatSet, make_featset, STAGES, BowDatabase, DeviceKeyFrame, BowFrames, ORBVocabulary, ComputeDistinctiveDescriptors, Rectifier, UndistortKeyPoints)
 
 __all__ = ["OrbxError", "KP_DTYPE", "lib", "lib_path", "ORBextractor", "ORBmatcher", "ComputeStereoMatches",
-           "FeatSet", "make_featset", "STAGES", "BowDatabase", "BowFrames", "ORBVocabulary", "ComputeDistinctiveDescriptors", "Rectifier", "UndistortKeyPoints"]
+           "FeatSet", "make_featset", "STAGES", "BowDatabase", "DeviceKeyFrame", "BowFrames", "ORBVocabulary", "ComputeDistinctiveDescriptors", "Rectifier", "UndistortKeyPoints"]

@@ -1,5 +1,7 @@
-// orbx_bow.hip — ORBmatcher::SearchByBoW (KF,F) / (KF,KF) and SearchForTriangulation for gfx950
-// (reference src/ORBmatcher.cc:171-303, :568-702, :704-871, :147-164, :1687-1728).
+// orbx_bow.hip — ORBmatcher::SearchByBoW (KF,F) / (KF,KF) for gfx950, the THROUGHPUT forms (reference src/ORBmatcher.cc:171-303,
+// :568-702, :1687-1728): thousands of (keyframe, frame) pairs per launch, FeatureVectors intersected on the device (the batched,
+// device-resident relocalisation chain of BASELINE config 3).  The per-call forms, SearchForTriangulation and the resident
+// keyframe handles live in orbx_match.hip.
 //
 // One 256-thread workgroup per keyframe pair.  The two FeatureVectors (CSR, node ids ascending)
 // are intersected by binary search (same node set as the reference's merge join); every shared
@@ -13,8 +15,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
-
-struct TriParams { float F[9]; float ex, ey; float sf2[ORBX_MAX_LEVELS]; float sig2[ORBX_MAX_LEVELS]; int only_stereo; };
 
 #define BOW_TH_LOW 50
 #define BOW_HISTO 30
@@ -393,89 +393,6 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
     histogram_filter(match, bins, nslots, check_ori, hist, keep3, &s_cnt, nmatches + pair);
 }
 
-// SearchForTriangulation: rows are independent (vbMatched2 is never written in the reference)
-__global__ __launch_bounds__(256) void k_triangulation(const DevFeat *__restrict__ side_a, const DevFeat *__restrict__ side_b,
-                                                       TriParams tp, int check_ori, int32_t *__restrict__ m12,
-                                                       int32_t *__restrict__ pairs, int cap, int *__restrict__ npairs)
-{
-    __shared__ int hist[BOW_HISTO];
-    __shared__ int keep3[3];
-    __shared__ int s_cnt;
-    __shared__ int s_w[4];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const DevFeat A = side_a[0];
-    const DevFeat B = side_b[0];
-    uint8_t *bins = bow_smem; // [A.n]
-    for (int i = tid; i < A.n; i += 256) { bins[i] = 255; m12[i] = -1; }
-    __syncthreads();
-    for (int ia = wv; ia < A.nnodes; ia += 4) {
-        const int ib = find_node(B.node_id, B.nnodes, A.node_id[ia]);
-        if (ib < 0) continue;
-        const int b0 = B.node_off[ib], b1 = B.node_off[ib + 1];
-        for (int i1 = A.node_off[ia]; i1 < A.node_off[ia + 1]; i1++) {
-            const int idx1 = (int)A.feat[i1];
-            if (A.flag[idx1]) continue;            // already has a MapPoint (:750)
-            const bool stereo1 = A.u_right[idx1] >= 0;
-            if (tp.only_stereo && !stereo1) continue;
-            const float x1 = A.x[idx1], y1 = A.y[idx1];
-            // epipolar line of kp1 in image 2 (:150-152)
-            const float la = x1 * tp.F[0] + y1 * tp.F[3] + tp.F[6];
-            const float lb = x1 * tp.F[1] + y1 * tp.F[4] + tp.F[7];
-            const float lc = x1 * tp.F[2] + y1 * tp.F[5] + tp.F[8];
-            const float den = la * la + lb * lb;
-            uint32_t da[8];
-            load_desc(A.desc, idx1, da);
-            unsigned key = 0xFFFFFFFFu; // dist<<20 | (0xFFFFF - position): min distance, LAST index on ties (:786)
-            for (int j = b0 + lane; j < b1; j += 64) {
-                const int idx2 = (int)B.feat[j];
-                if (B.flag[idx2]) continue;
-                const bool stereo2 = B.u_right[idx2] >= 0;
-                if (tp.only_stereo && !stereo2) continue;
-                uint32_t db[8];
-                load_desc(B.desc, idx2, db);
-                const int dist = hamming256(da, db);
-                if (dist > BOW_TH_LOW) continue;
-                const float x2 = B.x[idx2], y2 = B.y[idx2];
-                const int oct2 = B.octave[idx2];
-                if (!stereo1 && !stereo2) {
-                    const float distex = tp.ex - x2, distey = tp.ey - y2;
-                    if (distex * distex + distey * distey < 100 * tp.sf2[oct2]) continue;
-                }
-                const float num = la * x2 + lb * y2 + lc;
-                if (den == 0) continue;
-                const float dsqr = num * num / den;
-                if (!((double)dsqr < 3.84 * (double)tp.sig2[oct2])) continue;
-                const unsigned k = ((unsigned)dist << 20) | (0xFFFFFu - (unsigned)(j - b0));
-                key = k < key ? k : key;
-            }
-            key = wave_min_u32(key);
-            if (key == 0xFFFFFFFFu) continue;
-            if (lane == 0) {
-                const int idx2 = (int)B.feat[b0 + (int)(0xFFFFFu - (key & 0xFFFFFu))];
-                m12[idx1] = idx2;
-                bins[idx1] = (uint8_t)rot_bin(A.angle[idx1], B.angle[idx2]);
-            }
-        }
-    }
-    __syncthreads();
-    histogram_filter(m12, bins, A.n, check_ori, hist, keep3, &s_cnt, npairs + 1);
-    __syncthreads();
-    // ordered compaction of (idx1, idx2), ascending idx1 (:863-868)
-    const int per = (A.n + 255) >> 8;
-    const int beg = tid * per, end = min(beg + per, A.n);
-    int c = 0;
-    for (int i = beg; i < end; i++) c += m12[i] >= 0;
-    int total;
-    int off = block_excl_scan256(c, &total, s_w);
-    for (int i = beg; i < end; i++)
-        if (m12[i] >= 0) {
-            if (off < cap) { pairs[2 * off] = i; pairs[2 * off + 1] = m12[i]; }
-            off++;
-        }
-    if (tid == 0) npairs[0] = total;
-}
-
-
 // 0 = choose by size, 1 = always the wave form, 2 = always the table form (explicit debug entry point, no environment lookup)
 static std::atomic<int> g_bow_form{0};
 extern "C" int orbx_debug_set_bow_form(int form)
@@ -484,6 +401,8 @@ extern "C" int orbx_debug_set_bow_form(int form)
     g_bow_form.store(form, std::memory_order_relaxed);
     return ORBX_OK;
 }
+
+int orbx_bow_forced_form() { return g_bow_form.load(std::memory_order_relaxed); }
 
 // pairs < BOW_TABLE_MIN_PAIRS: too few workgroups to fill 256 CUs, the 16-wave latency form is faster per call
 #define BOW_TABLE_MIN_PAIRS 4096
@@ -565,11 +484,11 @@ static int bow_reserve(BowCtx *c, size_t blob, size_t out_ints)
 
 static size_t a16(size_t v) { return (v + 15) & ~(size_t)15; }
 
-static int feat_validate(const orbx_featset *f, int need_geom)
+int orbx_feat_validate(const orbx_featset *f, int need_geom, int need_flag)
 {
     if (!f || f->n < 0 || f->nnodes < 0) return 0;
     if (f->n >= (1 << 20)) return 0;
-    if (f->n && (!f->desc || !f->flag || !f->angle)) return 0;
+    if (f->n && (!f->desc || (need_flag && !f->flag) || !f->angle)) return 0;
     if (f->nnodes && (!f->node_id || !f->node_off || !f->feat)) return 0;
     if (need_geom && f->n && (!f->x || !f->y || !f->octave || !f->u_right)) return 0;
     if (f->nnodes) {
@@ -652,18 +571,21 @@ static void feat_pack(const orbx_featset *f, int geom, uint8_t *h, const uint8_t
     }
 }
 
-static int bow_run(int mode, int device, const orbx_featset *as, int na, const orbx_featset *b, int b_shared,
-                   float nnratio, int check_ori, int32_t *match, int *nmatches)
+// The SearchByBoW kernels of this file behind the host-pointer entry points of orbx_match.hip: taken when the test hook forces a
+// form, or when a vocabulary node is too large for the register form there.
+int orbx_bow_run_legacy(int mode, int device, const orbx_featset *as, int na, const orbx_featset *b,
+                        float nnratio, int check_ori, int32_t *match, int *nmatches)
 {
+    const int b_shared = 1;
     if (!as || !b || na < 1 || !match || !nmatches) { orbx_set_error("bow search: null argument"); return ORBX_E_INVALID; }
     size_t blob = a16(sizeof(DevFeat) * (size_t)(na + 1));
     int max_b = 0, max_slots = 0;
     for (int i = 0; i < na; i++) {
-        if (!feat_validate(&as[i], 0)) { orbx_set_error("bow search: malformed feature set %d", i); return ORBX_E_INVALID; }
+        if (!orbx_feat_validate(&as[i], 0, 1)) { orbx_set_error("bow search: malformed feature set %d", i); return ORBX_E_INVALID; }
         blob += feat_bytes(&as[i], 0);
         if (mode == 1 && as[i].n > max_slots) max_slots = as[i].n;
     }
-    if (!feat_validate(b, 0)) { orbx_set_error("bow search: malformed feature set"); return ORBX_E_INVALID; }
+    if (!orbx_feat_validate(b, 0, 1)) { orbx_set_error("bow search: malformed feature set"); return ORBX_E_INVALID; }
     blob += feat_bytes(b, 0);
     max_b = b->n;
     const int stride = mode == 0 ? b->n : max_slots;
@@ -710,7 +632,7 @@ extern "C" int orbx_bowdb_create(int device, const orbx_featset *kfs, int nkf, o
     *out = nullptr;
     size_t blob = a16(sizeof(DevFeat) * (size_t)nkf);
     for (int i = 0; i < nkf; i++) {
-        if (!feat_validate(&kfs[i], 0)) { orbx_set_error("orbx_bowdb_create: malformed feature set %d", i); return ORBX_E_INVALID; }
+        if (!orbx_feat_validate(&kfs[i], 0, 1)) { orbx_set_error("orbx_bowdb_create: malformed feature set %d", i); return ORBX_E_INVALID; }
         blob += feat_bytes(&kfs[i], 0);
     }
     BowCtx *c;
@@ -753,7 +675,7 @@ extern "C" int orbx_bowdb_search(orbx_bowdb *db, const orbx_featset *f, float nn
                                  int32_t *match_f, int *nmatches)
 {
     if (!db || !f || !match_f || !nmatches) { orbx_set_error("orbx_bowdb_search: null argument"); return ORBX_E_INVALID; }
-    if (!feat_validate(f, 0)) { orbx_set_error("orbx_bowdb_search: malformed feature set"); return ORBX_E_INVALID; }
+    if (!orbx_feat_validate(f, 0, 1)) { orbx_set_error("orbx_bowdb_search: malformed feature set"); return ORBX_E_INVALID; }
     ORBX_HIP(hipSetDevice(db->device));
     const size_t fb = a16(sizeof(DevFeat)) + feat_bytes(f, 0);
     if (fb > db->h_f_cap) {
@@ -805,69 +727,6 @@ extern "C" int orbx_bowdb_search_batch_device(orbx_bowdb *db, const orbx_bow_fra
     const int rc = bow_launch<0>(db->nkf, batch, fr->cap, fr->cap, stream ? (hipStream_t)stream : fr->last_stream, (const DevFeat *)db->d_blob,
                                  (const DevFeat *)fr->d_feats, 1, nnratio, check_orientation, (int32_t *)d_match, fr->cap, (int *)d_nmatches);
     if (rc) return rc;
-    return ORBX_OK;
-}
-
-extern "C" int orbx_search_by_bow_kf_f(int device, const orbx_featset *kf, const orbx_featset *f,
-                                       float nnratio, int check_orientation, int32_t *match_f, int *nmatches)
-{
-    return bow_run(0, device, kf, 1, f, 1, nnratio, check_orientation, match_f, nmatches);
-}
-
-extern "C" int orbx_search_by_bow_kf_f_batch(int device, const orbx_featset *kfs, int nkf, const orbx_featset *f,
-                                             float nnratio, int check_orientation, int32_t *match_f, int *nmatches)
-{
-    return bow_run(0, device, kfs, nkf, f, 1, nnratio, check_orientation, match_f, nmatches);
-}
-
-extern "C" int orbx_search_by_bow_kf_kf(int device, const orbx_featset *k1, const orbx_featset *k2,
-                                        float nnratio, int check_orientation, int32_t *match12, int *nmatches)
-{
-    return bow_run(1, device, k1, 1, k2, 1, nnratio, check_orientation, match12, nmatches);
-}
-
-extern "C" int orbx_search_for_triangulation(int device, const orbx_featset *k1, const orbx_featset *k2,
-                                             const float F12[9], float ex, float ey,
-                                             const float *sf2, const float *sig2, int nlevels2,
-                                             int only_stereo, int check_orientation, int32_t *pairs, int cap, int *npairs)
-{
-    if (!k1 || !k2 || !F12 || !sf2 || !sig2 || !pairs || !npairs || cap < 0 || nlevels2 < 1 || nlevels2 > ORBX_MAX_LEVELS) {
-        orbx_set_error("orbx_search_for_triangulation: invalid argument");
-        return ORBX_E_INVALID;
-    }
-    if (!feat_validate(k1, 1) || !feat_validate(k2, 1)) { orbx_set_error("triangulation search: malformed feature set"); return ORBX_E_INVALID; }
-    for (int i = 0; i < k2->n; i++)
-        if (k2->octave[i] < 0 || k2->octave[i] >= nlevels2) { orbx_set_error("octave out of range"); return ORBX_E_INVALID; }
-    BowCtx *c;
-    int rc = bow_ctx(device, &c);
-    if (rc) return rc;
-    const size_t blob = a16(sizeof(DevFeat) * 2) + feat_bytes(k1, 1) + feat_bytes(k2, 1);
-    const size_t out_ints = (size_t)k1->n + 2 * (size_t)cap + 2 + 16;
-    if ((rc = bow_reserve(c, blob, out_ints))) return rc;
-    DevFeat *hd = (DevFeat *)c->h_blob;
-    size_t off = a16(sizeof(DevFeat) * 2);
-    feat_pack(k1, 1, c->h_blob, c->d_blob, &off, &hd[0]);
-    feat_pack(k2, 1, c->h_blob, c->d_blob, &off, &hd[1]);
-    ORBX_HIP(hipMemcpyAsync(c->d_blob, c->h_blob, off, hipMemcpyHostToDevice, c->stream));
-    TriParams tp;
-    memset(&tp, 0, sizeof tp);
-    for (int i = 0; i < 9; i++) tp.F[i] = F12[i];
-    tp.ex = ex; tp.ey = ey; tp.only_stereo = only_stereo;
-    for (int i = 0; i < nlevels2; i++) { tp.sf2[i] = sf2[i]; tp.sig2[i] = sig2[i]; }
-    int32_t *d_m12 = c->d_out, *d_pairs = d_m12 + ((k1->n + 3) & ~3), *d_np = d_pairs + 2 * (size_t)cap;
-    const size_t lds = (size_t)((k1->n + 15) & ~15) + 16;
-    if (lds > 150 * 1024) { orbx_set_error("feature set too large for LDS"); return ORBX_E_INVALID; }
-    ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_triangulation), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const DevFeat *dA = (const DevFeat *)c->d_blob;
-    hipLaunchKernelGGL(k_triangulation, dim3(1), dim3(256), lds, c->stream, dA, dA + 1, tp, check_orientation, d_m12, d_pairs, cap, d_np);
-    ORBX_HIP(hipGetLastError());
-    int32_t *h_pairs = c->h_out;
-    ORBX_HIP(hipMemcpyAsync(h_pairs, d_pairs, (2 * (size_t)cap + 2) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    ORBX_HIP(hipStreamSynchronize(c->stream));
-    const int np = h_pairs[2 * (size_t)cap];
-    *npairs = np;
-    memcpy(pairs, h_pairs, sizeof(int32_t) * 2 * (size_t)(np < cap ? np : cap));
-    if (np > cap) { orbx_set_error("pair capacity %d < %d matches", cap, np); return ORBX_E_CAPACITY; }
     return ORBX_OK;
 }
 

@@ -21,6 +21,18 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     return v;
 }
 
+// inclusive wave64 prefix OR, same network
+__device__ __forceinline__ unsigned wave_incl_scan_or(unsigned v)
+{
+    v |= (unsigned)ORBX_DPP(v, 0, 0x111, 0xf, 0xf);
+    v |= (unsigned)ORBX_DPP(v, 0, 0x112, 0xf, 0xf);
+    v |= (unsigned)ORBX_DPP(v, 0, 0x114, 0xf, 0xf);
+    v |= (unsigned)ORBX_DPP(v, 0, 0x118, 0xf, 0xf);
+    v |= (unsigned)ORBX_DPP(v, 0, 0x142, 0xa, 0xf);
+    v |= (unsigned)ORBX_DPP(v, 0, 0x143, 0xc, 0xf);
+    return v;
+}
+
 // Wave64 reductions on the DPP data path (row_shr 1/2/4/8 inside each 16-lane row, then row_bcast 15 / 31
 // across rows; the total lands in lane 63 and is broadcast with v_readlane): 6 VALU + DPP steps instead of the six
 // dependent ds_bpermute round trips that __shfl_xor lowers to.  Lanes without a source read `identity`.

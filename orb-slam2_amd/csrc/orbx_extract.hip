@@ -684,10 +684,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         if (in_regs) { \
             _Pragma("unroll") for (int k_ = 0; k_ < RP; k_++) { \
                 const int i = tid + NT * k_; \
-                if (i < n) { const uint32_t p = rp[k_]; unsigned nd = rn[k_]; __VA_ARGS__; rn[k_] = nd; } \
+                if (i < n) { const uint32_t p = rp[k_]; (void)p; unsigned nd = rn[k_]; __VA_ARGS__; rn[k_] = nd; } \
             } \
         } else { \
-            for (int i = tid; i < n; i += NT) { const uint32_t p = pts[i]; unsigned nd = nid[i]; __VA_ARGS__; nid[i] = (uint16_t)nd; } \
+            for (int i = tid; i < n; i += NT) { const uint32_t p = pts[i]; (void)p; unsigned nd = nid[i]; __VA_ARGS__; nid[i] = (uint16_t)nd; } \
         } } while (0)
     TSTAMP(0);  // cell counts, prefix, gather
     // ---- roots (src/ORBextractor.cc:627-705)

@@ -150,6 +150,12 @@ struct orbx_bow_frames {
 };
 
 void orbx_set_error(const char *fmt, ...);
+// orbx_bow.hip: CSR / pointer validation of a feature set; the legacy SearchByBoW kernels behind orbx_match.hip's entry points;
+// the form forced by orbx_debug_set_bow_form (0 = none)
+int orbx_feat_validate(const orbx_featset *f, int need_geom, int need_flag);
+int orbx_bow_run_legacy(int mode, int device, const orbx_featset *as, int na, const orbx_featset *b,
+                        float nnratio, int check_ori, int32_t *match, int *nmatches);
+int orbx_bow_forced_form();
 #define ORBX_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
     orbx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return ORBX_E_HIP; } } while (0)
 

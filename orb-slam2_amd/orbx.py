@@ -87,6 +87,14 @@ def lib():
     L.orbx_search_by_bow_kf_f_batch.argtypes = [i, FS, i, FS, f, i, vp, vp]
     L.orbx_search_by_bow_kf_kf.argtypes = [i, FS, FS, f, i, vp, ip]
     L.orbx_search_for_triangulation.argtypes = [i, FS, FS, vp, f, f, vp, vp, i, i, i, vp, i, ip]
+    L.orbx_search_by_bow_kf_kf_batch.argtypes = [i, FS, FS, i, f, i, vp, vp]
+    L.orbx_search_for_triangulation_batch.argtypes = [i, FS, FS, i, vp, vp, vp, vp, i, i, i, vp, i, vp]
+    L.orbx_kf_create.argtypes = [i, FS, C.POINTER(vp)]
+    L.orbx_kf_destroy.argtypes = [vp]; L.orbx_kf_destroy.restype = None
+    L.orbx_kf_size.argtypes = [vp]
+    L.orbx_kf_search_by_bow_kf_f.argtypes = [vp, vp, vp, f, i, vp, ip]
+    L.orbx_kf_search_by_bow_kf_kf.argtypes = [vp, vp, vp, vp, i, f, i, vp, vp]
+    L.orbx_kf_search_for_triangulation.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, i, i, i, vp, i, vp]
     L.orbx_bowdb_create.argtypes = [i, FS, i, C.POINTER(vp)]
     L.orbx_bowdb_search.argtypes = [vp, FS, f, i, vp, vp]
     L.orbx_bowdb_size.argtypes = [vp]
@@ -124,6 +132,7 @@ def lib():
     L.orbx_debug_candidates.argtypes = [vp, i, i, vp, vp, vp, i, ip]
     L.orbx_debug_level_counts.argtypes = [vp, i, vp]
     L.orbx_debug_set_bow_form.argtypes = [i]
+    L.orbx_debug_match_timing.argtypes = [vp]
     _lib = L
     return L
 
@@ -446,6 +455,23 @@ class ORBVocabulary:
                     fv_node_id=fid[:fn.value].copy(), fv_node_off=foff[:fn.value + 1].copy(), fv_feat=ffeat[:foff[fn.value]].copy())
 
 
+class DeviceKeyFrame:
+    """orbx_kf: a keyframe's (or frame's) immutable matching data resident in HBM in FeatureVector order: descriptors,
+    FeatureVector, angles and, when given, positions / octaves / u_right.  Map-point flags are passed per search."""
+
+    def __init__(self, fs, device=0):
+        s, keep = make_featset(fs)
+        h = C.c_void_p()
+        _check(lib().orbx_kf_create(device, C.byref(s), C.byref(h)))
+        self._h, self.n, self.device = h, s.n, device
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().orbx_kf_destroy(h)
+            self._h = None
+
+
 class BowDatabase:
     """Device-resident keyframe set (include/orbx.h: orbx_bowdb_*): upload once, search many frames."""
 
@@ -536,6 +562,62 @@ class ORBmatcher:
         out = np.full((len(sets), b.n), -1, np.int32); n = np.zeros(len(sets), np.int32)
         _check(lib().orbx_search_by_bow_kf_f_batch(self.device, arr, len(sets), C.byref(b), self.mfNNratio, int(self.mbCheckOrientation), _p(out), _p(n)))
         return out, n
+
+    def SearchByBoWKeyFrames(self, pKF1, keyframes2):
+        """LoopClosing::ComputeSim3's loop (src/LoopClosing.cc:293-323): SearchByBoW(pKF1, pKF2) for every candidate in
+        one call -> (match12[n2, n1], nmatches[n2])"""
+        a, ka = make_featset(pKF1)
+        sets = [make_featset(k) for k in keyframes2]
+        arr = (FeatSet * len(sets))(*[s[0] for s in sets])
+        out = np.full((len(sets), a.n), -1, np.int32); n = np.zeros(len(sets), np.int32)
+        _check(lib().orbx_search_by_bow_kf_kf_batch(self.device, C.byref(a), arr, len(sets), self.mfNNratio, int(self.mbCheckOrientation), _p(out), _p(n)))
+        return out, n
+
+    def SearchForTriangulationBatch(self, pKF1, keyframes2, F12s, epipoles, scaleFactors2, levelSigma2_2, bOnlyStereo=False):
+        """LocalMapping::CreateNewMapPoints' loop (src/LocalMapping.cc:241-309): the current keyframe against every neighbour in
+        one call -> list of (npairs_i, 2) arrays"""
+        a, ka = make_featset(pKF1)
+        sets = [make_featset(k) for k in keyframes2]
+        arr = (FeatSet * len(sets))(*[s[0] for s in sets])
+        F = np.ascontiguousarray(np.asarray(F12s, np.float32).reshape(len(sets), 9))
+        ep = np.ascontiguousarray(np.asarray(epipoles, np.float32).reshape(len(sets), 2))
+        sf = np.ascontiguousarray(scaleFactors2, np.float32); sg = np.ascontiguousarray(levelSigma2_2, np.float32)
+        cap = max(a.n, 1)
+        pairs = np.zeros((len(sets), cap, 2), np.int32); n = np.zeros(len(sets), np.int32)
+        _check(lib().orbx_search_for_triangulation_batch(self.device, C.byref(a), arr, len(sets), _p(F), _p(ep), _p(sf), _p(sg), len(sf),
+                                                         int(bOnlyStereo), int(self.mbCheckOrientation), _p(pairs), cap, _p(n)))
+        return [pairs[i, :n[i]].copy() for i in range(len(sets))]
+
+    # ---- the same searches on resident keyframes (DeviceKeyFrame): flags travel per call
+    def SearchByBoWResident(self, kf, kf_flag, frame):
+        """SearchByBoW(pKF, F) with both sides resident -> (match_f, nmatches)"""
+        fl = np.ascontiguousarray(kf_flag, np.uint8)
+        out = np.full(frame.n, -1, np.int32); n = C.c_int()
+        _check(lib().orbx_kf_search_by_bow_kf_f(kf._h, _p(fl), frame._h, self.mfNNratio, int(self.mbCheckOrientation), _p(out), C.byref(n)))
+        return out, n.value
+
+    def SearchByBoWKeyFramesResident(self, kf1, flag1, kfs2, flags2):
+        f1 = np.ascontiguousarray(flag1, np.uint8)
+        f2 = [np.ascontiguousarray(x, np.uint8) for x in flags2]
+        hs = (C.c_void_p * len(kfs2))(*[k._h for k in kfs2])
+        fp = (C.c_void_p * len(kfs2))(*[x.ctypes.data for x in f2])
+        out = np.full((len(kfs2), kf1.n), -1, np.int32); n = np.zeros(len(kfs2), np.int32)
+        _check(lib().orbx_kf_search_by_bow_kf_kf(kf1._h, _p(f1), hs, fp, len(kfs2), self.mfNNratio, int(self.mbCheckOrientation), _p(out), _p(n)))
+        return out, n
+
+    def SearchForTriangulationResident(self, kf1, flag1, kfs2, flags2, F12s, epipoles, scaleFactors2, levelSigma2_2, bOnlyStereo=False):
+        f1 = np.ascontiguousarray(flag1, np.uint8) if flag1 is not None else None
+        f2 = [np.ascontiguousarray(x, np.uint8) for x in flags2] if flags2 is not None else None
+        hs = (C.c_void_p * len(kfs2))(*[k._h for k in kfs2])
+        fp = (C.c_void_p * len(kfs2))(*[x.ctypes.data for x in f2]) if f2 is not None else None
+        F = np.ascontiguousarray(np.asarray(F12s, np.float32).reshape(len(kfs2), 9))
+        ep = np.ascontiguousarray(np.asarray(epipoles, np.float32).reshape(len(kfs2), 2))
+        sf = np.ascontiguousarray(scaleFactors2, np.float32); sg = np.ascontiguousarray(levelSigma2_2, np.float32)
+        cap = max(kf1.n, 1)
+        pairs = np.zeros((len(kfs2), cap, 2), np.int32); n = np.zeros(len(kfs2), np.int32)
+        _check(lib().orbx_kf_search_for_triangulation(kf1._h, _p(f1), hs, fp, len(kfs2), _p(F), _p(ep), _p(sf), _p(sg), len(sf),
+                                                      int(bOnlyStereo), int(self.mbCheckOrientation), _p(pairs), cap, _p(n)))
+        return [pairs[i, :n[i]].copy() for i in range(len(kfs2))]
 
     @staticmethod
     def _frame(d):

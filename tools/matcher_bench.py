@@ -91,6 +91,14 @@ def measure(pkg, oracle_py=None, reps=200, cpu_reps=40, nbatch=20, device=0):
                                                                                  p(pairs), cap, C.byref(n))),
     }
     res["gpu"] = {k: round(_median_us(f, reps), 1) for k, f in gpu.items()}
+    if hasattr(L, "orbx_debug_match_timing"):
+        ph = np.zeros(4)
+        res["gpu_host_phases_us"] = {"fields": "prepare, launch, wait, copy-out"}
+        for k, f in gpu.items():
+            acc = []
+            for _ in range(50):
+                f(); L.orbx_debug_match_timing(p(ph)); acc.append(ph.copy())
+            res["gpu_host_phases_us"][k] = [round(float(v), 1) for v in np.median(np.array(acc), axis=0)]
     nm = {}
     gpu["search_by_bow_kf_f"](); nm["search_by_bow_kf_f"] = n.value
     gpu["search_by_bow_kf_kf"](); nm["search_by_bow_kf_kf"] = n.value
@@ -114,6 +122,46 @@ def measure(pkg, oracle_py=None, reps=200, cpu_reps=40, nbatch=20, device=0):
         res["gpu_batch"] = {"pairs_per_call": nbatch, "unit": "us per pair",
                             "search_for_triangulation_batch": round(tb / nbatch, 2), "search_by_bow_kf_kf_batch": round(kb / nbatch, 2),
                             "search_by_bow_kf_f_batch": round(fb / nbatch, 2)}
+
+    # ---- resident keyframes (orbx_kf_*): descriptors / FeatureVectors live in HBM, only flags, node intersection and results move
+    if hasattr(L, "orbx_kf_create"):
+        dcur = pkg.DeviceKeyFrame(tri_cur); dks = [pkg.DeviceKeyFrame(k) for k in tri_kfs]
+        hs1 = (C.c_void_p * 1)(dks[0]._h); hsN = (C.c_void_p * nbatch)(*[k._h for k in dks])
+        bflags = [np.ascontiguousarray(k["flag"]) for k in kfs]; tflags = [np.ascontiguousarray(k["flag"]) for k in tri_kfs]
+        bf1 = (C.c_void_p * 1)(bflags[0].ctypes.data); bfN = (C.c_void_p * nbatch)(*[x.ctypes.data for x in bflags])
+        tf1 = (C.c_void_p * 1)(tflags[0].ctypes.data); tfN = (C.c_void_p * nbatch)(*[x.ctypes.data for x in tflags])
+        cflag_b = np.ascontiguousarray(cur["flag"]); cflag_t = np.ascontiguousarray(tri_cur["flag"])
+        Fall = np.ascontiguousarray(np.stack([f.reshape(9) for f in Fs]).astype(np.float32))
+        exy = np.ascontiguousarray(np.array(eps, np.float32))
+        bpairs = np.zeros((nbatch, cap, 2), np.int32); bn = np.zeros(nbatch, np.int32); bm = np.full((nbatch, Fr.n), -1, np.int32)
+        r1 = {
+            "search_by_bow_kf_f": lambda: chk(L.orbx_kf_search_by_bow_kf_f(dks[0]._h, p(bflags[0]), dcur._h, 0.7, 1, p(out_f), C.byref(n))),
+            "search_by_bow_kf_kf": lambda: chk(L.orbx_kf_search_by_bow_kf_kf(dcur._h, p(cflag_b), hs1, bf1, 1, 0.75, 1, p(out_a), p(bn))),
+            "search_for_triangulation": lambda: chk(L.orbx_kf_search_for_triangulation(dcur._h, p(cflag_t), hs1, tf1, 1, p(F0), p(exy), p(sf), p(sg), 8, 0, 0,
+                                                                                       p(pairs), cap, p(bn))),
+        }
+        res["gpu_resident"] = {k: round(_median_us(f, reps), 1) for k, f in r1.items()}
+        if hasattr(L, "orbx_debug_match_timing"):
+            ph = np.zeros(4)
+            res["gpu_resident_host_phases_us"] = {"fields": "prepare, launch, wait, copy-out"}
+            for k, f in r1.items():
+                acc = []
+                for _ in range(50):
+                    f(); L.orbx_debug_match_timing(p(ph)); acc.append(ph.copy())
+                res["gpu_resident_host_phases_us"][k] = [round(float(v), 1) for v in np.median(np.array(acc), axis=0)]
+        rb = {
+            "search_by_bow_kf_kf": lambda: chk(L.orbx_kf_search_by_bow_kf_kf(dcur._h, p(cflag_b), hsN, bfN, nbatch, 0.75, 1, p(bm), p(bn))),
+            "search_for_triangulation": lambda: chk(L.orbx_kf_search_for_triangulation(dcur._h, p(cflag_t), hsN, tfN, nbatch, p(Fall), p(exy), p(sf), p(sg), 8, 0, 0,
+                                                                                       p(bpairs), cap, p(bn))),
+        }
+        res["gpu_resident_batch"] = {"pairs_per_call": nbatch, "unit": "us per pair"}
+        for k, f in rb.items():
+            res["gpu_resident_batch"][k] = round(_median_us(f, max(reps // 4, 10)) / nbatch, 2)
+            if hasattr(L, "orbx_debug_match_timing"):
+                ph = np.zeros(4); acc = []
+                for _ in range(20):
+                    f(); L.orbx_debug_match_timing(p(ph)); acc.append(ph.copy())
+                res["gpu_resident_batch"][k + "_host_phases_us_per_call"] = [round(float(v), 1) for v in np.median(np.array(acc), axis=0)]
 
     # ---- the CPU oracle on the same inputs (one thread, as the reference runs each search)
     if oracle_py is not None:
