@@ -20,9 +20,11 @@
  * Streams: a handle remembers the stream of its most recent "*_device" launches.  Whenever a call
  * has to rebuild the per-image-size tables (first call / a new image size) or to grow a workspace,
  * it first waits for that stream and for the handle's own stream, so tables and buffers are never
- * rewritten or freed under running kernels.  A caller stream must therefore stay valid until the
- * handle has been used with another stream or destroyed.  Steady state (same size, same batch)
- * never synchronises.  A kernel-side error (ORBX_E_CAPACITY from orbx_sync) belongs to the work
+ * rewritten or freed under running kernels.  A call that launches on a DIFFERENT stream than the
+ * previous one on the same handle is ordered behind the earlier work by an event (the handle's
+ * pyramid and candidate workspaces are shared by all its launches), without a host synchronisation.
+ * A caller stream must therefore stay valid until the handle has been used with another stream or
+ * destroyed.  Steady state (same size, same batch, same stream) neither synchronises nor records events.  A kernel-side error (ORBX_E_CAPACITY from orbx_sync) belongs to the work
  * that orbx_sync has just waited for; the flag is cleared when it is reported.
  */
 #ifndef ORBX_H
@@ -61,6 +63,16 @@ int orbx_device_count(void);
 int orbx_extractor_create(orbx_extractor **out, int nfeatures, float scale_factor, int nlevels,
                           int ini_th_fast, int min_th_fast, int device, int max_w, int max_h, int max_batch);
 void orbx_extractor_destroy(orbx_extractor *e);
+
+/* Which OpenCV generation's cv::GaussianBlur(7x7, sigma 2) the descriptors are computed on (src/ORBextractor.cc:1311).  The
+ * reference builds against "OpenCV 2.4.3 or later, tested with 2.4.11 and 3.2" (README.md:68), and OpenCV changed the 8-bit
+ * Gaussian at 3.4.2 to a fixed-point kernel that sums to exactly 256 -- different blurred pixels, different rBRIEF bits.  The
+ * arithmetic around the taps is the same in both, so the profile is the 7-tap table (orbx_gaussian_taps).  Default: 3.2, the
+ * version the reference was tested with.  Call right after orbx_extractor_create; it applies to all later extractions. */
+#define ORBX_CV_PROFILE_3_2 0     /* OpenCV <= 3.4.1: taps 18 34 49 55 49 34 18 (sum 257) */
+#define ORBX_CV_PROFILE_3_4_2 1   /* OpenCV >= 3.4.2, 4.x: taps 18 34 48 56 48 34 18 (sum 256) */
+int orbx_extractor_set_cv_profile(orbx_extractor *e, int profile);
+int orbx_gaussian_taps(int profile, int taps[7]);
 
 /* getters: GetLevels / GetScaleFactor / GetScaleFactors / GetInverseScaleFactors /
  * GetScaleSigmaSquares / GetInverseScaleSigmaSquares (include/ORBextractor.h:78-98).

@@ -98,6 +98,9 @@ def lib():
         L.oracle_fast_score.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.oracle_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_size_t]
         L.oracle_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.oracle_gaussian_blur7_profile.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        L.oracle_gaussian_taps.argtypes = [C.c_int, C.c_void_p]
+        L.oracle_set_cv_profile.argtypes = [C.c_void_p, C.c_int]
         L.oracle_distribute_octtree.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.oracle_hamming.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -151,6 +154,10 @@ class Oracle:
             self.L.oracle_destroy(self.h)
             self.h = None
 
+    def set_cv_profile(self, profile):
+        """0 = OpenCV <= 3.4.1 GaussianBlur taps (default), 1 = OpenCV >= 3.4.2 fixed-point taps"""
+        assert self.L.oracle_set_cv_profile(self.h, profile) == 0
+
     def _farr(self, fn, n=None):
         return np.ctypeslib.as_array(fn(self.h), shape=(n or self.nlevels,)).copy()
 
@@ -198,6 +205,12 @@ def stereo_match(oL, oR, kL, dL, kR, dR, bf, min_z):
     rc = lib().oracle_stereo_match(oL.h, oR.h, _p(kL), _p(dL), len(kL), _p(kR), _p(dR), len(kR), bf, min_z, _p(ur), _p(dp))
     assert rc == 0
     return ur, dp
+
+
+def gaussian_taps(profile):
+    t = np.zeros(7, np.int32)
+    lib().oracle_gaussian_taps(profile, t.ctypes.data)
+    return t
 
 
 def hamming(a, b):

@@ -165,29 +165,53 @@ static int reflect101(int i, int n)
     return i;
 }
 
-/* cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) for 8U, OpenCV<=3.3:
- * float kernel -> 8-bit fixed point (cvRound(k*256)); int32 row pass; (sum+2^15)>>16 column pass. */
-static void gauss7_taps(int taps[7])
+/* cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) for 8U (reference src/ORBextractor.cc:1311).  Two OpenCV
+ * generations, same arithmetic (exact integer row pass; (sum+2^15)>>16 column pass), different 8-bit fixed-point taps:
+ *   profile 0 (OpenCV <= 3.4.1): float kernel -> cvRound(k*256), not renormalised: 18 34 49 55 49 34 18 (sum 257);
+ *   profile 1 (OpenCV >= 3.4.2 / 4.x, getGaussianKernelFixedPoint_ED): rounded from the outside in, the rounding error
+ *             carried to the next tap, centre = 256 - the rest: 18 34 48 56 48 34 18 (sum 256).
+ * Both from memory of OpenCV: parity unpinned. */
+void oracle_gaussian_taps(int profile, int taps[7])
 {
-    float cf[7];
-    double sum = 0, scale2x = -0.5 / (2.0 * 2.0);
-    for (int i = 0; i < 7; i++) {
-        double x = i - 3.0;
-        double t = exp(scale2x * x * x);
-        cf[i] = (float)t;
-        sum += cf[i];
-    }
-    sum = 1. / sum;
-    for (int i = 0; i < 7; i++) {
-        cf[i] = (float)(cf[i] * sum);
-        taps[i] = cv_round_d((double)cf[i] * 256.0);
+    double scale2x = -0.5 / (2.0 * 2.0);
+    if (profile == 0) {
+        float cf[7];
+        double sum = 0;
+        for (int i = 0; i < 7; i++) {
+            double x = i - 3.0;
+            double t = exp(scale2x * x * x);
+            cf[i] = (float)t;
+            sum += cf[i];
+        }
+        sum = 1. / sum;
+        for (int i = 0; i < 7; i++) {
+            cf[i] = (float)(cf[i] * sum);
+            taps[i] = cv_round_d((double)cf[i] * 256.0);
+        }
+    } else {
+        double k[7], sum = 0, err = 0;
+        int rest = 0;
+        for (int i = 0; i < 7; i++) { double x = i - 3.0; k[i] = exp(scale2x * x * x); sum += k[i]; }
+        for (int i = 0; i < 3; i++) {
+            double adj = k[i] / sum * 256.0 + err;
+            int v = cv_round_d(adj);
+            err = adj - v;
+            taps[i] = taps[6 - i] = v;
+            rest += 2 * v;
+        }
+        taps[3] = 256 - rest;
     }
 }
 
 void oracle_gaussian_blur7(const uint8_t *src, int w, int h, size_t sstride, uint8_t *dst, size_t dstride)
 {
+    oracle_gaussian_blur7_profile(src, w, h, sstride, dst, dstride, 0);
+}
+
+void oracle_gaussian_blur7_profile(const uint8_t *src, int w, int h, size_t sstride, uint8_t *dst, size_t dstride, int profile)
+{
     int taps[7];
-    gauss7_taps(taps);
+    oracle_gaussian_taps(profile, taps);
     int *rows = malloc(sizeof(int) * (size_t)w * h);
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
@@ -474,8 +498,16 @@ struct orb_oracle {
     float sf[MAX_LEVELS], isf[MAX_LEVELS], sig2[MAX_LEVELS], isig2[MAX_LEVELS];
     int quota[MAX_LEVELS];
     int umax[HALF_PATCH + 1];
+    int cv_profile; /* which OpenCV generation's GaussianBlur taps: oracle_set_cv_profile */
     level_t lv[MAX_LEVELS];
 };
+
+int oracle_set_cv_profile(orb_oracle *o, int profile)
+{
+    if (!o || (profile != 0 && profile != 1)) return -1;
+    o->cv_profile = profile;
+    return 0;
+}
 
 orb_oracle *oracle_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th)
 {
@@ -686,7 +718,7 @@ int oracle_extract(orb_oracle *o, const uint8_t *img, int w, int h, size_t strid
         level_t *L = &o->lv[level];
         if (L->nkp == 0) continue;
         L->blur = malloc((size_t)L->w * L->h);
-        oracle_gaussian_blur7(L->pix, L->w, L->h, L->w, L->blur, L->w);
+        oracle_gaussian_blur7_profile(L->pix, L->w, L->h, L->w, L->blur, L->w, o->cv_profile);
         for (int i = 0; i < L->nkp; i++) {
             oracle_kp *k = &kps[offset + i];
             orb_descriptor(k->angle, L->blur, L->w, oracle_cv_round_f(k->x), oracle_cv_round_f(k->y), desc + (size_t)(offset + i) * 32);

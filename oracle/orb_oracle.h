@@ -66,6 +66,10 @@ int oracle_fast_score(const uint8_t *center, int stride, int threshold); /* 0 if
 void oracle_resize_linear(const uint8_t *src, int sw, int sh, size_t sstride,
                           uint8_t *dst, int dw, int dh, size_t dstride);
 void oracle_gaussian_blur7(const uint8_t *src, int w, int h, size_t sstride, uint8_t *dst, size_t dstride);
+/* profile 0 = OpenCV <= 3.4.1 taps (the default everywhere), 1 = OpenCV >= 3.4.2 fixed-point taps */
+void oracle_gaussian_taps(int profile, int taps[7]);
+void oracle_gaussian_blur7_profile(const uint8_t *src, int w, int h, size_t sstride, uint8_t *dst, size_t dstride, int profile);
+int oracle_set_cv_profile(orb_oracle *o, int profile);
 int oracle_distribute_octtree(const int *x, const int *y, const int *resp, int n,
                               int min_x, int max_x, int min_y, int max_y, int nfeat, int *out_idx, int cap);
 

@@ -15,7 +15,6 @@
 
 __constant__ uint32_t c_pat4[256];        // x0 | y0<<8 | x1<<16 | y1<<24, signed bytes (src/ORBextractor.cc:160-418, data)
 __constant__ uint4 c_omask[64];           // IC_Angle: per lane (row, half) the byte mask of its 16-pixel window inside the circular patch
-__constant__ int c_gauss[7];              // 8-bit fixed point 7-tap sigma=2 kernel
 
 // ================================================================ K1: pyramid level (E2)
 // cv::resize INTER_LINEAR 8UC1 from level l-1 to level l.  Coefficient tables are
@@ -904,6 +903,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
 struct DescLevel { int w, h, pitch, kp_off; long long pyr_off; float scale; int patch_size; };
 struct DescArgs {
     int nlevels, kp_total;
+    unsigned gauss;                   // taps g0 | g1 << 8 | g2 << 16 | g3 << 24 of the handle's 7-tap kernel (symmetric; orbx_gaussian_taps)
     int kp_off[ORBX_MAX_LEVELS];      // first staging slot of level i; INT_MAX for i >= nlevels
     DescLevel lv[ORBX_MAX_LEVELS];
 };
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(64) void k_desc(const DescArgs da, PyrRef pr, const
     dev_sincos(angle * factor_pi, &sn, &cs);
     // ---- row pass: 4 outputs per item from 3 aligned dwords.  Output k needs bytes k .. k + 6: instead of shifting the data
     // (v_alignbyte) the TAPS are shifted -- ten constant tap words, v_dot4_u32_u8 against each dword an output touches
-    const unsigned g0 = c_gauss[0], g1 = c_gauss[1], g2 = c_gauss[2], g3 = c_gauss[3];   // symmetric: g4 = g2, g5 = g1, g6 = g0
+    const unsigned g0 = da.gauss & 0xFFu, g1 = (da.gauss >> 8) & 0xFFu, g2 = (da.gauss >> 16) & 0xFFu, g3 = da.gauss >> 24;   // symmetric: g4 = g2, g5 = g1, g6 = g0
     const unsigned TA0 = g0 | g1 << 8 | g2 << 16 | g3 << 24, TB0 = g2 | g1 << 8 | g0 << 16;
     const unsigned TA1 = g0 << 8 | g1 << 16 | g2 << 24, TB1 = g3 | g2 << 8 | g1 << 16 | g0 << 24;
     const unsigned TA2 = g0 << 16 | g1 << 24, TB2 = g2 | g3 << 8 | g2 << 16 | g1 << 24, TC2 = g0;
@@ -1411,13 +1411,49 @@ static int upload_constants(orbx_extractor *e)
         }
         ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_omask), m, sizeof m));
     }
-    // cv::getGaussianKernel(7, 2, CV_32F) -> 8-bit fixed point
-    float cf[7]; double sum = 0; const double scale2x = -0.5 / (2.0 * 2.0);
-    for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)exp(scale2x * x * x); sum += cf[i]; }
-    sum = 1. / sum;
+    return ORBX_OK;
+}
+
+// The 7-tap sigma = 2 kernel of cv::GaussianBlur(.., Size(7, 7), 2, 2, BORDER_REFLECT_101) on 8-bit images (src/ORBextractor.cc:1311)
+// as the 8-bit fixed-point integers the OpenCV generation named by `profile` filters with.  Both generations run the same
+// arithmetic around the taps -- exact integer row pass, column pass (sum + 2^15) >> 16 -- so the table IS the profile:
+//   ORBX_CV_PROFILE_3_2   (OpenCV <= 3.4.1): cvRound(k * 256) of the float kernel, not renormalised: 18 34 49 55 49 34 18 (sum 257)
+//   ORBX_CV_PROFILE_3_4_2 (OpenCV >= 3.4.2 / 4.x, the bit-exact fixed-point path): rounded from the outside in with the
+//                          rounding error carried along, centre = 256 - the rest: 18 34 48 56 48 34 18 (sum 256)
+// (both restated from memory of OpenCV -- parity unpinned).
+extern "C" int orbx_gaussian_taps(int profile, int taps[7])
+{
+    if (!taps || (profile != ORBX_CV_PROFILE_3_2 && profile != ORBX_CV_PROFILE_3_4_2)) { orbx_set_error("orbx_gaussian_taps: unknown profile %d", profile); return ORBX_E_INVALID; }
+    const double scale2x = -0.5 / (2.0 * 2.0);
+    if (profile == ORBX_CV_PROFILE_3_2) {
+        float cf[7]; double sum = 0;
+        for (int i = 0; i < 7; i++) { const double x = i - 3.0; cf[i] = (float)exp(scale2x * x * x); sum += cf[i]; }
+        sum = 1. / sum;
+        for (int i = 0; i < 7; i++) { cf[i] = (float)(cf[i] * sum); taps[i] = (int)lrint((double)cf[i] * 256.0); }
+    } else {
+        double k[7], sum = 0, err = 0;
+        for (int i = 0; i < 7; i++) { const double x = i - 3.0; k[i] = exp(scale2x * x * x); sum += k[i]; }
+        int rest = 0;
+        for (int i = 0; i < 3; i++) {
+            const double adj = k[i] / sum * 256.0 + err;
+            const int v = (int)lrint(adj);
+            err = adj - v;
+            taps[i] = taps[6 - i] = v;
+            rest += 2 * v;
+        }
+        taps[3] = 256 - rest;
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extractor_set_cv_profile(orbx_extractor *e, int profile)
+{
+    if (!e) { orbx_set_error("null extractor"); return ORBX_E_INVALID; }
     int taps[7];
-    for (int i = 0; i < 7; i++) { cf[i] = (float)(cf[i] * sum); taps[i] = (int)lrint((double)cf[i] * 256.0); }
-    ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), taps, sizeof taps));
+    const int rc = orbx_gaussian_taps(profile, taps);
+    if (rc) return rc;
+    for (int i = 0; i < 4; i++) e->gauss[i] = taps[i];   // launch constants of k_desc: later launches use them, earlier ones keep theirs
+    e->cv_profile = profile;
     return ORBX_OK;
 }
 
@@ -1439,6 +1475,7 @@ extern "C" int orbx_extractor_create(orbx_extractor **out, int nfeatures, float 
     ORBX_HIP(hipSetDevice(device));
     orbx_extractor *e = new orbx_extractor();
     e->prof_mask = ~0u;
+    orbx_extractor_set_cv_profile(e, ORBX_CV_PROFILE_3_2);   // the OpenCV the reference was tested with (README.md:68)
     e->device = device; e->nfeatures = nfeatures; e->nlevels = nlevels; e->ini_th = ini_th; e->min_th = min_th;
     e->scale_factor = scale_factor; e->max_w = max_w; e->max_h = max_h; e->max_batch = max_batch;
     // src/ORBextractor.cc:436-461
@@ -1479,6 +1516,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *e)
     if (e->stream) hipStreamSynchronize(e->stream);
     for (auto &ev : e->prof_ev) { if (ev.owns_a && ev.a) hipEventDestroy(ev.a); if (ev.b) hipEventDestroy(ev.b); }
     for (auto ev : e->prof_pool) hipEventDestroy(ev);
+    if (e->ev_switch) hipEventDestroy(e->ev_switch);
     void *ptrs[] = { e->d_cand_prim, e->d_tree_tab, e->d_cells, e->d_geom, e->d_tabs, e->d_pyr, e->d_stage_in, e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid,
                      e->d_lvl_cnt, e->d_lvl_kp, e->d_out_kps, e->d_out_desc, e->d_out_n, e->d_out_ur, e->d_out_depth, e->d_st_dist, e->d_st_entries };
     for (void *p : ptrs) if (p) hipFree(p);
@@ -1536,6 +1574,19 @@ extern "C" int orbx_max_keypoints(const orbx_extractor *e, int w, int h)
     return total;
 }
 
+static_assert((ORBX_PIPE_DEPTH & (ORBX_PIPE_DEPTH - 1)) == 0, "tickets wrap at 2^31: the depth must divide it");
+
+int orbx_use_stream(orbx_extractor *e, hipStream_t s)
+{
+    if (e->last_launch_stream && e->last_launch_stream != s) {
+        if (!e->ev_switch) ORBX_HIP(hipEventCreateWithFlags(&e->ev_switch, hipEventDisableTiming));
+        ORBX_HIP(hipEventRecord(e->ev_switch, e->last_launch_stream));
+        ORBX_HIP(hipStreamWaitEvent(s, e->ev_switch, 0));
+    }
+    e->last_launch_stream = s;
+    return ORBX_OK;
+}
+
 extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, size_t img_stride, size_t pitch,
                                          int batch, int w, int h, void *d_kps, void *d_desc, int cap, void *d_n_out,
                                          void *stream)
@@ -1554,7 +1605,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
         return ORBX_E_CAPACITY;
     }
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-    e->last_launch_stream = s;
+    if ((rc = orbx_use_stream(e, s))) return rc;
     PyrRef pr;
     pr.img0 = (const uint8_t *)d_imgs; pr.img0_stride = (long long)img_stride; pr.img0_pitch = (int)pitch;
     pr.pyr = e->d_pyr; pr.pyr_stride = G.pyr_bytes;
@@ -1608,6 +1659,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
     DescArgs da;
     memset(&da, 0, sizeof da);
     da.nlevels = G.nlevels; da.kp_total = G.kp_total;
+    da.gauss = (unsigned)e->gauss[0] | (unsigned)e->gauss[1] << 8 | (unsigned)e->gauss[2] << 16 | (unsigned)e->gauss[3] << 24;
     for (int i = 0; i < ORBX_MAX_LEVELS; i++) {
         da.kp_off[i] = i < G.nlevels ? G.lv[i].kp_off : INT_MAX;
         if (i < G.nlevels) {
@@ -2003,8 +2055,10 @@ static int pipe_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t
         ORBX_HIP(hipMemcpyAsync(s.h_out + o_z, s.d_z, 4 * (size_t)need, hipMemcpyDeviceToHost, e->copy_out));
     }
     ORBX_HIP(hipEventRecord(s.ev_d2h, e->copy_out));
-    s.busy = true; s.cap = need; s.ticket = e->pipe_next; s.eyes = eyes;
-    *ticket = e->pipe_next++;
+    // tickets are the low 31 bits of an unsigned submit counter: never negative, and (the depth divides 2^31) still congruent to the slot
+    s.busy = true; s.cap = need; s.ticket = (int)(e->pipe_next & 0x7FFFFFFFu); s.eyes = eyes;
+    *ticket = s.ticket;
+    e->pipe_next++;
     return ORBX_OK;
 }
 

@@ -83,9 +83,11 @@ struct orbx_extractor {
     float sf[ORBX_MAX_LEVELS], isf[ORBX_MAX_LEVELS], sig2[ORBX_MAX_LEVELS], isig2[ORBX_MAX_LEVELS];
     int quota[ORBX_MAX_LEVELS];
     int umax[16];
+    int cv_profile, gauss[4];        // OpenCV generation whose GaussianBlur taps k_desc filters with (orbx_extractor_set_cv_profile)
 
     hipStream_t stream;
     hipStream_t last_launch_stream;  // stream of the most recent kernel launches on this handle's workspaces (caller's or `stream`)
+    hipEvent_t ev_switch;            // orders a launch on a new stream behind the work of the previous one (orbx_use_stream)
     // geometry of the current image size
     Geom geom;           // host copy (geom.w == 0: none yet)
     Geom *d_geom;        // device copy
@@ -113,7 +115,7 @@ struct orbx_extractor {
     void *d_st_entries; size_t st_ent_cap;  // row table entries (vRowIndices): (iR | octave<<16, x)
     void *scratch[8]; size_t scratch_cap[8]; // host-API upload buffers
     // pipelined stereo frames: copies ride their own streams so that frame i+1 uploads and frame i-1 downloads while frame i computes
-    PipeSlot pipe[ORBX_PIPE_DEPTH]; hipStream_t copy_in, copy_out; int pipe_next;
+    PipeSlot pipe[ORBX_PIPE_DEPTH]; hipStream_t copy_in, copy_out; unsigned pipe_next;
     // state of the most recent extract
     const uint8_t *last_img0; size_t last_img_stride, last_pitch; int last_batch;
     // profiling
@@ -171,6 +173,9 @@ int orbx_scratch(orbx_extractor *e, int slot, size_t bytes, void **out);
 // launches): called before any geometry rebuild or workspace reallocation, so tables are never rewritten and buffers
 // never freed under running kernels
 int orbx_quiesce(orbx_extractor *e);
+// the handle's workspaces are about to be used by launches on stream s: if the previous launches went to another stream, s first
+// waits for them (an event, no host synchronisation); records s as the handle's stream
+int orbx_use_stream(orbx_extractor *e, hipStream_t s);
 
 // level-0 / level-l pixel pointer of image b (device side helper)
 struct PyrRef {

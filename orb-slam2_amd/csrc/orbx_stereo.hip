@@ -356,7 +356,7 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
     pl.pyr = L->d_pyr; pl.pyr_stride = L->geom.pyr_bytes;
     pr.img0 = R->last_img0; pr.img0_stride = (long long)R->last_img_stride; pr.img0_pitch = (int)R->last_pitch;
     pr.pyr = R->d_pyr; pr.pyr_stride = R->geom.pyr_bytes;
-    L->last_launch_stream = s;
+    { int urc = orbx_use_stream(L, s); if (urc) return urc; if (R != L && (urc = orbx_use_stream(R, s))) return urc; }
     const float max_d = bf / min_z; // src/Frame.cc:609
     orbx_prof_begin(L, ORBX_STAGE_STEREO, s);
     hipLaunchKernelGGL(k_stereo_prep, dim3(batch), dim3(256), (size_t)2 * ((rows + 4) & ~3) * sizeof(int), s, L->d_geom,

@@ -58,6 +58,8 @@ def lib():
     L.orbx_last_error.restype = C.c_char_p
     L.orbx_device_count.restype = i
     L.orbx_extractor_create.argtypes = [C.POINTER(vp), i, f, i, i, i, i, i, i, i]
+    L.orbx_extractor_set_cv_profile.argtypes = [vp, i]
+    L.orbx_gaussian_taps.argtypes = [i, vp]
     L.orbx_extractor_destroy.argtypes = [vp]
     L.orbx_extractor_destroy.restype = None
     L.orbx_get_levels.argtypes = [vp]
@@ -157,12 +159,17 @@ def pinned_array(shape, dtype=np.uint8):
     nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
     owner = _Pinned(nbytes)
     buf = (C.c_uint8 * nbytes).from_address(owner.ptr)
-    a = np.frombuffer(buf, dtype=dtype).reshape(shape)
-    _PINNED_OWNERS[id(buf)] = owner      # keep the allocation alive as long as the process (frame buffers are long-lived)
-    return a
+    buf._orbx_owner = owner              # the ctypes buffer is the base object of every view: the pages are freed with the last of them
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
-_PINNED_OWNERS = {}
+CV_PROFILE_3_2, CV_PROFILE_3_4_2 = 0, 1
+
+
+def gaussian_taps(profile):
+    t = np.zeros(7, np.int32)
+    _check(lib().orbx_gaussian_taps(profile, _p(t)))
+    return t
 
 
 def debug_set_bow_form(form):
@@ -213,6 +220,7 @@ class ORBextractor:
         self._L = lib()
         self._h = C.c_void_p()
         self.nfeatures, self.nlevels, self.max_batch, self.device = nfeatures, nlevels, max_batch, device
+        self._pipe_shapes, self._pipe_last = {}, (max_size[0], max_size[1])   # image sizes of the tickets in flight (pipelined forms)
         _check(self._L.orbx_extractor_create(C.byref(self._h), nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST,
                                              device, max_size[0], max_size[1], max_batch))
 
@@ -223,6 +231,10 @@ class ORBextractor:
             self._h = None
 
     # -- getters (include/ORBextractor.h:78-98)
+    def set_cv_profile(self, profile):
+        """which OpenCV generation's GaussianBlur the descriptors are computed on: CV_PROFILE_3_2 (default) or CV_PROFILE_3_4_2"""
+        _check(self._L.orbx_extractor_set_cv_profile(self._h, profile))
+
     def GetLevels(self): return self._L.orbx_get_levels(self._h)
     def GetScaleFactor(self): return self._L.orbx_get_scale_factor(self._h)
 
@@ -282,7 +294,7 @@ class ORBextractor:
         h, w = image.shape
         t = C.c_int()
         _check(self._L.orbx_extract_submit(self._h, image.ctypes.data, w, h, image.strides[0], C.byref(t)))
-        self._pipe_shapes = getattr(self, "_pipe_shapes", {}); self._pipe_shapes[t.value] = (w, h); self._pipe_last = (w, h)
+        self._pipe_shapes[t.value] = (w, h); self._pipe_last = (w, h)
         return t.value
 
     def extract_wait(self, ticket):
@@ -300,11 +312,11 @@ class ORBextractor:
         h, w = imLeft.shape
         t = C.c_int()
         _check(self._L.orbx_extract_stereo_submit(self._h, imLeft.ctypes.data, imRight.ctypes.data, w, h, imLeft.strides[0], bf, min_z, C.byref(t)))
-        self._pipe_shapes = getattr(self, "_pipe_shapes", {}); self._pipe_shapes[t.value] = (w, h); self._pipe_last = (w, h)
+        self._pipe_shapes[t.value] = (w, h); self._pipe_last = (w, h)
         return t.value
 
     def extract_stereo_wait(self, ticket, copy=True):
-        w, h = self._pipe_shapes.get(ticket, self._pipe_last)
+        w, h = self._pipe_shapes.pop(ticket, self._pipe_last)       # an unknown ticket is the library's error to report
         cap = self.max_keypoints(w, h)
         b = getattr(self, "_pipe_out", None)
         if b is None or b[0].shape[1] != cap:
@@ -312,7 +324,6 @@ class ORBextractor:
                                   np.zeros(cap, np.float32), np.zeros(cap, np.float32))
         kps, desc, n, ur, z = b
         _check(self._L.orbx_extract_stereo_wait(self._h, ticket, _p(kps), _p(desc), cap, _p(n), _p(ur), _p(z)))
-        self._pipe_shapes.pop(ticket, None)
         if not copy:      # views into buffers that the next wait overwrites (measurement loops)
             return kps[0, :n[0]], desc[0, :n[0]], kps[1, :n[1]], desc[1, :n[1]], ur[:n[0]], z[:n[0]]
         return (kps[0, :n[0]].copy(), desc[0, :n[0]].copy(), kps[1, :n[1]].copy(), desc[1, :n[1]].copy(), ur[:n[0]].copy(), z[:n[0]].copy())
@@ -467,8 +478,8 @@ class DeviceKeyFrame:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
-            lib().orbx_kf_destroy(h)
+        if h and _lib is not None:
+            _lib.orbx_kf_destroy(h)
             self._h = None
 
 

@@ -46,6 +46,23 @@ def _check_stages(ex, orc, img, tag):
     return kps, desc
 
 
+def test_cv_profile_3_4_2(pkg, oracle):
+    """the GaussianBlur taps of OpenCV >= 3.4.2 (orbx_extractor_set_cv_profile): same keypoints, other descriptors, and still the
+    oracle's byte for byte; switching back restores the 3.2 descriptors"""
+    img = synth.image(6, 640, 480)
+    ex = _extractor(pkg, 1000, 640, 480)
+    orc = oracle.Oracle(1000, 1.2, 8, 20, 7)
+    k0, d0 = _check_stages(ex, orc, img, "profile 3.2")
+    ex.set_cv_profile(pkg.orbx.CV_PROFILE_3_4_2); orc.set_cv_profile(1)
+    k1, d1 = _check_stages(ex, orc, img, "profile 3.4.2")
+    assert k0.tobytes() == k1.tobytes() and (d0 != d1).any(axis=1).sum() > 100
+    ex.set_cv_profile(pkg.orbx.CV_PROFILE_3_2); orc.set_cv_profile(0)
+    k2, d2 = _check_stages(ex, orc, img, "profile 3.2 again")
+    assert d2.tobytes() == d0.tobytes()
+    with pytest.raises(pkg.OrbxError):
+        ex.set_cv_profile(7)
+
+
 @pytest.mark.parametrize("w,h,nf,seed", [(320, 240, 500, 1), (640, 480, 1000, 2), (752, 480, 1000, 3), (1241, 376, 2000, 4)])
 def test_extract_stage_parity(pkg, oracle, w, h, nf, seed):
     img = synth.image(seed, w, h)

@@ -111,6 +111,30 @@ def test_gaussian_taps(oracle):
     assert (out2 == 255).all()
 
 
+def test_gaussian_taps_both_opencv_profiles(oracle, pkg):
+    """the 7 taps are one table per OpenCV generation, and the product's table is the oracle's.  Profile 0 =
+    OpenCV <= 3.4.1 (cvRound(k * 256), sum 257), profile 1 = OpenCV >= 3.4.2 (error-diffused, sums to exactly 256)."""
+    t0, t1 = np.array([18, 34, 49, 55, 49, 34, 18]), np.array([18, 34, 48, 56, 48, 34, 18])
+    assert (oracle.gaussian_taps(0) == t0).all() and (oracle.gaussian_taps(1) == t1).all()
+    assert (pkg.orbx.gaussian_taps(pkg.orbx.CV_PROFILE_3_2) == t0).all() and (pkg.orbx.gaussian_taps(pkg.orbx.CV_PROFILE_3_4_2) == t1).all()
+    assert t1.sum() == 256
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (24, 30), dtype=np.uint8)
+    outs = []
+    for prof, taps in ((0, t0), (1, t1)):
+        out = np.zeros_like(img)
+        oracle.lib().oracle_gaussian_blur7_profile(img.ctypes.data, 30, 24, 30, out.ctypes.data, 30, prof)
+        pad = np.pad(img.astype(np.int64), 3, mode="reflect")
+        rows = sum(int(taps[k]) * pad[:, k:k + 30] for k in range(7))
+        full = sum(int(taps[k]) * rows[k:k + 24, :] for k in range(7))
+        assert (out == np.minimum((full + (1 << 15)) >> 16, 255)).all()
+        outs.append(out)
+    assert (outs[0] != outs[1]).any()      # the two generations do blur differently
+    flat = np.full((16, 16), 200, np.uint8); o1 = np.zeros_like(flat)
+    oracle.lib().oracle_gaussian_blur7_profile(flat.ctypes.data, 16, 16, 16, o1.ctypes.data, 16, 1)
+    assert (o1 == 200).all()               # a kernel that sums to 256 keeps a flat image (the 257 one brightens it: 200 -> 201)
+
+
 def test_blur_reflect101(oracle):
     rng = np.random.default_rng(3)
     img = rng.integers(0, 256, (24, 30), dtype=np.uint8)
