@@ -25,9 +25,20 @@ Outside the timed region the headline run also (rank 0 / every rank as noted):
     stream overlapped with compute on two handles -> D2H of all results; `single_stream_c_abi` = one camera stream through
     orbx_extract_stereo_submit / _wait from a plain C client (examples/stereo_stream.c).  The headline `value` excludes PCIe;
   * times the KITTI 2000-feature workload (BASELINE configs 2 / 5) on every rank with its own barrier-aligned window ->
-    config.kitti2000_frames_per_s (whole-job aggregate), so that an N-GPU line also carries BASELINE config 5.
+    config.kitti2000_frames_per_s (whole-job aggregate), so that an N-GPU line also carries BASELINE config 5;
+  * runs short legs of the other BASELINE configs in the same process (N = 1, rank 0) -> config.other_configs: `tum640`
+    (config 1: 640x480 mono @1000, CPU oracle beside the GPU rate), `euroc_bow` (config 3), `fhd4000` (config 4) and
+    `euroc_track` (extract + ComputeBoW + SearchByBoW(previous keyframe, frame)), each with its own `verified`
+    block (every frame of its last step against the oracle; BoW: 64 keyframes x 4 frames of the search rows) and a
+    CPU-oracle figure on one thread (mono: src/Frame.cc:205 runs one extraction);
+  * times the three north-star matchers per call next to the CPU oracle -> config.matchers (tools/matcher_bench.py).
+`roofline.traffic` and `roofline.issue` come from committed rocprofv3 counter files (profiles/*_traffic.json, *_sq_counters.json),
+not from this run: each is stamped with its source file and the hash of the kernel sources it was collected on, and nulled /
+marked stale when orb-slam2_amd/csrc has changed since.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -46,6 +57,8 @@ WORKLOADS = {
     "stereo2000": (1241, 376, 2000, "stereo", 128, "frames/sec ORB extract + L/R stereo match, KITTI 1241x376 @2000 feats (BASELINE config 2)"),
     "euroc_bow": (752, 480, 1000, "bow", 32, "frames/sec ORB extract + SearchByBoW vs 500-KF map, EuRoC 752x480 @1000 feats (BASELINE config 3)"),
     "fhd4000": (1920, 1080, 4000, "mono", 64, "frames/sec ORB extract, 1920x1080 @4000 feats (BASELINE config 4)"),
+    "tum640": (640, 480, 1000, "mono", 256, "frames/sec ORB extract, TUM 640x480 mono @1000 feats (BASELINE config 1)"),
+    "euroc_track": (752, 480, 1000, "bow", 64, "frames/sec ORB extract + ComputeBoW + SearchByBoW(previous keyframe, frame), EuRoC 752x480 @1000 feats (SURVEY 8d)"),
 }
 BF, FX = 386.1448, 718.856          # reference Examples/Stereo/KITTI00-02.yaml:8,25
 MIN_Z = BF / FX                     # mb = mbf/fx (src/Frame.cc:118)
@@ -116,34 +129,68 @@ def cpu_baseline(frames, all_core_frames=4):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))      # the share of host cores one GPU gets on the bench box
-    done = [0] * cores
+    cores = max(1, cores)               # every core the process may run on (one stream per core, core count stated)
 
-    def stream(ci):
-        a, b = oracle_py.Oracle(NFEAT, 1.2, NLEVELS, 20, 7), oracle_py.Oracle(NFEAT, 1.2, NLEVELS, 20, 7)
-        for i in range(all_core_frames):
-            left, right = frames[(ci + i) % len(frames)]
-            kl, dl = a.extract(left); kr, dr = b.extract(right)
-            oracle_py.stereo_match(a, b, kl, dl, kr, dr, BF, MIN_Z)
-            done[ci] += 1
-    ths = [threading.Thread(target=stream, args=(ci,)) for ci in range(cores)]
-    t0 = time.perf_counter()
-    for t in ths: t.start()
-    for t in ths: t.join()
-    el = time.perf_counter() - t0
-    out["all_cores"] = {"value": round(sum(done) / el, 2), "unit": "frames/s", "cores": cores,
-                        "sample": f"{cores} independent streams (one per available core, threads in the C oracle), {all_core_frames} stereo frames each"}
+    def run_streams(nthreads):
+        done = [0] * nthreads
+
+        def stream(ci):
+            a, b = oracle_py.Oracle(NFEAT, 1.2, NLEVELS, 20, 7), oracle_py.Oracle(NFEAT, 1.2, NLEVELS, 20, 7)
+            for i in range(all_core_frames):
+                left, right = frames[(ci + i) % len(frames)]
+                kl, dl = a.extract(left); kr, dr = b.extract(right)
+                oracle_py.stereo_match(a, b, kl, dl, kr, dr, BF, MIN_Z)
+                done[ci] += 1
+        ths = [threading.Thread(target=stream, args=(ci,)) for ci in range(nthreads)]
+        t0 = time.perf_counter()
+        for t in ths: t.start()
+        for t in ths: t.join()
+        return round(sum(done) / (time.perf_counter() - t0), 2)
+    # one stream per core the affinity mask names; a container may grant fewer core-seconds than the mask suggests (a one-GPU box
+    # of the pool: 256 in the mask), so smaller thread counts are tried too and the best is the figure
+    sweep = {str(n): run_streams(n) for n in sorted({cores, min(cores, 64), min(cores, 16)})}
+    best = max(sweep, key=sweep.get)
+    out["all_cores"] = {"value": sweep[best], "unit": "frames/s", "cores": int(best), "affinity_cores": cores, "frames_per_s_by_threads": sweep,
+                        "sample": f"independent streams, one thread each in the C oracle (every core of the affinity mask, and 64 / 16 threads), {all_core_frames} stereo frames per stream; value = the best"}
     return out
 
 
-def load_issue_model():
-    """measured VALU wave-instructions per image of every kernel (rocprofv3 SQ_INSTS_VALU, tools/collect_sq.py) and the
-    issue-rate model of DESIGN.md section 5: 1024 SIMDs, mix-weighted cycles per wave64 VALU instruction from
-    tools/ubench/op_cost.hip (full-rate opcodes ~2.5 cycles, the rest ~4.3)"""
-    path = os.path.join(ROOT, "profiles", "r02_sq_counters.json")
-    if not os.path.exists(path):
-        return None
-    return json.load(open(path))
+def cpu_baseline_mono(images, bow=None):
+    """the CPU oracle on one thread (the reference extracts a monocular frame on the calling thread, src/Frame.cc:205); with
+    `bow`: + Frame::ComputeBoW + SearchByBoW against every keyframe of the map (oracle vocabulary / matcher)"""
+    from oracle import oracle_py
+    o = oracle_py.Oracle(NFEAT, 1.2, NLEVELS, 20, 7)
+    times = []
+    for img in images:
+        t0 = time.perf_counter()
+        k, d = o.extract(img)
+        if bow is not None:
+            t = bow["ovoc"].transform(d, 4)
+            q = dict(desc=d, node_id=t["fv_node_id"], node_off=t["fv_node_off"], feat=t["fv_feat"], flag=np.zeros(len(d), np.uint8), angle=k["angle"].copy())
+            for kf in bow["kfs"]:
+                oracle_py.search_by_bow_kf_f(kf, q, 0.75, True)
+        times.append(time.perf_counter() - t0)
+    times = np.array(times)
+    what = "extract" if bow is None else f"extract + ComputeBoW + SearchByBoW against {len(bow['kfs'])} keyframes"
+    return {"value": round(float(len(times) / times.sum()), 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{len(times)} frames {W}x{H} @{NFEAT} feats, {what}, through oracle/liborb_oracle.so on one thread, median {np.median(times) * 1e3:.1f} ms/frame",
+            "host_cpus": os.cpu_count()}
+
+
+def csrc_sha():
+    """hash of the kernel sources: counter files under profiles/ say which sources they were collected on"""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "orb-slam2_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def newest_profile(pattern):
+    """newest committed counter file profiles/r??_<pattern> (by round tag) -> (path relative to the repo, document) or (None, None)"""
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + pattern)))
+    if not fs:
+        return None, None
+    return os.path.relpath(fs[-1], ROOT), json.load(open(fs[-1]))
 
 
 class StereoRig:
@@ -252,43 +299,13 @@ def host_fed_c_client(streams, frames=1500):
         return {"error": str(exc)[:200]}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (0 = the workload's default)")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="stereo1000",
-                    help="stereo1000 is the BASELINE.json headline metric; the others are the remaining single-GPU configs")
-    ap.add_argument("--cpu-frames", type=int, default=240, help="frames of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--bow-host-path", action="store_true", help="euroc_bow: per-frame host-pointer ComputeBoW + search (round-1 form)")
-    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs (tiled to the batch)")
-    ap.add_argument("--extras", type=int, default=1, help="0 = only the timed headline region (profiling runs): no batch sweep, host-fed or KITTI-2000 legs")
-    ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of the last step's outputs")
-    args = ap.parse_args()
+def run_workload(ctx, args):
+    """one workload: warm-up, stage breakdown, timed region, verification, roofline -> the dict of its JSON line"""
     global W, H, NFEAT
     W, H, NFEAT, kind, def_batch, metric = WORKLOADS[args.workload]
     if args.batch <= 0:
         args.batch = def_batch
-
-    import torch
-    import torch.distributed as dist
-    import __graft_entry__ as ge
-
-    pkg = ge.load_pkg()
-    st = pkg.streams
-    # ORBX_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices)
-    backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    if backend != "nccl":
-        local %= max(torch.cuda.device_count(), 1)
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    rank, world = st.init(backend, device_id=dev if backend == "nccl" else None)   # "nccl" is RCCL on ROCm; no-op for a single process
-    assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
-    dist_dev = dev if backend == "nccl" else None
-
-    pkg.lib()  # fails loudly if liborbx.so is missing: there is no fallback path
+    torch, pkg, st, dev, local, rank, world, dist_dev = (ctx[k] for k in ("torch", "pkg", "st", "dev", "local", "rank", "world", "dist_dev"))
     from tools import synth
 
     B = args.batch
@@ -321,7 +338,8 @@ def main():
     def extract():
         ex.extract_batch_device(imgs.data_ptr(), H * pitch, pitch, NI, W, H, kps.data_ptr(), desc.data_ptr(), cap, nout.data_ptr(), sp)
 
-    bow = None
+    bow, bow_cpu = None, None
+    NKF = args.keyframes if args.keyframes > 0 else (1 if args.workload == "euroc_track" else 500)
     if kind == "bow":
         # BASELINE config 3: 500-keyframe synthetic map: keyframe descriptors = frame descriptors
         # with Bernoulli(0.08) bit flips, shuffled; hasGoodMP ~ Bernoulli(0.6); FeatureVector from a seeded
@@ -346,7 +364,7 @@ def main():
                                   flag=np.zeros(len(dd), np.uint8), angle=kp["angle"].copy()))
         kfs = []
         base = frames_fs[0]
-        for _ in range(500):
+        for _ in range(NKF):
             perm = rng.permutation(len(base["desc"]))
             dk = synth.flip_bits(rng, base["desc"], 0.08)[perm]
             t = voc.transform(dk, 4)
@@ -354,7 +372,8 @@ def main():
                             flag=(rng.random(len(dk)) < 0.6).astype(np.uint8), angle=base["angle"][perm]))
         bow = {"db": pkg.BowDatabase(kfs, device=local), "voc": voc, "frames": frames_fs, "ms": 0.0, "tms": 0.0, "queries": 0, "matches": 0,
                "fr": pkg.BowFrames(NI, cap, device=local),
-               "d_match": torch.zeros((NI, 500, cap), dtype=torch.int32, device=dev), "d_nm": torch.zeros((NI, 500), dtype=torch.int32, device=dev),
+               "d_match": torch.zeros((NI, NKF, cap), dtype=torch.int32, device=dev), "d_nm": torch.zeros((NI, NKF), dtype=torch.int32, device=dev),
+               "kfs": kfs, "vocab_arrays": (par, leaf, nd, wt),
                "ev": [], "host_path": args.bow_host_path, "kf_feats": int(sum(len(k_["desc"]) for k_ in kfs)),
                "kf_list": int(sum(len(k_["feat"]) for k_ in kfs)), "kf_nodes": int(sum(len(k_["node_id"]) for k_ in kfs))}
 
@@ -432,6 +451,41 @@ def main():
         expect = oracle_results(pairs)
         verified = rig.verify(expect, len(pairs))
 
+    if not stereo and rank == 0 and not args.no_verify:
+        # every frame of the batch against the oracle's extraction of its image; BoW: + the search rows of up to 64 keyframes x 4
+        # frames against the oracle's ComputeBoW + SearchByBoW (the keyframes' FeatureVectors re-derived by the oracle too)
+        from oracle import oracle_py
+        orc = oracle_py.Oracle(NFEAT, 1.2, NLEVELS, 20, 7)
+        ref = [orc.extract(m) for m in monos]
+        k_all = kps.cpu().numpy().view(np.uint8).reshape(NI, cap, 28); d_all = desc.cpu().numpy()
+        badf = [i for i in range(B) if not (int(n_h[i]) == len(ref[i % len(monos)][0]) and
+                                            k_all[i, :n_h[i]].tobytes() == ref[i % len(monos)][0].tobytes() and
+                                            d_all[i, :n_h[i]].tobytes() == ref[i % len(monos)][1].tobytes())]
+        verified = {"frames": B, "distinct_images": len(monos), "checked": "keypoints (28 B each) and descriptors of every frame of the last step",
+                    "against": "oracle/liborb_oracle.so", "bit_exact": not badf, "mismatching_frames": badf[:8]}
+        if bow is not None:
+            par, leaf, nd, wt = bow["vocab_arrays"]
+            ovoc = oracle_py.Vocabulary(10, 6, par, leaf, nd, wt)
+            bow_cpu = {"ovoc": ovoc, "kfs": bow["kfs"]}
+            if not bow["host_path"]:
+                nkc, nfc = min(NKF, 64), min(B, 4)
+                dm = bow["d_match"][:nfc, :nkc].cpu().numpy(); dn = bow["d_nm"][:nfc, :nkc].cpu().numpy()
+                badp = []
+                for f in range(nfc):
+                    ok_, od_ = ref[f % len(monos)]
+                    t = ovoc.transform(od_, 4)
+                    q = dict(desc=od_, node_id=t["fv_node_id"], node_off=t["fv_node_off"], feat=t["fv_feat"], flag=np.zeros(len(od_), np.uint8), angle=ok_["angle"].copy())
+                    for kq in range(nkc):
+                        kf = bow["kfs"][kq]
+                        tk = ovoc.transform(kf["desc"], 4)
+                        same_fv = (np.array_equal(tk["fv_node_id"], kf["node_id"]) and np.array_equal(tk["fv_node_off"], kf["node_off"]) and np.array_equal(tk["fv_feat"], kf["feat"]))
+                        exp, en = oracle_py.search_by_bow_kf_f(kf, q, 0.75, True)
+                        if not (same_fv and en == int(dn[f, kq]) and np.array_equal(dm[f, kq, :len(exp)], exp)):
+                            badp.append((f, kq))
+                verified["bow"] = {"pairs_checked": nfc * nkc, "what": f"search rows of keyframes 0..{nkc - 1} x frames 0..{nfc - 1} of the last launch, and those keyframes' FeatureVectors, "
+                                                                      "against oracle ComputeBoW + SearchByBoW", "mismatching_pairs": badp[:8]}
+                verified["bit_exact"] = verified["bit_exact"] and not badp
+
     # dominant kernel + roofline (per launch: total stage time / launches; resize = 7 launches per step)
     stage_ms = {k: v[0] for k, v in prof.items()}     # timed region: only the dominant stage has events
     dom = dom_stage
@@ -453,23 +507,25 @@ def main():
             # `per_pair_model_bytes` for comparison.
             frame_side = B * nkp_avg * (32 + 1 + 4 + 4) + B * 100 * 8
             map_side = bow["kf_list"] * 33 + bow["kf_nodes"] * 8 + bow["kf_feats"] * 4
-            bytes_per_launch = map_side + frame_side + 500 * B * 4 * nkp_avg
-            bow_models = {"compulsory_bytes": int(bytes_per_launch), "of_which_match_rows_out": int(500 * B * 4 * nkp_avg),
-                          "per_pair_model_bytes": int(500 * B * (32 + 4 + 1 + 4) * 2 * nkp_avg + 500 * B * 4 * nkp_avg)}
+            bytes_per_launch = map_side + frame_side + NKF * B * 4 * nkp_avg
+            bow_models = {"compulsory_bytes": int(bytes_per_launch), "of_which_match_rows_out": int(NKF * B * 4 * nkp_avg),
+                          "per_pair_model_bytes": int(NKF * B * (32 + 4 + 1 + 4) * 2 * nkp_avg + NKF * B * 4 * nkp_avg)}
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None   # HBM bytes per launch from the rocprofv3 PMC passes (tools/collect_pmc.py), same workload only
-    for tname in ("r02_traffic.json", "r01_traffic.json"):
-        tpath = os.path.join(ROOT, "profiles", tname if args.workload == "stereo1000" else tname.replace("traffic", "traffic_" + args.workload))
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            kern = tj.get("kernels", {}).get("k_" + dom.split("<")[0])
-            if kern and tj.get("images_per_launch"):
-                traffic = int(kern["hbm_bytes_per_launch"] * NI / tj["images_per_launch"])
-            break
+    # HBM bytes per launch from the rocprofv3 PMC passes (tools/collect_pmc.py): a committed file, not this run -- stamped with its
+    # source and nulled when the kernel sources have changed since it was collected
+    traffic, traffic_src = None, None
+    sha_now = csrc_sha()
+    tpath, tj = newest_profile("traffic.json" if args.workload == "stereo1000" else "traffic_" + args.workload + ".json")
+    if tj:
+        kern = tj.get("kernels", {}).get("k_" + dom.split("<")[0])
+        fresh = tj.get("csrc_sha") == sha_now
+        traffic_src = f"{tpath}@csrc {tj.get('csrc_sha', 'unstamped')}" + ("" if fresh else f" -- STALE (sources now {sha_now}): not reported")
+        if kern and tj.get("images_per_launch") and fresh:
+            traffic = int(kern["hbm_bytes_per_launch"] * NI / tj["images_per_launch"])
     step_ms = {k: round(v, 4) for k, v in stage_all_ms.items()}
     step_ms[dom_stage] = round(stage_ms[dom_stage] / args.steps, 4)
     roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "stage_ms_per_step": step_ms,
                 "stage_ms_source": f"{dom_stage}: HIP events inside the timed region; other stages: {n_prof} untimed steps with events at every stage boundary"}
@@ -478,30 +534,37 @@ def main():
                                       for k, v in step_ms.items() if v > 0}
     if bow_models:
         roofline["byte_models"] = bow_models
-    im = load_issue_model()
+    ipath, im = newest_profile("sq_counters.json")
     if im and args.workload == "stereo1000" and ("k_" + dom) in im.get("kernels", {}):
         kk = im["kernels"]["k_" + dom]
-        per_image = kk["SQ_INSTS_VALU"] / im["images_per_launch"]
-        valu = per_image * NI / per_step_launches
-        cyc = im["issue_model"]["cycles_per_valu_inst"]["k_" + dom]
-        peak = im["issue_model"]["simds"] * im["issue_model"]["clock_ghz"] * 1e9 / cyc
-        roofline["issue"] = {"valu_insts": int(valu), "cycles_per_valu_inst": cyc, "peak_wave_insts_per_s": round(peak, 0),
-                             "frac": round(valu / (avg_ms * 1e-3) / peak, 4),
-                             "note": "wave64 VALU instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/r02_sq_counters.json) / launch time, against "
-                                     "1024 SIMDs x clock / mix-weighted cycles per instruction measured by tools/ubench/op_cost.hip (DESIGN.md section 5)"}
+        if im.get("csrc_sha") != sha_now:
+            roofline["issue"] = {"stale": True, "source": f"{ipath}@csrc {im.get('csrc_sha', 'unstamped')}; sources now {sha_now}: not reported"}
+        else:
+            per_image = kk["SQ_INSTS_VALU"] / im["images_per_launch"]
+            valu = per_image * NI / per_step_launches
+            cyc = im["issue_model"]["cycles_per_valu_inst"]["k_" + dom]
+            peak = im["issue_model"]["simds"] * im["issue_model"]["clock_ghz"] * 1e9 / cyc
+            roofline["issue"] = {"valu_insts": int(valu), "cycles_per_valu_inst": cyc, "peak_wave_insts_per_s": round(peak, 0),
+                                 "frac": round(valu / (avg_ms * 1e-3) / peak, 4), "source": f"{ipath}@csrc {im['csrc_sha']}",
+                                 "note": "MODEL-DERIVED: wave64 VALU instructions per launch (rocprofv3 SQ_INSTS_VALU from the committed counter file, not this run) / "
+                                         "this run's launch time, against 1024 SIMDs x clock / mix-weighted cycles per instruction measured by "
+                                         "tools/ubench/op_cost.hip (DESIGN.md section 5)"}
+            if "SQ_ACTIVE_INST_VALU" in kk and kk.get("launch_ms"):
+                # counter-only figure (no price list): SIMD-cycles the vector ALUs were busy / SIMD-cycles of the launch, both from the counter run
+                roofline["issue"]["valu_busy_frac_counters"] = round(kk["SQ_ACTIVE_INST_VALU"] * 4 / (im["issue_model"]["simds"] * kk["launch_ms"] * 1e-3 * im["issue_model"]["clock_ghz"] * 1e9), 4)
 
     desc_txt = {"stereo": f"KITTI-shape stereo {W}x{H}, nFeatures={NFEAT}/eye, 8 levels, FAST 20/7: "
                           "extract(L)+extract(R)+ComputeStereoMatches; 1 frame = 1 stereo pair; images RESIDENT IN HBM when the timed region "
                           "starts (kernel throughput: excludes PCIe; the host-fed rates are under config.host_fed)",
                 "mono": f"mono {W}x{H}, nFeatures={NFEAT}, 8 levels, FAST 20/7: extract only",
                 "bow": f"mono {W}x{H}, nFeatures={NFEAT}: extract + ComputeBoW (synthetic k=10 L=6 vocabulary on device) + SearchByBoW(ratio 0.75, "
-                       "checkOri) of every frame against a device-resident 500-keyframe synthetic map; device-resident chain "
+                       f"checkOri) of every frame against a device-resident {NKF}-keyframe synthetic map; device-resident chain "
                        "(orbx_bow_transform_batch_device -> orbx_bowdb_search_batch_device), matches stay in HBM"}[kind]
     out = {"metric": metric, "value": round(value, 2),
            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": {"workload": desc_txt, "name": args.workload,
+           "config": {"workload": desc_txt, "name": args.workload, "csrc_sha": sha_now,
                       "frames_per_step_per_gpu": B, "images_per_step_per_gpu": NI,
                       "keypoints_per_image": round(nkp_avg, 1), "stereo_matches_per_frame": round(matched, 1),
                       "parallelism": f"{world} independent camera-stream batches, one per GPU"},
@@ -515,6 +578,7 @@ def main():
             out["config"]["bow_ms_per_query_frame_incl_host"] = round(bow["ms"] / bow["queries"], 4)
             out["config"]["of_which_bow_transform_ms"] = round(bow["tms"] / bow["queries"], 4)
         out["config"]["bow_matches_per_query_frame"] = round(bow["matches"] / bow["queries"], 1)
+        out["config"]["keyframes"] = NKF
 
     # ---- extra legs, all outside the timed headline region
     if stereo and args.extras and args.workload == "stereo1000":
@@ -559,13 +623,87 @@ def main():
             out["config"]["host_fed"] = hf
     if rank == 0 and world == 1 and args.cpu_frames > 0 and stereo:
         out["cpu_baseline"] = cpu_baseline([pairs[i % len(pairs)] for i in range(args.cpu_frames)])
+    elif rank == 0 and world == 1 and args.cpu_frames > 0:
+        if bow is not None and bow_cpu is None:
+            from oracle import oracle_py
+            bow_cpu = {"ovoc": oracle_py.Vocabulary(10, 6, *bow["vocab_arrays"]), "kfs": bow["kfs"]}
+        out["cpu_baseline"] = cpu_baseline_mono([monos[i % len(monos)] for i in range(args.cpu_frames)], bow_cpu)
     elif rank == 0:
         out["cpu_baseline"] = None
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (0 = the workload's default)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="stereo1000",
+                    help="stereo1000 is the BASELINE.json headline metric; the others are the remaining single-GPU configs")
+    ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU-baseline sample (0 = skip; default 240 stereo / 6 otherwise)")
+    ap.add_argument("--bow-host-path", action="store_true", help="euroc_bow: per-frame host-pointer ComputeBoW + search (round-1 form)")
+    ap.add_argument("--keyframes", type=int, default=0, help="BoW workloads: keyframes of the synthetic map (0 = 500; euroc_track: 1)")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs / images (tiled to the batch)")
+    ap.add_argument("--extras", type=int, default=1, help="0 = only the timed headline region (profiling runs): no batch sweep, host-fed, other-config or matcher legs")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of the last step's outputs")
+    args = ap.parse_args()
+    if args.cpu_frames < 0:
+        args.cpu_frames = 240 if WORKLOADS[args.workload][3] == "stereo" else 6
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+
+    pkg = ge.load_pkg()
+    st = pkg.streams
+    # ORBX_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    rank, world = st.init(backend, device_id=dev if backend == "nccl" else None)   # "nccl" is RCCL on ROCm; no-op for a single process
+    assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
+    pkg.lib()  # fails loudly if liborbx.so is missing: there is no fallback path
+    ctx = {"torch": torch, "pkg": pkg, "st": st, "dev": dev, "local": local, "rank": rank, "world": world,
+           "dist_dev": dev if backend == "nccl" else None}
+    out = run_workload(ctx, args)
+    bad = out.get("verified") is not None and not out["verified"]["bit_exact"]
+
+    if rank == 0 and world == 1 and args.extras and args.workload == "stereo1000":
+        # ---- the other BASELINE configs, short legs in the same process (outside the headline window)
+        others = {}
+        for name, steps, batch, distinct, cpuf, nkf in (("tum640", 10, 0, 4, 6, 0), ("euroc_bow", 6, 0, 4, 3, 0),
+                                                        ("fhd4000", 6, 0, 2, 3, 0), ("euroc_track", 8, 0, 4, 4, 1)):
+            a2 = argparse.Namespace(**vars(args))
+            a2.workload, a2.steps, a2.warmup, a2.batch, a2.distinct, a2.cpu_frames, a2.extras, a2.keyframes = name, steps, 2, batch, distinct, cpuf, 0, nkf
+            torch.cuda.empty_cache()
+            o = run_workload(ctx, a2)
+            r = o["roofline"]
+            others[name] = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "steps": steps, "ms_per_step": o["ms_per_step"],
+                            "frames_per_step": o["config"]["frames_per_step_per_gpu"], "keypoints_per_image": o["config"]["keypoints_per_image"],
+                            "verified": o.get("verified"), "cpu_baseline": o.get("cpu_baseline"),
+                            "roofline": {k: r[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "traffic", "traffic_source") if k in r}}
+            for k in ("bow_device_chain", "bow_matches_per_query_frame", "keyframes"):
+                if k in o["config"]:
+                    others[name][k] = o["config"][k]
+            bad = bad or (o.get("verified") is not None and not o["verified"]["bit_exact"])
+        out["config"]["other_configs"] = others
+        # ---- the three north-star matchers, one pair per call, next to the CPU oracle
+        try:
+            from oracle import oracle_py
+            from tools import matcher_bench
+            out["config"]["matchers"] = matcher_bench.measure(pkg, oracle_py, reps=100, cpu_reps=30, device=local)
+            bad = bad or out["config"]["matchers"].get("verified") is False
+        except Exception as exc:    # measurement leg only
+            out["config"]["matchers"] = {"error": str(exc)[:300]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
-    if verified is not None and not verified["bit_exact"]:
+    if bad:
         sys.exit(3)
 
 

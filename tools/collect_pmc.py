@@ -18,6 +18,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (csrc_sha: which kernel sources these counters belong to)
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 workload = sys.argv[3] if len(sys.argv) > 3 else "stereo1000"   # euroc_bow: BASELINE config 3 (k_bow<0>, k_vocab_*, k_bow_build)
@@ -40,7 +42,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             res[k]["launches_sampled"] = len(v)
 for k in res:
     res[k]["hbm_bytes_per_launch"] = int(1024 * (res[k].get("FETCH_SIZE_KiB_per_launch", 0) + res[k].get("WRITE_SIZE_KiB_per_launch", 0)))
-doc = {"tag": tag, "workload": workload, "frames_per_step": batch, "images_per_launch": 2 * batch if workload.startswith("stereo") else batch,
+doc = {"tag": tag, "workload": workload, "csrc_sha": bench.csrc_sha(), "frames_per_step": batch, "images_per_launch": 2 * batch if workload.startswith("stereo") else batch,
        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace; mean over dispatches; "
                  "no gfx950 x2 correction (4 B per lane loads calibrate at ~1.0x on k_resize)",
        "kernels": res}

@@ -5,6 +5,8 @@ Run ON THE GPU BOX: `gpurun -- python3 tools/collect_sq.py r01`.  Writes gpurun_
 import collections, csv, glob, json, os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (csrc_sha: which kernel sources these counters belong to)
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 PASSES = [
     ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"],
@@ -31,7 +33,7 @@ for i, counters in enumerate(PASSES):
             for c, v in cs.items():
                 res[k][c] = sum(v) / len(v)
     print("pass", i, "done", flush=True)
-json.dump(res, open(os.path.join(ROOT, "gpurun_out", f"{tag}_sq.json"), "w"), indent=1)
+json.dump({"csrc_sha": bench.csrc_sha(), "kernels": res}, open(os.path.join(ROOT, "gpurun_out", f"{tag}_sq.json"), "w"), indent=1)
 for k, v in res.items():
     w = v.get("SQ_WAVES", 1)
     print(k, {c: round(x / w, 1) for c, x in v.items()})

@@ -36,6 +36,16 @@ sq = os.path.join(ROOT, "gpurun_out", f"{tag}_sq.json")
 if os.path.exists(sq):
     mix = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py")]))
     kern = json.load(open(sq))
+    sha = kern.get("csrc_sha") if "kernels" in kern else None
+    kern = kern.get("kernels", kern)
+    # launch durations of the plain kernel trace of the same build (no counters attached): the denominator of the counter-only
+    # VALU-busy figure in bench.py
+    if stats:
+        import csv
+        for r in csv.DictReader(open(os.path.join(dst, f"{tag}_z_kernel_stats.csv"))):
+            k = r["Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
+            if k in kern:
+                kern[k]["launch_ms"] = float(r["AverageNs"]) / 1e6
     cyc = {}
     for k in kern:
         cands = [v for n, v in mix["kernels"].items() if n.split("<")[0] == k]
@@ -45,7 +55,7 @@ if os.path.exists(sq):
                    "default bench workload (512 images per launch).  SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count in units of 4 cycles. "
                    "issue_model: wave64 VALU issue cost per SIMD by opcode class measured with tools/ubench/op_cost.hip on the same GPU "
                    "(profiles/%s_op_cost.txt), weighted with each kernel's static instruction mix (tools/isa_mix.py)." % tag,
-           "images_per_launch": 512, "kernels": kern,
+           "images_per_launch": 512, "csrc_sha": sha, "kernels": kern,
            "issue_model": {"simds": 1024, "clock_ghz": 2.4, "fast_class_cycles": mix["fast_cycles"], "slow_class_cycles": mix["slow_cycles"],
                            "cycles_per_valu_inst": cyc, "static_mix": mix["kernels"]}}
     json.dump(doc, open(os.path.join(dst, f"{tag}_sq_counters.json"), "w"), indent=1)
