@@ -69,9 +69,11 @@ struct ProfEvent { hipEvent_t a, b; int stage; bool owns_a; };
 struct PipeSlot {
     uint8_t *h_in, *d_in; size_t in_cap;     // both eyes, pinned host staging and device level 0
     uint8_t *h_out; size_t h_out_cap;        // pinned: [n0 n1 flag | keypoints x2 | descriptors x2 | uRight | depth]
-    void *d_kps, *d_desc, *d_n; float *d_ur, *d_z; int out_cap;
+    uint8_t *d_out;                          // one device block in the layout of h_out (a single download per frame)
+    void *d_kps, *d_desc, *d_n; float *d_ur, *d_z; int out_cap;   // views into d_out
     hipEvent_t ev_h2d, ev_done, ev_d2h;      // input landed / kernels finished / results landed in h_out
     int cap, ticket, eyes; bool busy;
+    struct orbx_extractor *lane;             // the kernel lane (the handle or its shadow) that ran the slot's frame
 };
 #define ORBX_PIPE_DEPTH 4
 
@@ -116,6 +118,9 @@ struct orbx_extractor {
     void *scratch[8]; size_t scratch_cap[8]; // host-API upload buffers
     // pipelined stereo frames: copies ride their own streams so that frame i+1 uploads and frame i-1 downloads while frame i computes
     PipeSlot pipe[ORBX_PIPE_DEPTH]; hipStream_t copy_in, copy_out; unsigned pipe_next;
+    bool pipe_counted;               // this handle is counted in the process-wide number of pipelined handles
+    orbx_extractor *lane2;           // second kernel lane of the pipelined forms: odd submissions run on its stream and workspaces, so the
+                                     // launch chains of neighbouring frames overlap (a frame alone fills a few percent of the chip)
     // state of the most recent extract
     const uint8_t *last_img0; size_t last_img_stride, last_pitch; int last_batch;
     // profiling
@@ -173,6 +178,7 @@ int orbx_scratch(orbx_extractor *e, int slot, size_t bytes, void **out);
 // launches): called before any geometry rebuild or workspace reallocation, so tables are never rewritten and buffers
 // never freed under running kernels
 int orbx_quiesce(orbx_extractor *e);
+void orbx_pipe_handle_released();
 // the handle's workspaces are about to be used by launches on stream s: if the previous launches went to another stream, s first
 // waits for them (an event, no host synchronisation); records s as the handle's stream
 int orbx_use_stream(orbx_extractor *e, hipStream_t s);
