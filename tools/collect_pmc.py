@@ -5,9 +5,11 @@ Run ON THE GPU BOX (e.g. `gpurun -- python3 tools/collect_pmc.py r01`).  FETCH_S
 collected in SEPARATE passes (they do not fit one pass on gfx950: MI355X_MICROARCH.md, rocprofv3 PMC slots),
 each with --kernel-trace only.  rocprofv3 is given `python3 bench.py ...` directly after `--` (no shell,
 env or launcher hop).  Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB per dispatch.
-gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE halves the bytes of 16-B-per-lane streaming reads;
-the kernels here read 4 B per lane (dword tile loads), for which `k_resize` calibrates the counter at ~1.0x
-(170 MB counted for 180 MB algorithmic per step), so no factor is applied; both raw counters are stored.
+gfx950 correction: FETCH_SIZE tallies the L2's 128-byte memory-side read requests at 64 bytes.  Calibrated on known byte
+counts in the access patterns these kernels use (tools/ubench/fetch_calib.hip, profiles/r03_fetch_calibration.json: a 512 MiB
+stream read with global_load_dword, global_load_dwordx4, global_load_lds_dword and global_load_lds_dwordx4 reports 0.500 x the
+bytes in every case; WRITE_SIZE reports 1.000 x for dword and dwordx4 stores), so FETCH_SIZE is DOUBLED here; the raw counters are
+stored beside the corrected bytes.  (Round 2 took the raw value for dword loads: its "k_resize 156 MB = algorithmic" was half the truth.)
 """
 import collections
 import csv
@@ -25,6 +27,7 @@ batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 workload = sys.argv[3] if len(sys.argv) > 3 else "stereo1000"   # euroc_bow: BASELINE config 3 (k_bow<0>, k_vocab_*, k_bow_build)
 out_dir = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{workload}")
 res = collections.defaultdict(dict)
+FETCH_FACTOR = 2.0     # profiles/r03_fetch_calibration.json: FETCH_SIZE = 0.500 x the bytes for every streaming read pattern in use
 env = dict(os.environ, TMPDIR="/tmp")
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(out_dir, counter)
@@ -41,10 +44,13 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             res[k][counter + "_KiB_per_launch"] = sum(v) / len(v)
             res[k]["launches_sampled"] = len(v)
 for k in res:
-    res[k]["hbm_bytes_per_launch"] = int(1024 * (res[k].get("FETCH_SIZE_KiB_per_launch", 0) + res[k].get("WRITE_SIZE_KiB_per_launch", 0)))
+    res[k]["fetch_bytes_per_launch_corrected"] = int(1024 * FETCH_FACTOR * res[k].get("FETCH_SIZE_KiB_per_launch", 0))
+    res[k]["write_bytes_per_launch"] = int(1024 * res[k].get("WRITE_SIZE_KiB_per_launch", 0))
+    res[k]["hbm_bytes_per_launch"] = res[k]["fetch_bytes_per_launch_corrected"] + res[k]["write_bytes_per_launch"]
 doc = {"tag": tag, "workload": workload, "csrc_sha": bench.csrc_sha(), "frames_per_step": batch, "images_per_launch": 2 * batch if workload.startswith("stereo") else batch,
        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace; mean over dispatches; "
-                 "no gfx950 x2 correction (4 B per lane loads calibrate at ~1.0x on k_resize)",
+                 "FETCH_SIZE x 2 (gfx950 tallies 128-byte read requests at 64 bytes; calibrated on known byte counts for dword, dwordx4, "
+                 "lds_dword and lds_dwordx4 loads, profiles/r03_fetch_calibration.json), WRITE_SIZE as reported",
        "kernels": res}
 path = os.path.join(ROOT, "gpurun_out", f"{tag}_traffic.json" if workload == "stereo1000" else f"{tag}_traffic_{workload}.json")
 json.dump(doc, open(path, "w"), indent=1)
