@@ -94,14 +94,20 @@ extern __shared__ __align__(16) unsigned char bow_smem[];
 // typical node holds ~10 x 10 features.  Walking the first side of a node with one wave (64 lanes over ~10 candidates,
 // two wave reductions per step) left most lanes idle, so the kernel is split in two phases per batch of nodes:
 //   1. all Hamming distances of all shared nodes, one (node, a, b) triple per thread, into an LDS table (u16;
-//      0xFFFE = the first-side feature takes no part, 0xFFFF = the second-side feature takes no part);
+//      0xFE = the first-side feature takes no part, 0xFF = the second-side feature takes no part);
 //   2. the greedy walk of a node by ONE thread on that table (pure LDS reads, no descriptor traffic), 64 nodes per
 //      wave side by side.
 // Nodes are packed into passes of at most BOW_MATCAP table entries; a single node larger than that is walked by a
 // wave straight from global memory (node_greedy_wave, the former kernel body).
+// Table entries are BYTES: a distance is clamped to 253 (0xFE = the first-side feature takes no part, 0xFF = the second-side one).
+// An accepted match has best1 <= TH_LOW = 50, and the ratio test best1 < nnratio * best2 reads the same for best2 = 253 as for any
+// larger best2 as long as nnratio * 253 > 50, i.e. nnratio >= 0.2 (bow_launch sends smaller ratios -- ORB-SLAM2 uses 0.6 to 0.9 --
+// to the wave form).  8192 one-byte entries cost the LDS that 4096 two-byte ones did and halve the passes of a typical
+// 1000 x 1000 pair (14 700 distances: 4.2 passes -> 2.3).
 #ifndef BOW_MATCAP
-#define BOW_MATCAP 4096
+#define BOW_MATCAP 8192
 #endif
+#define BOW_DCLAMP 253
 #define BOW_CHUNK 256
 
 template <int MODE>
@@ -215,6 +221,7 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
     __shared__ uint16_t fall_list[BOW_CHUNK];
     __shared__ uint16_t choice[BOW_ROWCAP];          // per first-side row of the pass: chosen position in its node or 0xFFFF
     __shared__ uint8_t row_node[BOW_ROWCAP];         // per row: its (compacted) node, 0..255 inside the chunk
+    __shared__ uint8_t node_dirty[2][BOW_CHUNK];     // per node: a row of it changed its choice in the previous / this round
     // grid.y = query frame of a batched (KF set) x (frames) search (1 otherwise)
     const int pair = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const DevFeat A = sides_a[pair];
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
     uint8_t *claimed = bow_smem;                 // [B.n]   (wave fallback only)
     uint8_t *bins = bow_smem + ((B.n + 15) & ~15); // [nslots]
     unsigned *own = reinterpret_cast<unsigned *>(bins + ((nslots + 15) & ~15)); // [B.n] earliest row choosing a list position
-    uint16_t *mat = reinterpret_cast<uint16_t *>(own + ((B.n + 3) & ~3));        // [BOW_MATCAP]
+    uint8_t *mat = reinterpret_cast<uint8_t *>(own + ((B.n + 3) & ~3));          // [BOW_MATCAP]
     int32_t *match = match_out + ((long long)frame * gridDim.x + pair) * match_stride;
     nmatches += (long long)frame * gridDim.x;
     for (int i = tid; i < B.n; i += 256) claimed[i] = 0;
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
         const int npass = s_npass, nfall = s_nfall;
         BOW_STAT(2, npass); BOW_STAT(3, nfall); BOW_STAT(4, base == 0);
         for (int ps = 0; ps < npass; ps++) {
-            const int q0 = pass_first[ps], q1 = pass_first[ps + 1], total = pass_total[ps], rows = pass_rows[ps];
+            const int q0 = pass_first[ps], q1 = pass_first[ps + 1], rows = pass_rows[ps];
             // ---- phase 1: every distance of the pass, one (node, a, b) triple per thread, four in flight.  Descriptors and
             // flags are read from the copies stored in LIST order (sdesc / sflag): the triples of neighbouring lanes touch
             // neighbouring 32-byte records (4 per cache line) instead of 64 unrelated lines per load instruction, and no
@@ -292,39 +299,37 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
                 const int acn = (int)(c_cnt[q] & 0xFFFF), rb = c_roff[q];
                 for (int i1 = lane; i1 < acn; i1 += 64) row_node[rb + i1] = (uint8_t)q;
             }
-            for (int e0 = tid; e0 < total; e0 += 4 * 256) {
-                int e[4], pa[4], pb[4];
-                bool live[4];
+            __syncthreads();                      // row_node is read below
+            // lane = first-side ROW of the pass: its descriptor is fetched once and stays in registers, the columns of its node are
+            // walked four at a time (independent loads in flight); neighbouring lanes are rows of the same node and read the same
+            // second-side descriptors (one request per distinct address).  (Until round 3 a lane took one (row, column) entry and
+            // found its node by binary search in the pass's offset table: six dependent LDS reads per distance, 80 % of the kernel.)
+            for (int r = tid; r < rows; r += 256) {
+                const int lo = row_node[r];
+                const int bcn = (int)(c_cnt[lo] >> 16), i1 = r - c_roff[lo];
+                const long long pa = c_aoff[lo] + i1, pb0 = c_boff[lo];
+                uint8_t *row = mat + c_moff[lo] + i1 * bcn;
+                if (!A.sflag[pa]) { row[0] = 0xFE; continue; }       // the row takes no part: phase 2 looks at row[0] only
+                uint32_t da[8];
+                load_desc(A.sdesc, pa, da);
+                for (int j0 = 0; j0 < bcn; j0 += 4) {
+                    unsigned code[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    e[u] = e0 + 256 * u;
-                    live[u] = e[u] < total;
-                    int lo = q0, hi = q1 - 1;      // last node with c_moff <= e
-                    const int ee = live[u] ? e[u] : 0;
-                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (c_moff[mid] <= ee) lo = mid; else hi = mid - 1; }
-                    const unsigned cnt = c_cnt[lo];
-                    const int r = ee - c_moff[lo], bcn = (int)(cnt >> 16);
-                    int i1 = (int)__umulhi((unsigned)r, c_inv[lo]);
-                    if (bcn == 1) i1 = r;       // 2^32 / 1 does not fit the magic
-                    pa[u] = c_aoff[lo] + i1;
-                    pb[u] = c_boff[lo] + (r - i1 * bcn);
+                    for (int u = 0; u < 4; u++) {
+                        const int j = min(j0 + u, bcn - 1);
+                        uint32_t db[8];
+                        load_desc(B.sdesc, pb0 + j, db);
+                        const bool bcol = MODE == 1 ? B.sflag[pb0 + j] != 0 : true;
+                        code[u] = !bcol ? 0xFFu : (unsigned)min(hamming256(da, db), BOW_DCLAMP);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (j0 + u < bcn) row[j0 + u] = (uint8_t)code[u];
                 }
-                unsigned code[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    uint32_t da[8], db[8];
-                    load_desc(A.sdesc, pa[u], da);
-                    load_desc(B.sdesc, pb[u], db);
-                    const bool arow = A.sflag[pa[u]] != 0;
-                    const bool bcol = MODE == 1 ? B.sflag[pb[u]] != 0 : true;
-                    code[u] = !arow ? 0xFFFEu : !bcol ? 0xFFFFu : (unsigned)hamming256(da, db);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (live[u]) mat[e[u]] = (uint16_t)code[u];
             }
             for (int r = tid; r < rows; r += 256) choice[r] = 0xFFFF;
-            BOW_STAT(0, total); BOW_STAT(5, rows);
+            node_dirty[0][tid] = 1; node_dirty[1][tid] = 0;
+            BOW_STAT(0, pass_total[ps]); BOW_STAT(5, rows);
             __syncthreads();
 #ifdef ORBX_DIAG
             unsigned long long _tb1 = __builtin_amdgcn_s_memtime();
@@ -343,26 +348,34 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
                 }
                 __syncthreads();
                 int changed = 0;
+                // a node none of whose rows changed in the previous round is settled: the columns its rows see taken are exactly
+                // the choices of that node's own earlier rows, so recomputing them returns the same choices (most nodes settle
+                // in the first two rounds; the rounds after that only walk the few that still move)
+                const uint8_t *was = node_dirty[round & 1];
+                uint8_t *now = node_dirty[(round & 1) ^ 1];
                 for (int r = tid; r < rows; r += 256) {
                     const int lo = row_node[r];
+                    if (!was[lo]) continue;
                     const int bcn = (int)(c_cnt[lo] >> 16), boff = c_boff[lo];
-                    const uint16_t *row = mat + c_moff[lo] + (r - c_roff[lo]) * bcn;
+                    const uint8_t *row = mat + c_moff[lo] + (r - c_roff[lo]) * bcn;
                     unsigned nc = 0xFFFF;
-                    if (row[0] != 0xFFFE) {          // A.flag (:205-210 / :606-613)
+                    if (row[0] != 0xFE) {            // A.flag (:205-210 / :606-613)
                         int best1 = 256, best2 = 256, bj = -1;
                         for (int j = 0; j < bcn; j++) {
                             const int d = row[j];
-                            if (d == 0xFFFF || own[boff + j] < (unsigned)r) continue;
+                            if (d == 0xFF || own[boff + j] < (unsigned)r) continue;
                             if (d < best1) { best2 = best1; best1 = d; bj = j; } // first position wins ties (strict <)
                             else if (d < best2) best2 = d;
                         }
                         const bool ok_dist = MODE == 0 ? best1 <= BOW_TH_LOW : best1 < BOW_TH_LOW;
                         if (bj >= 0 && ok_dist && (float)best1 < nnratio * (float)best2) nc = (unsigned)bj;
                     }
-                    if (nc != choice[r]) { choice[r] = (uint16_t)nc; changed = 1; }
+                    if (nc != choice[r]) { choice[r] = (uint16_t)nc; changed = 1; now[lo] = 1; }
                 }
                 BOW_STAT(1, 1);
                 if (!__syncthreads_or(changed)) break;
+                node_dirty[round & 1][tid] = 0;     // becomes the "this round" row of the round after next
+                __syncthreads();
             }
 #ifdef ORBX_DIAG
             BOW_STAT(7, __builtin_amdgcn_s_memtime() - _tb1);
@@ -414,7 +427,8 @@ static int bow_launch(int npairs_x, int nframes_y, int max_b, int max_slots, hip
     bool table = (long long)npairs_x * nframes_y >= BOW_TABLE_MIN_PAIRS;
     const int forced = g_bow_form.load(std::memory_order_relaxed); // orbx_debug_set_bow_form: the parity tests run both forms on small inputs
     if (forced) table = forced == 2;
-    const size_t lds = table ? base + 4 * (size_t)((max_b + 3) & ~3) + 2 * BOW_MATCAP : base;
+    if (!(nnratio >= 0.2f)) table = false;     // the byte table clamps distances at 253: exact only while nnratio * 253 > TH_LOW
+    const size_t lds = table ? base + 4 * (size_t)((max_b + 3) & ~3) + BOW_MATCAP : base;
     if (lds > 150 * 1024) { orbx_set_error("feature sets too large for LDS"); return ORBX_E_INVALID; }
     if (table) {
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -4,6 +4,9 @@ tools/ubench/op_cost.hip on MI355X (gpurun_out/op_cost.txt -> profiles/r02_op_co
 instruction issues in ~2.5 cycles per SIMD only for a small set of opcodes (add / sub / and / or / xor / not / lshr / ashr /
 mov, the 16-bit VOP2 forms, f32 add / mul) and in ~4.3 cycles for everything else (min / max / min3 / max3, perm, alignbyte,
 packed-16, mul / mad, dot, cmp, cndmask, bcnt / mbcnt, bfe, lshl, any SDWA / DPP form, any form with an SGPR source).
+v_fma_f32 / v_fmac_f32 are full rate on normal operands (tools/ubench/fma_forms.hip, profiles/r03_fma_forms.txt; round 2 had timed
+them on denormals).  The cycle figures are priced at the idle-chip clock (2.4 GHz): in cycles of the loaded clock (~1.9-2.0 GHz) the two
+classes are ~2.1 and ~3.6, i.e. the guide's 2-cycle wave64 issue and its half-rate class; as TIMES per instruction they are what they are.
 Compiles orbx_extract.hip / orbx_stereo.hip to ISA (no GPU needed) and prints, per kernel, the instruction counts per class
 and the mix-weighted cycles per VALU instruction that bench.py's roofline.issue uses (written into
 profiles/r02_sq_counters.json by tools/collect_sq.py)."""
@@ -17,7 +20,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAST_CYC, SLOW_CYC = 2.5, 4.3
 FAST = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_lshrrev_b32", "v_ashrrev_i32",
-        "v_mov_b32", "v_add_f32", "v_sub_f32", "v_mul_f32", "v_add_u16", "v_sub_u16", "v_subrev_u16", "v_min_u16", "v_max_u16", "v_min_i16",
+        "v_mov_b32", "v_add_f32", "v_sub_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_mac_f32", "v_add_u16", "v_sub_u16", "v_subrev_u16", "v_min_u16", "v_max_u16", "v_min_i16",
         "v_max_i16", "v_mul_lo_u16", "v_lshlrev_b16", "v_lshrrev_b16", "v_ashrrev_i16", "v_add_f16", "v_sub_f16", "v_mul_f16", "v_max_f16",
         "v_min_f16"}
 
