@@ -6,6 +6,8 @@
 
 #include <orbx.h>
 
+#include "orbx_adapter.h"
+
 namespace ORB_SLAM2
 {
 
@@ -19,8 +21,10 @@ void Frame::ComputeStereoMatches()
     // mb = mbf / fx, which makes maxD = mbf / minZ = fx.  The ABI takes it explicitly.
     const float b = mbf / fx;
     if (orbx_stereo_match(mpORBextractorLeft->Handle(), mpORBextractorRight->Handle(), reinterpret_cast<const orbx_keypoint *>(&mvKeys[0]),
-                          mDescriptors.data, N, mvKeysRight.empty() ? NULL : reinterpret_cast<const orbx_keypoint *>(&mvKeysRight[0]),
-                          mDescriptorsRight.data, (int)mvKeysRight.size(), mbf, b, &mvuRight[0], &mvDepth[0]) != ORBX_OK)
+                          orbx_adapter::dense_descriptors(mDescriptors, N), N,
+                          mvKeysRight.empty() ? NULL : reinterpret_cast<const orbx_keypoint *>(&mvKeysRight[0]),
+                          orbx_adapter::dense_descriptors(mDescriptorsRight, (int)mvKeysRight.size()), (int)mvKeysRight.size(), mbf, b, &mvuRight[0],
+                          &mvDepth[0]) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
 }
 

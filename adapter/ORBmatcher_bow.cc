@@ -41,8 +41,8 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint *> &vpMapPo
     f.flag.assign(F.N, 0);
     keys_to_angles(pKF->mvKeysUn, kf.angle);                                       // :253: pKF->mvKeysUn vs F.mvKeys
     keys_to_angles(F.mvKeys, f.angle);
-    kf.bind(pKF->mDescriptors.data, pKF->N);
-    f.bind(F.mDescriptors.data, F.N);
+    kf.bind(orbx_adapter::dense_descriptors(pKF->mDescriptors, pKF->N), pKF->N);
+    f.bind(orbx_adapter::dense_descriptors(F.mDescriptors, F.N), F.N);
     vector<int32_t> match(F.N > 0 ? F.N : 1);
     int nmatches = 0;
     if (orbx_search_by_bow_kf_f(0, &kf.fs, &f.fs, mfNNratio, mbCheckOrientation ? 1 : 0, &match[0], &nmatches) != ORBX_OK)
@@ -65,8 +65,8 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &
     good_points(vpMapPoints2, k2.flag);
     keys_to_angles(pKF1->mvKeysUn, k1.angle);                                      // :654
     keys_to_angles(pKF2->mvKeysUn, k2.angle);
-    k1.bind(pKF1->mDescriptors.data, pKF1->N);
-    k2.bind(pKF2->mDescriptors.data, pKF2->N);
+    k1.bind(orbx_adapter::dense_descriptors(pKF1->mDescriptors, pKF1->N), pKF1->N);
+    k2.bind(orbx_adapter::dense_descriptors(pKF2->mDescriptors, pKF2->N), pKF2->N);
     vector<int32_t> match12(pKF1->N > 0 ? pKF1->N : 1);
     int nmatches = 0;
     if (orbx_search_by_bow_kf_kf(0, &k1.fs, &k2.fs, mfNNratio, mbCheckOrientation ? 1 : 0, &match12[0], &nmatches) != ORBX_OK)
@@ -92,7 +92,7 @@ static void triangulation_side(KeyFrame *pKF, Side &s)
         s.octave[i] = kp.octave;
         s.u_right[i] = pKF->mvuRight[i];
     }
-    s.bind(pKF->mDescriptors.data, n);
+    s.bind(orbx_adapter::dense_descriptors(pKF->mDescriptors, n), n);
 }
 
 int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t, size_t> > &vMatchedPairs,

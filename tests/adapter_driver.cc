@@ -6,12 +6,18 @@
 //   adapter_driver csr                 FeatureVector -> flatten() -> orbx_featset round trip (no GPU needed)
 //   adapter_driver run in.bin out.txt  stereo pair through the adaptor classes; every result is written as
 //                                      "name n v0 v1 ..." lines (floats as their uint32 bit patterns)
+//   adapter_driver track in.bin voc.txt out.txt   the per-frame searches of Tracking (SearchByProjection x 2, SearchForInitialization),
+//                                      Frame::ComputeBoW / UndistortKeyPoints and MapPoint::ComputeDistinctiveDescriptors through the
+//                                      compiled adaptors; built with -DORBX_ADAPTER_CAPTURE so that the inputs each search handed to the
+//                                      ABI are written next to its results (the test gives the CPU oracle the same inputs)
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdexcept>
 #include <utility>
 #include <vector>
+
+#include <map>
 
 #include "Frame.h"
 #include "KeyFrame.h"
@@ -21,7 +27,10 @@
 
 using namespace ORB_SLAM2;
 
-float Frame::fx = 718.856f;
+float Frame::fx = 718.856f, Frame::fy = 718.856f, Frame::cx = 607.1928f, Frame::cy = 185.2157f;
+float Frame::mnMinX = 0.f, Frame::mnMaxX = 1241.f, Frame::mnMinY = 0.f, Frame::mnMaxY = 376.f;
+
+namespace orbx_adapter { void DistinctiveDescriptors(const std::vector<ORB_SLAM2::MapPoint *> &points); }
 
 static uint32_t bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
@@ -185,11 +194,227 @@ static int mode_run(const char *in_path, const char *out_path)
     return 0;
 }
 
+
+#ifdef ORBX_ADAPTER_CAPTURE
+static void dump_u8(FILE *f, const char *name, const std::vector<uint8_t> &v)
+{
+    fprintf(f, "%s %zu", name, v.size());
+    for (size_t i = 0; i < v.size(); i++) fprintf(f, " %d", (int)v[i]);
+    fprintf(f, "\n");
+}
+static void dump_capture(FILE *fo, const std::string &pre, bool points)
+{
+    const orbx_adapter::Capture &c = orbx_adapter::capture();
+    dump_f(fo, (pre + "cur_x").c_str(), c.cx); dump_f(fo, (pre + "cur_y").c_str(), c.cy); dump_f(fo, (pre + "cur_angle").c_str(), c.cangle);
+    dump_f(fo, (pre + "cur_uright").c_str(), c.curight); dump_i(fo, (pre + "cur_octave").c_str(), c.coctave);
+    dump_u8(fo, (pre + "cur_occupied").c_str(), c.coccupied); dump_u8(fo, (pre + "cur_desc").c_str(), c.cdesc);
+    dump_f(fo, (pre + "cur_bounds").c_str(), std::vector<float>(c.bounds, c.bounds + 4));
+    if (!points) return;
+    dump_f(fo, (pre + "pts_u").c_str(), c.pu); dump_f(fo, (pre + "pts_v").c_str(), c.pv); dump_f(fo, (pre + "pts_aux").c_str(), c.paux);
+    dump_f(fo, (pre + "pts_angle").c_str(), c.pangle); dump_f(fo, (pre + "pts_view").c_str(), c.pview); dump_i(fo, (pre + "pts_level").c_str(), c.plevel);
+    dump_u8(fo, (pre + "pts_desc").c_str(), c.pdesc); dump_u8(fo, (pre + "pts_valid").c_str(), c.pvalid); dump_u8(fo, (pre + "pts_has_obs").c_str(), c.phas_obs);
+}
+
+// per feature: the index (inside `store`) of the MapPoint it holds, -1 none, -2 a point from elsewhere (it held it before the search)
+static std::vector<int> held(const std::vector<MapPoint *> &vp, const std::vector<MapPoint> &store)
+{
+    std::vector<int> out(vp.size(), -1);
+    for (size_t i = 0; i < vp.size(); i++)
+        if (vp[i]) out[i] = (vp[i] >= &store[0] && vp[i] < &store[0] + store.size()) ? (int)(vp[i] - &store[0]) : -2;
+    return out;
+}
+
+static cv::Mat pose(float tx, float ty, float tz)
+{
+    cv::Mat T(4, 4, CV_32F);
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T.at<float>(r, c) = r == c ? 1.f : 0.f;
+    // a small rotation about y so that Rcw is not the identity
+    const float a = 0.01f, ca = 0.99995f, sa = 0.0099998f; (void)a;
+    T.at<float>(0, 0) = ca; T.at<float>(0, 2) = sa; T.at<float>(2, 0) = -sa; T.at<float>(2, 2) = ca;
+    T.at<float>(0, 3) = tx; T.at<float>(1, 3) = ty; T.at<float>(2, 3) = tz;
+    return T;
+}
+
+static int mode_track(const char *in_path, const char *voc_path, const char *out_path)
+{
+    FILE *fi = fopen(in_path, "rb");
+    if (!fi) { fprintf(stderr, "cannot open %s\n", in_path); return 2; }
+    int hdr[2];
+    if (fread(hdr, 4, 2, fi) != 2) return 2;
+    const int w = hdr[0], h = hdr[1];
+    cv::Mat imL(h, w, CV_8UC1), imR(h, w, CV_8UC1);
+    if (fread(imL.data, 1, (size_t)w * h, fi) != (size_t)w * h || fread(imR.data, 1, (size_t)w * h, fi) != (size_t)w * h) return 2;
+    fclose(fi);
+    FILE *fo = fopen(out_path, "w");
+    if (!fo) return 2;
+    ORBextractor exL(1000, 1.2f, 8, 20, 7), exR(1000, 1.2f, 8, 20, 7);
+    Frame cur, last;
+    exL(imL, cv::Mat(), cur.mvKeys, cur.mDescriptors);
+    exR(imR, cv::Mat(), last.mvKeys, last.mDescriptors);
+    const std::vector<float> sf = exL.GetScaleFactors();
+    Frame *fr[2] = { &cur, &last };
+    for (int k = 0; k < 2; k++) {
+        Frame &F = *fr[k];
+        F.N = (int)F.mvKeys.size();
+        F.mvKeysUn = F.mvKeys;
+        F.mvScaleFactors = sf; F.mnScaleLevels = 8; F.mbf = 386.1448f; F.mb = F.mbf / Frame::fx;
+        F.mvuRight.assign(F.N, -1.0f);
+        for (int i = 0; i < F.N; i += 4) F.mvuRight[i] = F.mvKeys[i].pt.x - 7.5f;
+        F.mvpMapPoints.assign(F.N, static_cast<MapPoint *>(NULL));
+        F.mvbOutlier.assign(F.N, false);
+    }
+    // ---- the last frame's map points: each right-eye keypoint backprojected into the CURRENT camera 12 px to the right of where
+    // the right eye saw it, at 8 .. 14 m, and expressed in world coordinates through the current pose
+    std::vector<MapPoint> store(last.N);
+    std::vector<MapPoint> old(cur.N);           // points the current frame already holds
+    for (int i = 0; i < last.N; i++) {
+        MapPoint &P = store[i];
+        P.mDescriptor = last.mDescriptors.row(i).clone();
+        P.nObs = i % 3;
+        if (i % 5 != 3) last.mvpMapPoints[i] = &P;
+        last.mvbOutlier[i] = i % 9 == 4;
+    }
+    for (int i = 0; i < cur.N; i += 11) { old[i].nObs = i % 22 == 0 ? 2 : 0; cur.mvpMapPoints[i] = &old[i]; }
+    dump_keys(fo, "keysCur", cur.mvKeys); dump_keys(fo, "keysLast", last.mvKeys);
+    const std::vector<MapPoint *> cur_before = cur.mvpMapPoints;
+    const float tz[2] = { -0.2f, -0.9f };       // |twc.z| below / above mb = 0.537: the plain window, then the forward (bForward) one
+    for (int variant = 0; variant < 2; variant++) {
+        cur.mTcw = pose(0.05f, -0.02f, tz[variant]);
+        last.mTcw = pose(0.f, 0.f, 0.f);
+        for (int i = 0; i < last.N; i++) {
+            const float z = 8.f + (float)(i % 7), u = last.mvKeys[i].pt.x + 12.f, v = last.mvKeys[i].pt.y;
+            const float xc = (u - Frame::cx) / Frame::fx * z, yc = (v - Frame::cy) / Frame::fy * z;
+            // x3Dw = Rcw^T (x3Dc - tcw)
+            cv::Mat d(3, 1, CV_32F);
+            d.at<float>(0) = xc - cur.mTcw.at<float>(0, 3); d.at<float>(1) = yc - cur.mTcw.at<float>(1, 3); d.at<float>(2) = z - cur.mTcw.at<float>(2, 3);
+            store[i].mWorldPos = cur.mTcw.rowRange(0, 3).colRange(0, 3).t() * d;
+        }
+        cur.mvpMapPoints = cur_before;
+        ORBmatcher m(0.9f, true);
+        const int n = m.SearchByProjection(cur, last, 15.f, variant == 0);
+        const std::string pre = variant == 0 ? "lastA_" : "lastB_";
+        dump_capture(fo, pre, true);
+        dump_i(fo, (pre + "held").c_str(), held(cur.mvpMapPoints, store)); dump_i(fo, (pre + "n").c_str(), std::vector<int>(1, n));
+        dump_i(fo, (pre + "mono").c_str(), std::vector<int>(1, variant == 0));
+    }
+    // ---- Tracking::SearchLocalPoints: map points with their tracking variables set by Frame::isInFrustum
+    {
+        std::vector<MapPoint> local(last.N);
+        std::vector<MapPoint *> vp(last.N);
+        for (int i = 0; i < last.N; i++) {
+            MapPoint &P = local[i];
+            P.mDescriptor = last.mDescriptors.row(i).clone();
+            P.nObs = i % 4;
+            P.mbTrackInView = i % 7 != 3;
+            P.mbBad = i % 13 == 5;
+            P.mTrackProjX = last.mvKeys[i].pt.x + 10.f; P.mTrackProjY = last.mvKeys[i].pt.y + 0.5f; P.mTrackProjXR = P.mTrackProjX - 7.f;
+            P.mnTrackScaleLevel = last.mvKeys[i].octave;
+            P.mTrackViewCos = i % 2 ? 0.999f : 0.9f;
+            vp[i] = &P;
+        }
+        cur.mvpMapPoints = cur_before;
+        ORBmatcher m(0.8f, true);
+        const int n = m.SearchByProjection(cur, vp, 3.f);
+        dump_capture(fo, "local_", true);
+        dump_i(fo, "local_held", held(cur.mvpMapPoints, local)); dump_i(fo, "local_n", std::vector<int>(1, n));
+    }
+    // ---- Tracking::MonocularInitialization
+    {
+        std::vector<cv::Point2f> prev(cur.N);
+        for (int i = 0; i < cur.N; i++) prev[i] = cur.mvKeysUn[i].pt;
+        std::vector<int> m12;
+        ORBmatcher m(0.9f, true);
+        const int n = m.SearchForInitialization(cur, last, prev, m12, 100);
+        dump_capture(fo, "init_", false);
+        dump_i(fo, "init_m12", m12); dump_i(fo, "init_n", std::vector<int>(1, n));
+        std::vector<float> pv;
+        for (int i = 0; i < cur.N; i++) { pv.push_back(prev[i].x); pv.push_back(prev[i].y); }
+        dump_f(fo, "init_prev_after", pv);
+    }
+    // ---- Frame::ComputeBoW with the vocabulary file the test wrote
+    if (orbx_adapter::LoadVocabulary(voc_path) != ORBX_OK) { fprintf(stderr, "vocabulary: %s\n", orbx_last_error()); return 4; }
+    cur.ComputeBoW();
+    {
+        std::vector<long long> ids, fid, foff(1, 0), ffeat; std::vector<double> vals;
+        for (DBoW2::BowVector::const_iterator it = cur.mBowVec.begin(); it != cur.mBowVec.end(); ++it) { ids.push_back(it->first); vals.push_back(it->second); }
+        for (DBoW2::FeatureVector::const_iterator it = cur.mFeatVec.begin(); it != cur.mFeatVec.end(); ++it) {
+            fid.push_back(it->first);
+            for (size_t k = 0; k < it->second.size(); k++) ffeat.push_back(it->second[k]);
+            foff.push_back((long long)ffeat.size());
+        }
+        dump_i(fo, "bow_id", ids); dump_i(fo, "fv_id", fid); dump_i(fo, "fv_off", foff); dump_i(fo, "fv_feat", ffeat);
+        fprintf(fo, "bow_val %zu", vals.size());
+        for (size_t i = 0; i < vals.size(); i++) { unsigned long long u; memcpy(&u, &vals[i], 8); fprintf(fo, " %llu", u); }
+        fprintf(fo, "\n");
+    }
+    // ---- Frame::UndistortKeyPoints (a TUM-like lens)
+    {
+        cur.mK = cv::Mat(3, 3, CV_32F);
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) cur.mK.at<float>(r, c) = 0.f;
+        cur.mK.at<float>(0, 0) = 517.3f; cur.mK.at<float>(1, 1) = 516.5f; cur.mK.at<float>(0, 2) = 318.6f; cur.mK.at<float>(1, 2) = 255.3f; cur.mK.at<float>(2, 2) = 1.f;
+        cur.mDistCoef = cv::Mat(5, 1, CV_32F);
+        const float dc[5] = { 0.2624f, -0.9531f, -0.0054f, 0.0026f, 1.1633f };
+        for (int i = 0; i < 5; i++) cur.mDistCoef.at<float>(i) = dc[i];
+        cur.UndistortKeyPoints();
+        std::vector<float> xy;
+        for (int i = 0; i < cur.N; i++) { xy.push_back(cur.mvKeysUn[i].pt.x); xy.push_back(cur.mvKeysUn[i].pt.y); }
+        dump_f(fo, "undist_xy", xy);
+    }
+    // ---- MapPoint::ComputeDistinctiveDescriptors: points seen by "keyframes" = the two eyes and a third with mixed rows
+    {
+        KeyFrame kfs[3];
+        kfs[0].mDescriptors = cur.mDescriptors; kfs[1].mDescriptors = last.mDescriptors;
+        kfs[2].mDescriptors = cur.mDescriptors.clone();
+        for (int i = 0; i + 1 < kfs[2].mDescriptors.rows; i += 2) memcpy(kfs[2].mDescriptors.ptr<uchar>(i), last.mDescriptors.ptr<uchar>(i % last.N), 32);
+        kfs[1].mbBad = false;
+        const int npts = 40;
+        std::vector<MapPoint> pts(npts);
+        std::vector<MapPoint *> pp(npts);
+        std::vector<long long> obs;
+        for (int p = 0; p < npts; p++) {
+            const int nobs = 1 + p % 9;
+            for (int o = 0; o < nobs && o < 3; o++) pts[p].mObservations[&kfs[o]] = (size_t)((p * 7 + o * 13) % std::min(cur.N, last.N));
+            pts[p].mbBad = p == 17;
+            pp[p] = &pts[p];
+        }
+        kfs[1].mbBad = true;        // its observations are left out (:287)
+        for (int p = 0; p < npts; p += 2) pts[p].ComputeDistinctiveDescriptors();           // one at a time ...
+        std::vector<MapPoint *> rest;
+        for (int p = 1; p < npts; p += 2) rest.push_back(pp[p]);
+        orbx_adapter::DistinctiveDescriptors(rest);                                          // ... and the batched form
+        fprintf(fo, "distinct_obs %d", npts * 7);
+        for (int p = 0; p < npts; p++) {
+            // per point: bad flag, then (keyframe index, row) of up to three observations in the order of the std::map walk
+            fprintf(fo, " %d", (int)pts[p].mbBad);
+            int k = 0;
+            for (std::map<KeyFrame *, size_t>::iterator it = pts[p].mObservations.begin(); it != pts[p].mObservations.end(); ++it, ++k)
+                fprintf(fo, " %d %d", (int)(it->first - &kfs[0]), (int)it->second);
+            for (; k < 3; k++) fprintf(fo, " -1 -1");
+        }
+        fprintf(fo, "\n");
+        fprintf(fo, "distinct_desc %d", npts * 33);
+        for (int p = 0; p < npts; p++) {
+            fprintf(fo, " %d", pts[p].mDescriptor.empty() ? 0 : 1);
+            for (int b = 0; b < 32; b++) fprintf(fo, " %d", pts[p].mDescriptor.empty() ? 0 : (int)pts[p].mDescriptor.data[b]);
+        }
+        fprintf(fo, "\n");
+        dump_mat(fo, "kf2_desc", kfs[2].mDescriptors);
+    }
+    dump_mat(fo, "descCur", cur.mDescriptors); dump_mat(fo, "descLast", last.mDescriptors);
+    fclose(fo);
+    printf("adaptor track ok: %d / %d keypoints\n", cur.N, last.N);
+    return 0;
+}
+#endif
+
 int main(int argc, char **argv)
 {
     try {
         if (argc >= 2 && !strcmp(argv[1], "csr")) return mode_csr();
         if (argc >= 4 && !strcmp(argv[1], "run")) return mode_run(argv[2], argv[3]);
+#ifdef ORBX_ADAPTER_CAPTURE
+        if (argc >= 5 && !strcmp(argv[1], "track")) return mode_track(argv[2], argv[3], argv[4]);
+#endif
     } catch (const std::exception &e) {
         fprintf(stderr, "exception: %s\n", e.what());
         return 3;

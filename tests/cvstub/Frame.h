@@ -11,13 +11,20 @@ namespace ORB_SLAM2 {
 class Frame
 {
 public:
-    Frame() : mpORBextractorLeft(NULL), mpORBextractorRight(NULL), mbf(0), mb(0), N(0) {}
+    Frame() : mpORBextractorLeft(NULL), mpORBextractorRight(NULL), mbf(0), mb(0), N(0), mnScaleLevels(0) {}
     void ComputeStereoMatches();
+    void ComputeBoW();              // defined by adapter/Frame_bow.cc
+    void UndistortKeyPoints();      // defined by adapter/Frame_bow.cc
 
     ORBextractor *mpORBextractorLeft, *mpORBextractorRight;
-    static float fx;
+    static float fx, fy, cx, cy;
+    static float mnMinX, mnMaxX, mnMinY, mnMaxY;
     float mbf, mb;
     int N;
+    int mnScaleLevels;
+    std::vector<float> mvScaleFactors;
+    std::vector<bool> mvbOutlier;
+    cv::Mat mTcw, mK, mDistCoef;
     std::vector<cv::KeyPoint> mvKeys, mvKeysRight, mvKeysUn;
     std::vector<float> mvuRight, mvDepth;
     DBoW2::BowVector mBowVec;

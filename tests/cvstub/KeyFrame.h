@@ -10,7 +10,8 @@ namespace ORB_SLAM2 {
 class KeyFrame
 {
 public:
-    KeyFrame() : N(0), fx(0), fy(0), cx(0), cy(0) {}
+    KeyFrame() : N(0), fx(0), fy(0), cx(0), cy(0), mbBad(false) {}
+    bool isBad() { return mbBad; }
     std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }
     MapPoint *GetMapPoint(const size_t &idx) { return mvpMapPoints[idx]; }
     cv::Mat GetCameraCenter() { return Ow.clone(); }
@@ -26,6 +27,7 @@ public:
     DBoW2::FeatureVector mFeatVec;
     std::vector<float> mvScaleFactors, mvLevelSigma2;
 
+    bool mbBad;                             // protected in the reference
     std::vector<MapPoint *> mvpMapPoints;   // protected in the reference
     cv::Mat Ow, Rcw, tcw;                   // protected in the reference
 };

@@ -65,7 +65,19 @@ public:
     int type() const { return type_; }
     size_t elemSize() const { return type_ == CV_32F ? 4 : 1; }
     size_t total() const { return (size_t)rows * cols; }
+    bool isContinuous() const { return rows <= 1 || step == (size_t)cols * elemSize(); }
     Mat rowRange(int a, int b) const { Mat m(*this); m.data = data + (size_t)a * step; m.rows = b - a; return m; }
+    Mat colRange(int a, int b) const { Mat m(*this); m.data = data + (size_t)a * elemSize(); m.cols = b - a; return m; }   // a view: step unchanged
+    Mat row(int r) const { return rowRange(r, r + 1); }
+    Mat col(int c) const { return colRange(c, c + 1); }
+    Mat t() const
+    {
+        assert(type_ == CV_32F);
+        Mat m(cols, rows, CV_32F);
+        for (int r = 0; r < rows; r++)
+            for (int c = 0; c < cols; c++) *reinterpret_cast<float *>(m.data + (size_t)c * m.step + (size_t)r * 4) = *reinterpret_cast<const float *>(data + (size_t)r * step + (size_t)c * 4);
+        return m;
+    }
     Mat clone() const { Mat m(rows, cols, type_); for (int r = 0; r < rows; r++) memcpy(m.data + r * m.step, data + r * step, (size_t)cols * elemSize()); return m; }
     void copyTo(const _OutputArray &dst) const;
     template <typename T> T &at(int r, int c) { return *reinterpret_cast<T *>(data + (size_t)r * step + (size_t)c * sizeof(T)); }
@@ -99,6 +111,15 @@ inline Mat operator+(const Mat &a, const Mat &b)
     Mat c(a.rows, a.cols, CV_32F);
     for (int i = 0; i < a.rows; i++)
         for (int j = 0; j < a.cols; j++) c.at<float>(i, j) = a.at<float>(i, j) + b.at<float>(i, j);
+    return c;
+}
+
+inline Mat operator-(const Mat &a)
+{
+    assert(a.type() == CV_32F);
+    Mat c(a.rows, a.cols, CV_32F);
+    for (int i = 0; i < a.rows; i++)
+        for (int j = 0; j < a.cols; j++) c.at<float>(i, j) = -a.at<float>(i, j);
     return c;
 }
 

@@ -17,7 +17,8 @@ import pytest
 from tools import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ADAPTER = [os.path.join(ROOT, "adapter", f) for f in ("ORBextractor.cc", "Frame_stereo.cc", "ORBmatcher_bow.cc")]
+ADAPTER = [os.path.join(ROOT, "adapter", f) for f in ("ORBextractor.cc", "Frame_stereo.cc", "ORBmatcher_bow.cc", "ORBmatcher_proj.cc", "Frame_bow.cc",
+                                                       "MapPoint_distinctive.cc")]
 INC = ["-I", os.path.join(ROOT, "adapter"), "-I", os.path.join(ROOT, "tests", "cvstub"), "-I", os.path.join(ROOT, "include")]
 REF = "/root/reference"
 
@@ -30,7 +31,8 @@ def _build_driver(tmpdir, real_dbow2=False):
     if real_dbow2:   # "Thirdparty/DBoW2/DBoW2/FeatureVector.h" now resolves to the reference's own header
         inc = ["-I", REF] + inc
         extra = [os.path.join(REF, "Thirdparty/DBoW2/DBoW2", f) for f in ("FeatureVector.cpp", "BowVector.cpp")]
-    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-Wextra"] + inc + [os.path.join(ROOT, "tests", "adapter_driver.cc")] + ADAPTER + extra +
+    # ORBX_ADAPTER_CAPTURE: the projection adaptors keep a copy of what they hand to the ABI (the `track` mode writes it out)
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-DORBX_ADAPTER_CAPTURE"] + inc + [os.path.join(ROOT, "tests", "adapter_driver.cc")] + ADAPTER + extra +
                           ["-L", os.path.join(ROOT, "orb-slam2_amd"), "-lorbx", "-Wl,-rpath," + os.path.join(ROOT, "orb-slam2_amd"), "-o", exe])
     return exe
 
@@ -44,6 +46,36 @@ def test_cv_keypoint_stub_is_28_bytes(tmp_path):
     src = os.path.join(tmp_path, "t.cc")
     open(src, "w").write('#include <opencv2/core/core.hpp>\n#include <orbx.h>\nstatic_assert(sizeof(cv::KeyPoint) == 28 && sizeof(orbx_keypoint) == 28, "");\nint main(){return 0;}\n')
     subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only"] + INC + [src])
+
+
+def _decls(text, names):
+    """{method name: [normalised parameter lists]} of the member declarations `int name(...);` in a header"""
+    import re
+    out = {}
+    for m in re.finditer(r"\bint\s+(\w+)\s*\(([^;{]*)\)\s*;", text):
+        if m.group(1) in names:
+            params = []
+            for prm in m.group(2).split(","):
+                prm = re.sub(r"=[^,]*$", "", prm)                      # default value
+                prm = re.sub(r"\bstd::", "", prm)
+                prm = re.sub(r"\s*([*&<>])\s*", r"\1", " ".join(prm.split()))
+                prm = re.sub(r"[*&]?\s*\w+$", lambda t: t.group(0)[0] if t.group(0)[0] in "*&" else "", prm).strip()   # drop the parameter name
+                params.append(prm)
+            out.setdefault(m.group(1), []).append(tuple(params))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "include/ORBmatcher.h")), reason="reference checkout absent")
+def test_signatures_match_the_reference_header():
+    """every ORBmatcher method an adaptor defines is declared in tests/cvstub/ORBmatcher.h with the parameter types the reference's
+    include/ORBmatcher.h (:41-83) gives it: the stand-in header cannot drift from the interface the drop-in has to meet"""
+    names = {"SearchByProjection", "SearchByBoW", "SearchForInitialization", "SearchForTriangulation"}
+    ref = _decls(open(os.path.join(REF, "include/ORBmatcher.h"), errors="replace").read(), names)
+    stub = _decls(open(os.path.join(ROOT, "tests/cvstub/ORBmatcher.h")).read(), names)
+    assert stub, "no declarations parsed"
+    for name, sigs in stub.items():
+        for sig in sigs:
+            assert sig in ref.get(name, []), f"{name}{sig} is not a signature of the reference header: {ref.get(name)}"
 
 
 CSR_EXPECT = ["id 0 3 7 900000", "off 0 1 4 7 8", "feat 16 11 14 15 10 12 17 13"]
@@ -149,3 +181,95 @@ def test_adapter_runs_and_matches_oracle(pkg, oracle, tmp_path):
     exp3 = oracle.search_for_triangulation(t_r, t_l, F12, float(ex), float(ey), np.asarray(oL.scale_factors(), np.float32),
                                            np.asarray(oL.level_sigma2(), np.float32), 0.6, False, False)
     assert int(r["tri_n"][0]) == len(exp3) and (r["triPairs"].reshape(-1, 2) == exp3.reshape(-1, 2)).all() and len(exp3) > 5
+
+
+def _u8(a):
+    return a.astype(np.uint8)
+
+
+def _cur(r, pre):
+    return dict(x=_f32(r[pre + "cur_x"]), y=_f32(r[pre + "cur_y"]), octave=r[pre + "cur_octave"].astype(np.int32), angle=_f32(r[pre + "cur_angle"]),
+                u_right=_f32(r[pre + "cur_uright"]), desc=_u8(r[pre + "cur_desc"]).reshape(-1, 32), occupied=_u8(r[pre + "cur_occupied"]),
+                bounds=[float(v) for v in _f32(r[pre + "cur_bounds"])])
+
+
+def _pts(r, pre):
+    return dict(u=_f32(r[pre + "pts_u"]), v=_f32(r[pre + "pts_v"]), aux=_f32(r[pre + "pts_aux"]), level=r[pre + "pts_level"].astype(np.int32),
+                angle=_f32(r[pre + "pts_angle"]), view_cos=_f32(r[pre + "pts_view"]), desc=_u8(r[pre + "pts_desc"]).reshape(-1, 32),
+                valid=_u8(r[pre + "pts_valid"]), has_obs=_u8(r[pre + "pts_has_obs"]))
+
+
+@pytest.mark.gpu
+def test_adapter_tracking_searches(pkg, oracle, tmp_path):
+    """Tracking's per-frame searches, Frame::ComputeBoW / UndistortKeyPoints and MapPoint::ComputeDistinctiveDescriptors through the
+    COMPILED adaptors (adapter/ORBmatcher_proj.cc, Frame_bow.cc, MapPoint_distinctive.cc), against the CPU oracle fed with exactly
+    the inputs each adaptor handed to the ABI"""
+    w, h = 1241, 376
+    left, right, _ = synth.stereo_pair(517, w, h)
+    inp, outp, vocp = os.path.join(tmp_path, "in.bin"), os.path.join(tmp_path, "out.txt"), os.path.join(tmp_path, "voc.txt")
+    with open(inp, "wb") as f:
+        f.write(np.array([w, h], np.int32).tobytes()); f.write(left.tobytes()); f.write(right.tobytes())
+    oL, oR = oracle.Oracle(1000, 1.2, 8, 20, 7), oracle.Oracle(1000, 1.2, 8, 20, 7)
+    kL, dL = oL.extract(left); kR, dR = oR.extract(right)
+    par, leaf, nd, wt = synth.vocab_tree(77, 10, 3, stop_frac=0.02, data=dL)
+    synth.write_vocab_text(vocp, 10, 3, par, leaf, nd, wt)
+    exe = _build_driver(str(tmp_path))
+    run = subprocess.run([exe, "track", inp, vocp, outp], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    r = _parse(outp)
+    assert _keys(r["keysCur"], pkg).tobytes() == kL.tobytes() and _keys(r["keysLast"], pkg).tobytes() == kR.tobytes()
+    sf = np.asarray(oL.scale_factors(), np.float32)
+    nL, nR = len(kL), len(kR)
+    # ---- SearchByProjection(CurrentFrame, LastFrame): both pose variants (plain window / bForward)
+    for pre, direction in (("lastA_", 0), ("lastB_", 1)):
+        cur, pts = _cur(r, pre), _pts(r, pre)
+        assert len(cur["x"]) == nL and len(pts["u"]) == nR and cur["desc"].tobytes() == dL.tobytes()
+        iR = np.arange(nR)
+        assert (pts["valid"] == ((iR % 5 != 3) & (iR % 9 != 4))).all()                      # has a point and is no outlier
+        ok = pts["valid"] == 1
+        assert (pts["desc"][ok] == dR[ok]).all() and (pts["level"][ok] == kR["octave"][ok]).all()
+        # the prologue's projection: each point was placed to project 12 px right of its right-eye position (float32 round trips)
+        assert np.abs(pts["u"][ok] - (kR["x"][ok] + 12)).max() < 0.05 and np.abs(pts["v"][ok] - kR["y"][ok]).max() < 0.05
+        assert np.abs(1.0 / pts["aux"][ok] - (8 + iR[ok] % 7)).max() < 1e-3
+        exp, en = oracle.search_by_projection_last(cur, pts, sf, 15.0, direction, 386.1448, True)
+        held = r[pre + "held"]
+        before = np.where(np.arange(nL) % 11 == 0, -2, -1)
+        assert int(r[pre + "n"][0]) == en and (held == np.where(exp >= 0, exp, before)).all(), pre
+        assert en > 30
+    # ---- SearchByProjection(F, vpMapPoints)
+    cur, pts = _cur(r, "local_"), _pts(r, "local_")
+    iR = np.arange(nR)
+    assert (pts["valid"] == ((iR % 7 != 3) & (iR % 13 != 5))).all()
+    exp, en = oracle.search_by_projection_points(cur, pts, sf, 3.0, 0.8)
+    before = np.where(np.arange(nL) % 11 == 0, -2, -1)
+    assert int(r["local_n"][0]) == en and (r["local_held"] == np.where(exp >= 0, exp, before)).all() and en > 30
+    # ---- SearchForInitialization(F1 = current, F2 = last)
+    f2 = _cur(r, "init_")
+    f1 = dict(x=kL["x"], y=kL["y"], octave=kL["octave"], angle=kL["angle"], u_right=np.where(np.arange(nL) % 4 == 0, kL["x"] - 7.5, -1).astype(np.float32),
+              desc=dL, occupied=np.zeros(nL, np.uint8), bounds=f2["bounds"])
+    prev = np.stack([kL["x"], kL["y"]], axis=1)
+    exp, en = oracle.search_for_initialization(f1, f2, prev, 100, 0.9, True)
+    assert int(r["init_n"][0]) == en and (r["init_m12"] == exp).all() and en > 20
+    after = _f32(r["init_prev_after"]).reshape(-1, 2)
+    want = prev.copy(); m = exp >= 0
+    want[m, 0] = kR["x"][exp[m]]; want[m, 1] = kR["y"][exp[m]]
+    assert after.tobytes() == want.astype(np.float32).tobytes()
+    # ---- Frame::ComputeBoW
+    ovoc = oracle.Vocabulary(path=vocp)
+    t = ovoc.transform(dL, 4)
+    assert (r["bow_id"] == t["bow_id"]).all() and r["bow_val"].astype(np.uint64).view(np.float64).tobytes() == t["bow_val"].tobytes()
+    assert (r["fv_id"] == t["fv_node_id"]).all() and (r["fv_off"] == t["fv_node_off"]).all() and (r["fv_feat"] == t["fv_feat"]).all()
+    # ---- Frame::UndistortKeyPoints
+    xy = np.stack([kL["x"], kL["y"]], axis=1)
+    exp_xy = oracle.undistort_points(xy, 517.3, 516.5, 318.6, 255.3, np.array([0.2624, -0.9531, -0.0054, 0.0026, 1.1633], np.float32))
+    assert _f32(r["undist_xy"]).tobytes() == exp_xy.astype(np.float32).tobytes()
+    # ---- MapPoint::ComputeDistinctiveDescriptors (single and batched form)
+    kf_desc = [dL, dR, _u8(r["kf2_desc"]).reshape(-1, 32)]
+    obs = r["distinct_obs"].reshape(-1, 7); got = r["distinct_desc"].reshape(-1, 33)
+    for p in range(len(obs)):
+        rows = [kf_desc[k][row] for k, row in obs[p, 1:].reshape(3, 2) if k >= 0 and k != 1]    # keyframe 1 is bad: its observation is left out
+        if obs[p, 0] or not rows:
+            assert got[p, 0] == 0, p                                                            # a bad point / no usable observation: untouched
+            continue
+        best = oracle.distinctive_descriptor(np.array(rows, np.uint8))
+        assert got[p, 0] == 1 and (got[p, 1:] == rows[best]).all(), p
