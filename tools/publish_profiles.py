@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", f"final_{tag}")
 dst = os.path.join(ROOT, "profiles")
 
@@ -29,9 +29,18 @@ for name, out in (("bench_default.json", f"{tag}_z_bench_default.json"), ("bench
 stats = glob.glob(os.path.join(src, "prof", "*", "*kernel_stats.csv"))
 if stats:
     shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, f"{tag}_z_kernel_stats.csv"))   # the newest run
-tr = os.path.join(ROOT, "gpurun_out", f"{tag}_traffic.json")
-if os.path.exists(tr):
-    shutil.copy(tr, os.path.join(dst, f"{tag}_traffic.json"))
+for name in (f"{tag}_traffic.json", f"{tag}_traffic_euroc_bow.json"):
+    tr = os.path.join(ROOT, "gpurun_out", name)
+    if os.path.exists(tr):
+        shutil.copy(tr, os.path.join(dst, name))
+others = glob.glob(os.path.join(src, "prof_others", "*", "*kernel_stats.csv"))
+if others:
+    shutil.copy(max(others, key=os.path.getmtime), os.path.join(dst, f"{tag}_other_kernels_stats.csv"))
+for name, out in (("b1_chain.txt", f"{tag}_b1_launch_chain.txt"), ("matcher_kernels.txt", f"{tag}_matcher_kernels.txt"), ("matchers.json", f"{tag}_z_matchers.json"),
+                  ("match_stamps.txt", f"{tag}_match_stamps.txt"), ("hostfed_c.txt", f"{tag}_hostfed_c.txt")):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, out))
 sq = os.path.join(ROOT, "gpurun_out", f"{tag}_sq.json")
 if os.path.exists(sq):
     mix = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py")]))
