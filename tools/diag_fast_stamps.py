@@ -7,7 +7,7 @@ import numpy as np, torch
 import __graft_entry__ as ge
 from tools import synth
 pkg = ge.load_pkg(); L = pkg.lib()
-W,H,B = 1241,376,64
+W,H,B = 1241,376,(int(sys.argv[1]) if len(sys.argv) > 1 else 64)
 pairs=[synth.stereo_pair(1000+i,W,H)[:2] for i in range(4)]
 pitch=1280; host=np.zeros((2*B,H,pitch),np.uint8)
 for i in range(B): host[i,:,:W]=pairs[i%4][0]; host[B+i,:,:W]=pairs[i%4][1]
