@@ -117,12 +117,15 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
     int nmatches = 0;
     ORBX_CAPTURE(cur.ff, &pts.pp);
     if (orbx_search_by_projection_last_frame(0, &cur.ff, &pts.pp, &CurrentFrame.mvScaleFactors[0], (int)CurrentFrame.mvScaleFactors.size(), th,
-                                             bForward ? 1 : bBackward ? 2 : 0, CurrentFrame.mbf, mbCheckOrientation ? 1 : 0, &match[0],
+                                             bForward ? 1 : bBackward ? 2 : 0, CurrentFrame.mbf, mbCheckOrientation ? 3 : 0, &match[0],
                                              &nmatches) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
-    for (int f = 0; f < CurrentFrame.N; f++)
+    for (int f = 0; f < CurrentFrame.N; f++) {
         if (match[f] >= 0)
-            CurrentFrame.mvpMapPoints[f] = LastFrame.mvpMapPoints[match[f]];   // :1500; features the rotation filter cleared keep what they held
+            CurrentFrame.mvpMapPoints[f] = LastFrame.mvpMapPoints[match[f]];   // :1500
+        else if (match[f] == -2)
+            CurrentFrame.mvpMapPoints[f] = static_cast<MapPoint *>(NULL);      // matched, then cleared by the rotation filter (:1526-1545)
+    }
     return nmatches;
 }
 

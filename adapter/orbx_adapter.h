@@ -124,10 +124,10 @@ struct Capture {
     std::vector<uint8_t> coccupied, cdesc, pdesc, pvalid, phas_obs;
     float bounds[4];
 };
-inline Capture &capture() { static Capture c; return c; }
-inline void capture_call(const orbx_frame_feats &f, const orbx_proj_points *p)
+inline Capture &capture(int slot = 0) { static Capture c[2]; return c[slot]; }
+inline void capture_call(const orbx_frame_feats &f, const orbx_proj_points *p, int slot = 0)
 {
-    Capture &c = capture();
+    Capture &c = capture(slot);
     const size_t n = (size_t)f.n;
     c.cx.assign(f.x, f.x + n); c.cy.assign(f.y, f.y + n); c.cangle.assign(f.angle, f.angle + n); c.curight.assign(f.u_right, f.u_right + n);
     c.coctave.assign(f.octave, f.octave + n); c.coccupied.assign(f.occupied, f.occupied + n); c.cdesc.assign(f.desc, f.desc + 32 * n);
@@ -140,8 +140,10 @@ inline void capture_call(const orbx_frame_feats &f, const orbx_proj_points *p)
     }
 }
 #define ORBX_CAPTURE(f, p) orbx_adapter::capture_call(f, p)
+#define ORBX_CAPTURE2(f, p) orbx_adapter::capture_call(f, p, 1)
 #else
 #define ORBX_CAPTURE(f, p) do { } while (0)
+#define ORBX_CAPTURE2(f, p) do { } while (0)
 #endif
 
 } // namespace orbx_adapter

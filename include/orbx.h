@@ -359,7 +359,10 @@ typedef struct {
 /* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (src/ORBmatcher.cc:1396-1553;
  * Tracking::TrackWithMotionModel).  direction: 0 none, 1 bForward, 2 bBackward (:1412-1413).  match_cur[cur->n] =
  * index of the point each current feature finally holds (-1 none); *nmatches = the reference's return value
- * (it counts every accepted point, also one whose feature a later point overwrote). */
+ * (it counts every accepted point, also one whose feature a later point overwrote).
+ * check_orientation: 0 off, 1 on, 3 on + a feature whose match the rotation filter cleared reads -2 instead of -1: the
+ * reference sets CurrentFrame.mvpMapPoints[...] = NULL there (:1526-1545), which differs from "never matched" when the
+ * feature held a point before the call; the same two bits in orbx_search_by_projection_keyframe (:1660-1680). */
 int orbx_search_by_projection_last_frame(int device, const orbx_frame_feats *cur, const orbx_proj_points *pts,
                                          const float *scale_factors, int nlevels, float th, int direction, float mbf,
                                          int check_orientation, int32_t *match_cur, int *nmatches);

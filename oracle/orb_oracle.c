@@ -879,17 +879,18 @@ static int rot_bin(float a1, float a2)
     return bin;
 }
 /* clear matches outside the three dominant bins; returns how many were removed */
-static int rh_filter(rot_hist *h, int32_t *match)
+static int rh_filter_mark(rot_hist *h, int32_t *match, int32_t cleared)
 {
     int i1, i2, i3, removed = 0;
     oracle_three_maxima(h->n, HISTO_LENGTH, &i1, &i2, &i3);
     for (int i = 0; i < HISTO_LENGTH; i++) {
         if (i != i1 && i != i2 && i != i3)
-            for (int j = 0; j < h->n[i]; j++) { match[h->v[i][j]] = -1; removed++; }
+            for (int j = 0; j < h->n[i]; j++) { match[h->v[i][j]] = cleared; removed++; }
         free(h->v[i]);
     }
     return removed;
 }
+static int rh_filter(rot_hist *h, int32_t *match) { return rh_filter_mark(h, match, -1); }
 
 /* merge-join cursor advance == std::map::lower_bound on ascending ids */
 static int lower_bound_u32(const uint32_t *a, int n, uint32_t key)
@@ -1341,10 +1342,10 @@ int oracle_search_by_projection_last(const oracle_frame_feats *cur, const oracle
             match_cur[best_idx] = i;
             blocked[best_idx] = pts->has_obs[i];
             nmatches++;
-            if (check_ori) rh_push(&rh, rot_bin(pts->angle[i], cur->angle[best_idx]), best_idx);
+            if (check_ori & 1) rh_push(&rh, rot_bin(pts->angle[i], cur->angle[best_idx]), best_idx);
         }
     }
-    if (check_ori) nmatches -= rh_filter(&rh, match_cur);
+    if (check_ori & 1) nmatches -= rh_filter_mark(&rh, match_cur, (check_ori & 2) ? -2 : -1);
     grid_free(g); free(cand); free(blocked);
     return nmatches;
 }
@@ -1427,10 +1428,10 @@ int oracle_search_by_projection_keyframe(const oracle_frame_feats *cur, const or
             match_cur[best_idx] = i;
             blocked[best_idx] = 1;
             nmatches++;
-            if (check_ori) rh_push(&rh, rot_bin(pts->angle[i], cur->angle[best_idx]), best_idx);
+            if (check_ori & 1) rh_push(&rh, rot_bin(pts->angle[i], cur->angle[best_idx]), best_idx);
         }
     }
-    if (check_ori) nmatches -= rh_filter(&rh, match_cur);
+    if (check_ori & 1) nmatches -= rh_filter_mark(&rh, match_cur, (check_ori & 2) ? -2 : -1);
     grid_free(g); free(cand); free(blocked);
     return nmatches;
 }

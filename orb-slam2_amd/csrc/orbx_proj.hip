@@ -49,6 +49,7 @@ struct ProjParams {
     int max_dist;      // TH_HIGH, TH_LOW or ORBdist
     int ratio;         // 1: same-level ratio test of the map-point search (:117-121)
     int check_ori;
+    int mark_cleared;  // 1: a feature whose match the rotation filter cleared reads -2 instead of -1 (the reference leaves NULL there, not the old holder)
     int init_search;   // 1: SearchForInitialization's sequential rule (k_init_resolve)
     int claims;        // 0: points are independent (Fuse, SearchBySim3)  1: an accepted match of a point with
                        // Observations() > 0 blocks its feature  2: every accepted match blocks it
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(DevFrame F, DevPoints P, 
             const int f = cur[i];
             if (f < 0) continue;
             const int b = nxt[i];
-            if (b != keep3[0] && b != keep3[1] && b != keep3[2]) { match[f] = -1; pt_choice[i] = -1; removed++; } // :1518-1523, one decrement per entry
+            if (b != keep3[0] && b != keep3[1] && b != keep3[2]) { match[f] = pp.mark_cleared ? -2 : -1; pt_choice[i] = -1; removed++; } // :1518-1523, one decrement per entry
         }
         if (removed) atomicSub(&s_cnt, removed);
         __threadfence_block();
@@ -597,7 +598,7 @@ extern "C" int orbx_search_by_projection_last_frame(int device, const orbx_frame
     ProjParams pp;
     memset(&pp, 0, sizeof pp);
     pp.radius_mode = 0; pp.bounds = 1; pp.need_pos_aux = 1; pp.lo_off = -1; pp.hi_off = 1; pp.direction = direction;
-    pp.ur_mode = 1; pp.max_dist = 100; pp.check_ori = check_orientation; pp.claims = 1;
+    pp.ur_mode = 1; pp.max_dist = 100; pp.check_ori = check_orientation & 1; pp.mark_cleared = (check_orientation >> 1) & 1; pp.claims = 1;
     pp.th = th; pp.mbf = mbf;
     return proj_run(device, cur, pts, scale_factors, nlevels, pp, match_cur, nmatches);
 }
@@ -619,7 +620,7 @@ extern "C" int orbx_search_by_projection_keyframe(int device, const orbx_frame_f
 {
     ProjParams pp;
     memset(&pp, 0, sizeof pp);
-    pp.bounds = 1; pp.lo_off = -1; pp.hi_off = 1; pp.max_dist = orb_dist; pp.check_ori = check_orientation; pp.claims = 2;
+    pp.bounds = 1; pp.lo_off = -1; pp.hi_off = 1; pp.max_dist = orb_dist; pp.check_ori = check_orientation & 1; pp.mark_cleared = (check_orientation >> 1) & 1; pp.claims = 2;
     pp.th = th;
     return proj_run(device, cur, pts, scale_factors, nlevels, pp, match_cur, nmatches);
 }

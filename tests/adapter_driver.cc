@@ -10,6 +10,7 @@
 //                                      Frame::ComputeBoW / UndistortKeyPoints and MapPoint::ComputeDistinctiveDescriptors through the
 //                                      compiled adaptors; built with -DORBX_ADAPTER_CAPTURE so that the inputs each search handed to the
 //                                      ABI are written next to its results (the test gives the CPU oracle the same inputs)
+//   adapter_driver map in.bin out.txt  the relocalisation / local-mapping / loop-closing searches (adapter/ORBmatcher_fuse.cc) the same way
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -202,9 +203,9 @@ static void dump_u8(FILE *f, const char *name, const std::vector<uint8_t> &v)
     for (size_t i = 0; i < v.size(); i++) fprintf(f, " %d", (int)v[i]);
     fprintf(f, "\n");
 }
-static void dump_capture(FILE *fo, const std::string &pre, bool points)
+static void dump_capture(FILE *fo, const std::string &pre, bool points, int slot = 0)
 {
-    const orbx_adapter::Capture &c = orbx_adapter::capture();
+    const orbx_adapter::Capture &c = orbx_adapter::capture(slot);
     dump_f(fo, (pre + "cur_x").c_str(), c.cx); dump_f(fo, (pre + "cur_y").c_str(), c.cy); dump_f(fo, (pre + "cur_angle").c_str(), c.cangle);
     dump_f(fo, (pre + "cur_uright").c_str(), c.curight); dump_i(fo, (pre + "cur_octave").c_str(), c.coctave);
     dump_u8(fo, (pre + "cur_occupied").c_str(), c.coccupied); dump_u8(fo, (pre + "cur_desc").c_str(), c.cdesc);
@@ -405,7 +406,176 @@ static int mode_track(const char *in_path, const char *voc_path, const char *out
     printf("adaptor track ok: %d / %d keypoints\n", cur.N, last.N);
     return 0;
 }
+// MapPoint::PredictScale (reference src/MapPoint.cc:393-415): level = ceil(log(maxDistance / dist) / log(scaleFactor)), clamped
+namespace ORB_SLAM2 {
+static int predict(float maxd, float dist, float logsf, int nlevels)
+{
+    const float ratio = maxd / dist;
+    int n = (int)ceil(log(ratio) / logsf);
+    if (n < 0) n = 0; else if (n >= nlevels) n = nlevels - 1;
+    return n;
+}
+int MapPoint::PredictScale(const float &currentDist, KeyFrame *pKF) { return predict(mfMaxDistance, currentDist, pKF->mfLogScaleFactor, pKF->mnScaleLevels); }
+int MapPoint::PredictScale(const float &currentDist, Frame *pF) { return predict(mfMaxDistance, currentDist, pF->mfLogScaleFactor, pF->mnScaleLevels); }
+}
+
+static void dump_points(FILE *fo, const char *name, const std::vector<MapPoint> &st, KeyFrame *pKF)
+{
+    // per point: bad, index of the point it was replaced by (-1 none; -2 a point of another store), observation index in pKF (-1 none), Observations()
+    fprintf(fo, "%s %zu", name, st.size() * 4);
+    for (size_t i = 0; i < st.size(); i++) {
+        MapPoint &P = const_cast<MapPoint &>(st[i]);
+        long long rep = -1;
+        if (P.mpReplaced) rep = (P.mpReplaced >= &st[0] && P.mpReplaced < &st[0] + st.size()) ? (long long)(P.mpReplaced - &st[0]) : -2;
+        fprintf(fo, " %d %lld %d %d", (int)P.mbBad, rep, P.GetIndexInKeyFrame(pKF), P.nObs);
+    }
+    fprintf(fo, "\n");
+}
+
+// local mapping / loop closing / relocalisation searches through adapter/ORBmatcher_fuse.cc
+static int mode_map(const char *in_path, const char *out_path)
+{
+    FILE *fi = fopen(in_path, "rb");
+    if (!fi) { fprintf(stderr, "cannot open %s\n", in_path); return 2; }
+    int hdr[2];
+    if (fread(hdr, 4, 2, fi) != 2) return 2;
+    const int w = hdr[0], h = hdr[1];
+    cv::Mat imL(h, w, CV_8UC1), imR(h, w, CV_8UC1);
+    if (fread(imL.data, 1, (size_t)w * h, fi) != (size_t)w * h || fread(imR.data, 1, (size_t)w * h, fi) != (size_t)w * h) return 2;
+    fclose(fi);
+    FILE *fo = fopen(out_path, "w");
+    if (!fo) return 2;
+    ORBextractor exL(1000, 1.2f, 8, 20, 7), exR(1000, 1.2f, 8, 20, 7);
+    std::vector<cv::KeyPoint> keysL, keysR;
+    cv::Mat descL, descR;
+    exL(imL, cv::Mat(), keysL, descL);
+    exR(imR, cv::Mat(), keysR, descR);
+    const std::vector<float> sf = exL.GetScaleFactors(), s2 = exL.GetScaleSigmaSquares(), is2 = exL.GetInverseScaleSigmaSquares();
+    dump_keys(fo, "keysL", keysL); dump_keys(fo, "keysR", keysR);
+    const int nL = (int)keysL.size(), nR = (int)keysR.size();
+    const float logsf = logf(1.2f);
+    // the keyframe the points are projected into: the left eye, with a pose
+    KeyFrame kfL, kfR;
+    std::vector<MapPoint> storeL, storeR;
+    std::vector<float> urL(nL, -1.f);
+    for (int i = 0; i < nL; i += 3) urL[i] = keysL[i].pt.x - 6.f;
+    fill_keyframe(kfL, keysL, descL, urL, storeL, 6, 3, sf, s2);
+    fill_keyframe(kfR, keysR, descR, std::vector<float>(), storeR, 5, 3, sf, s2);
+    KeyFrame *kk[2] = { &kfL, &kfR };
+    for (int k = 0; k < 2; k++) {
+        KeyFrame &K = *kk[k];
+        K.mbf = 386.1448f; K.mnScaleLevels = 8; K.mfLogScaleFactor = logsf; K.mvInvLevelSigma2 = is2;
+        K.mnMinX = 0; K.mnMinY = 0; K.mnMaxX = w; K.mnMaxY = h;
+        const cv::Mat T = pose(k == 0 ? 0.03f : -0.02f, 0.01f, k == 0 ? -0.1f : 0.05f);
+        K.Rcw = T.rowRange(0, 3).colRange(0, 3).clone(); K.tcw = T.rowRange(0, 3).col(3).clone();
+        K.Ow = -K.Rcw.t() * K.tcw;
+    }
+    // map points of the RIGHT keyframe's features, placed in the world so that they project into the LEFT keyframe 9 px right of their
+    // right-eye position at 6 .. 11 m; maxDistance chosen so that PredictScale returns about the feature's octave
+    for (int i = 0; i < nR; i++) {
+        MapPoint &P = storeR[i];
+        const float z = 6.f + (float)(i % 6), u = keysR[i].pt.x + 9.f, v = keysR[i].pt.y;
+        cv::Mat pc(3, 1, CV_32F);
+        pc.at<float>(0) = (u - kfL.cx) / kfL.fx * z; pc.at<float>(1) = (v - kfL.cy) / kfL.fy * z; pc.at<float>(2) = z;
+        P.mWorldPos = kfL.Rcw.t() * (pc - kfL.tcw);
+        const cv::Mat PO = P.mWorldPos - kfL.Ow;
+        const float dist = (float)cv::norm(PO);
+        P.mNormalVector = (i % 10 == 7 ? -1.0 : 1.0) / dist * PO;      // every tenth point is seen from behind: rejected by the viewing-angle test
+        P.mfMaxDistance = dist * powf(1.2f, (float)keysR[i].octave) * 0.95f;
+        P.mfMinDistance = i % 17 == 3 ? dist * 2.f : 0.05f;            // some fail the distance range
+        P.mDescriptor = descR.row(i).clone();
+        P.nObs = 1 + i % 4;
+        P.mObservations[&kfR] = (size_t)i;
+    }
+    for (int i = 0; i < nL; i++) {                                      // the left keyframe's own points (what Fuse may replace / be replaced by)
+        storeL[i].mDescriptor = descL.row(i).clone(); storeL[i].nObs = 1 + i % 5; storeL[i].mObservations[&kfL] = (size_t)i;
+        storeL[i].mWorldPos = cv::Mat(3, 1, CV_32F);
+        const float z = 7.f + (float)(i % 5);
+        cv::Mat pc(3, 1, CV_32F);
+        pc.at<float>(0) = (keysL[i].pt.x - 9.f - kfL.cx) / kfL.fx * z; pc.at<float>(1) = (keysL[i].pt.y - kfL.cy) / kfL.fy * z; pc.at<float>(2) = z;
+        storeL[i].mWorldPos = kfL.Rcw.t() * (pc - kfL.tcw);
+        storeL[i].mfMaxDistance = (float)cv::norm(storeL[i].mWorldPos - kfL.Ow) * powf(1.2f, (float)keysL[i].octave) * 0.95f;
+        storeL[i].mfMinDistance = 0.05f;
+        storeL[i].mNormalVector = (1.0 / cv::norm(storeL[i].mWorldPos - kfL.Ow)) * (storeL[i].mWorldPos - kfL.Ow);
+    }
+    const std::vector<MapPoint> storeR0 = storeR, storeL0 = storeL;
+    const std::vector<MapPoint *> mpL0 = kfL.mvpMapPoints, mpR0 = kfR.mvpMapPoints;
+    std::vector<MapPoint *> vpR(nR);
+    for (int i = 0; i < nR; i++) vpR[i] = &storeR[i];
+
+    // ---- 1. relocalisation: SearchByProjection(CurrentFrame, pKF = the right keyframe, sAlreadyFound, th, ORBdist)
+    {
+        Frame cur;
+        cur.N = nL; cur.mvKeys = keysL; cur.mvKeysUn = keysL; cur.mDescriptors = descL; cur.mvuRight = urL;
+        cur.mvScaleFactors = sf; cur.mnScaleLevels = 8; cur.mfLogScaleFactor = logsf; cur.mbf = 386.1448f; cur.mb = 0.537f;
+        cur.mTcw = pose(0.03f, 0.01f, -0.1f);                          // the left keyframe's pose
+        cur.mvpMapPoints.assign(nL, static_cast<MapPoint *>(NULL));
+        for (int i = 0; i < nL; i += 13) cur.mvpMapPoints[i] = &storeL[i];
+        std::set<MapPoint *> found;
+        for (int i = 0; i < nR; i += 19) found.insert(&storeR[i]);
+        ORBmatcher m(0.9f, true);
+        const int n = m.SearchByProjection(cur, &kfR, found, 10.f, 100);
+        dump_capture(fo, "reloc_", true);
+        dump_i(fo, "reloc_held", held(cur.mvpMapPoints, storeR)); dump_i(fo, "reloc_n", std::vector<int>(1, n));
+    }
+    // ---- 2. loop closing: SearchByProjection(pKF, Scw, vpPoints, vpMatched, th)
+    cv::Mat Scw = pose(0.03f, 0.01f, -0.1f);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) Scw.at<float>(r, c) *= 1.1f;   // s [R | t]
+    {
+        std::vector<MapPoint *> matched(nL, static_cast<MapPoint *>(NULL));
+        for (int i = 0; i < nL; i += 9) matched[i] = &storeL[i];
+        matched[1] = &storeR[40];                                       // a point of vpPoints that is already matched: skipped (:331)
+        ORBmatcher m(0.75f, true);
+        const int n = m.SearchByProjection(&kfL, Scw, vpR, matched, 10);
+        dump_capture(fo, "sim3p_", true);
+        dump_i(fo, "sim3p_held", held(matched, storeR)); dump_i(fo, "sim3p_n", std::vector<int>(1, n));
+    }
+    // ---- 3. local mapping: Fuse(pKF, vpMapPoints, th)
+    {
+        std::vector<MapPoint *> vp = vpR;
+        for (int i = 0; i < nR; i += 23) vp[i] = NULL;
+        for (int i = 5; i < nR; i += 29) storeR[i].mObservations[&kfL] = 0;   // already in the keyframe
+        ORBmatcher m(0.6f, true);
+        const int n = m.Fuse(&kfL, vp, 3.f);
+        dump_capture(fo, "fuse_", true);
+        dump_i(fo, "fuse_n", std::vector<int>(1, n));
+        dump_points(fo, "fuse_ptsR", storeR, &kfL); dump_points(fo, "fuse_ptsL", storeL, &kfL);
+        dump_i(fo, "fuse_kf_points", held(kfL.mvpMapPoints, storeR));
+        storeR = storeR0; storeL = storeL0; kfL.mvpMapPoints = mpL0;
+    }
+    // ---- 4. loop closing: Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)
+    {
+        std::vector<MapPoint *> repl(nR, static_cast<MapPoint *>(NULL));
+        ORBmatcher m(0.8f, true);
+        const int n = m.Fuse(&kfL, Scw, vpR, 4.f, repl);
+        dump_capture(fo, "fuse2_", true);
+        dump_i(fo, "fuse2_n", std::vector<int>(1, n));
+        dump_i(fo, "fuse2_replace", held(repl, storeL));
+        dump_points(fo, "fuse2_ptsR", storeR, &kfL);
+        dump_i(fo, "fuse2_kf_points", held(kfL.mvpMapPoints, storeR));
+        storeR = storeR0; storeL = storeL0; kfL.mvpMapPoints = mpL0;
+    }
+    // ---- 5. loop closing: SearchBySim3(pKF1 = left, pKF2 = right, vpMatches12, s12, R12, t12, th)
+    {
+        // the right keyframe's OWN features carry points that project into the left one (above); give the left keyframe's points the
+        // mirror property: storeL[i] projects into the right keyframe 9 px left of its left-eye position
+        kfR.Rcw = kfL.Rcw.clone(); kfR.tcw = kfL.tcw.clone(); kfR.Ow = kfL.Ow.clone();     // same pose: T12 = identity, s12 = 1
+        cv::Mat R12(3, 3, CV_32F), t12(3, 1, CV_32F);
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R12.at<float>(r, c) = r == c ? 1.f : 0.f; t12.at<float>(r) = 0.f; }
+        std::vector<MapPoint *> m12(nL, static_cast<MapPoint *>(NULL));
+        for (int i = 0; i < nL; i += 31) if (kfL.mvpMapPoints[i]) m12[i] = &storeR[(i * 3) % nR];   // already matched pairs
+        ORBmatcher m(0.75f, true);
+        const int n = m.SearchBySim3(&kfL, &kfR, m12, 1.0f, R12, t12, 7.5f);
+        dump_capture(fo, "sim3_12_", true, 0); dump_capture(fo, "sim3_21_", true, 1);
+        dump_i(fo, "sim3_held", held(m12, storeR)); dump_i(fo, "sim3_n", std::vector<int>(1, n));
+    }
+    dump_mat(fo, "descL", descL); dump_mat(fo, "descR", descR);
+    fclose(fo);
+    printf("adaptor map ok: %d / %d keypoints\n", nL, nR);
+    return 0;
+}
 #endif
+
 
 int main(int argc, char **argv)
 {
@@ -414,6 +584,7 @@ int main(int argc, char **argv)
         if (argc >= 4 && !strcmp(argv[1], "run")) return mode_run(argv[2], argv[3]);
 #ifdef ORBX_ADAPTER_CAPTURE
         if (argc >= 5 && !strcmp(argv[1], "track")) return mode_track(argv[2], argv[3], argv[4]);
+        if (argc >= 4 && !strcmp(argv[1], "map")) return mode_map(argv[2], argv[3]);
 #endif
     } catch (const std::exception &e) {
         fprintf(stderr, "exception: %s\n", e.what());

@@ -11,7 +11,7 @@ namespace ORB_SLAM2 {
 class Frame
 {
 public:
-    Frame() : mpORBextractorLeft(NULL), mpORBextractorRight(NULL), mbf(0), mb(0), N(0), mnScaleLevels(0) {}
+    Frame() : mpORBextractorLeft(NULL), mpORBextractorRight(NULL), mbf(0), mb(0), N(0), mnScaleLevels(0), mfLogScaleFactor(0) {}
     void ComputeStereoMatches();
     void ComputeBoW();              // defined by adapter/Frame_bow.cc
     void UndistortKeyPoints();      // defined by adapter/Frame_bow.cc
@@ -22,6 +22,7 @@ public:
     float mbf, mb;
     int N;
     int mnScaleLevels;
+    float mfLogScaleFactor;
     std::vector<float> mvScaleFactors;
     std::vector<bool> mvbOutlier;
     cv::Mat mTcw, mK, mDistCoef;

@@ -5,6 +5,7 @@
 #define CVSTUB_CORE_H
 
 #include <assert.h>
+#include <math.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
@@ -80,6 +81,18 @@ public:
     }
     Mat clone() const { Mat m(rows, cols, type_); for (int r = 0; r < rows; r++) memcpy(m.data + r * m.step, data + r * step, (size_t)cols * elemSize()); return m; }
     void copyTo(const _OutputArray &dst) const;
+    double dot(const Mat &o) const
+    {
+        assert(type_ == CV_32F && o.type_ == CV_32F && total() == o.total());
+        double acc = 0;
+        for (int r = 0; r < rows; r++)
+            for (int c = 0; c < cols; c++) {
+                const size_t k = (size_t)r * cols + c;     // the other operand may be a row against a column of the same length
+                acc += (double)*reinterpret_cast<const float *>(data + (size_t)r * step + (size_t)c * 4) *
+                       *reinterpret_cast<const float *>(o.data + (k / o.cols) * o.step + (k % o.cols) * 4);
+            }
+        return acc;
+    }
     template <typename T> T &at(int r, int c) { return *reinterpret_cast<T *>(data + (size_t)r * step + (size_t)c * sizeof(T)); }
     template <typename T> const T &at(int r, int c) const { return *reinterpret_cast<const T *>(data + (size_t)r * step + (size_t)c * sizeof(T)); }
     template <typename T> T &at(int i) { return cols == 1 ? at<T>(i, 0) : at<T>(0, i); }
@@ -113,6 +126,25 @@ inline Mat operator+(const Mat &a, const Mat &b)
         for (int j = 0; j < a.cols; j++) c.at<float>(i, j) = a.at<float>(i, j) + b.at<float>(i, j);
     return c;
 }
+
+inline Mat operator-(const Mat &a, const Mat &b)
+{
+    assert(a.type() == CV_32F && a.rows == b.rows && a.cols == b.cols);
+    Mat c(a.rows, a.cols, CV_32F);
+    for (int i = 0; i < a.rows; i++)
+        for (int j = 0; j < a.cols; j++) c.at<float>(i, j) = a.at<float>(i, j) - b.at<float>(i, j);
+    return c;
+}
+inline Mat operator*(double k, const Mat &a)
+{
+    assert(a.type() == CV_32F);
+    Mat c(a.rows, a.cols, CV_32F);
+    for (int i = 0; i < a.rows; i++)
+        for (int j = 0; j < a.cols; j++) c.at<float>(i, j) = (float)(a.at<float>(i, j) * k);
+    return c;
+}
+inline Mat operator/(const Mat &a, double k) { return (1.0 / k) * a; }
+inline double norm(const Mat &a) { return sqrt(a.dot(a)); }
 
 inline Mat operator-(const Mat &a)
 {

@@ -17,8 +17,8 @@ import pytest
 from tools import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ADAPTER = [os.path.join(ROOT, "adapter", f) for f in ("ORBextractor.cc", "Frame_stereo.cc", "ORBmatcher_bow.cc", "ORBmatcher_proj.cc", "Frame_bow.cc",
-                                                       "MapPoint_distinctive.cc")]
+ADAPTER = [os.path.join(ROOT, "adapter", f) for f in ("ORBextractor.cc", "Frame_stereo.cc", "ORBmatcher_bow.cc", "ORBmatcher_proj.cc", "ORBmatcher_fuse.cc",
+                                                       "Frame_bow.cc", "MapPoint_distinctive.cc")]
 INC = ["-I", os.path.join(ROOT, "adapter"), "-I", os.path.join(ROOT, "tests", "cvstub"), "-I", os.path.join(ROOT, "include")]
 REF = "/root/reference"
 
@@ -69,7 +69,7 @@ def _decls(text, names):
 def test_signatures_match_the_reference_header():
     """every ORBmatcher method an adaptor defines is declared in tests/cvstub/ORBmatcher.h with the parameter types the reference's
     include/ORBmatcher.h (:41-83) gives it: the stand-in header cannot drift from the interface the drop-in has to meet"""
-    names = {"SearchByProjection", "SearchByBoW", "SearchForInitialization", "SearchForTriangulation"}
+    names = {"SearchByProjection", "SearchByBoW", "SearchForInitialization", "SearchForTriangulation", "SearchBySim3", "Fuse"}
     ref = _decls(open(os.path.join(REF, "include/ORBmatcher.h"), errors="replace").read(), names)
     stub = _decls(open(os.path.join(ROOT, "tests/cvstub/ORBmatcher.h")).read(), names)
     assert stub, "no declarations parsed"
@@ -231,10 +231,11 @@ def test_adapter_tracking_searches(pkg, oracle, tmp_path):
         # the prologue's projection: each point was placed to project 12 px right of its right-eye position (float32 round trips)
         assert np.abs(pts["u"][ok] - (kR["x"][ok] + 12)).max() < 0.05 and np.abs(pts["v"][ok] - kR["y"][ok]).max() < 0.05
         assert np.abs(1.0 / pts["aux"][ok] - (8 + iR[ok] % 7)).max() < 1e-3
-        exp, en = oracle.search_by_projection_last(cur, pts, sf, 15.0, direction, 386.1448, True)
+        exp, en = oracle.search_by_projection_last(cur, pts, sf, 15.0, direction, 386.1448, 3)   # 3: orientation check + cleared features marked -2
         held = r[pre + "held"]
-        before = np.where(np.arange(nL) % 11 == 0, -2, -1)
-        assert int(r[pre + "n"][0]) == en and (held == np.where(exp >= 0, exp, before)).all(), pre
+        before = np.where(np.arange(nL) % 11 == 0, -2, -1)        # (-2 in `held`: the feature still holds the point it held before the search)
+        # a feature the rotation filter cleared ends NULL as in the reference (:1526-1545), also when it held a point before
+        assert int(r[pre + "n"][0]) == en and (held == np.where(exp >= 0, exp, np.where(exp == -2, -1, before))).all(), pre
         assert en > 30
     # ---- SearchByProjection(F, vpMapPoints)
     cur, pts = _cur(r, "local_"), _pts(r, "local_")
@@ -273,3 +274,108 @@ def test_adapter_tracking_searches(pkg, oracle, tmp_path):
             continue
         best = oracle.distinctive_descriptor(np.array(rows, np.uint8))
         assert got[p, 0] == 1 and (got[p, 1:] == rows[best]).all(), p
+
+
+@pytest.mark.gpu
+def test_adapter_map_searches(pkg, oracle, tmp_path):
+    """relocalisation, local-mapping and loop-closing searches through the COMPILED adapter/ORBmatcher_fuse.cc: SearchByProjection(Frame, KeyFrame, ...),
+    SearchByProjection(KeyFrame, Scw, ...), both Fuse overloads (with the map surgery the adaptor applies in the reference's order, replayed here
+    from the oracle's answer) and SearchBySim3 -- each against the CPU oracle fed with exactly what the adaptor handed to the ABI"""
+    w, h = 1241, 376
+    left, right, _ = synth.stereo_pair(519, w, h)
+    inp, outp = os.path.join(tmp_path, "in.bin"), os.path.join(tmp_path, "out.txt")
+    with open(inp, "wb") as f:
+        f.write(np.array([w, h], np.int32).tobytes()); f.write(left.tobytes()); f.write(right.tobytes())
+    exe = _build_driver(str(tmp_path))
+    run = subprocess.run([exe, "map", inp, outp], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    r = _parse(outp)
+    oL, oR = oracle.Oracle(1000, 1.2, 8, 20, 7), oracle.Oracle(1000, 1.2, 8, 20, 7)
+    kL, dL = oL.extract(left); kR, dR = oR.extract(right)
+    assert _keys(r["keysL"], pkg).tobytes() == kL.tobytes() and _keys(r["keysR"], pkg).tobytes() == kR.tobytes()
+    nL, nR = len(kL), len(kR)
+    sf = np.asarray(oL.scale_factors(), np.float32); inv2 = np.asarray(oL.inv_level_sigma2(), np.float32)
+    iL, iR = np.arange(nL), np.arange(nR)
+    has_L, bad_L = iL % 3 != 2, iL % 6 == 1          # tests/adapter_driver.cc: fill_keyframe(kfL, ..., bad_every 6, none_every 3)
+    has_R, bad_R = iR % 3 != 2, iR % 5 == 1
+    # ---- 1. relocalisation
+    cur, pts = _cur(r, "reloc_"), _pts(r, "reloc_")
+    assert cur["desc"].tobytes() == dL.tobytes() and (cur["occupied"] == (iL % 13 == 0)).all()
+    assert not (pts["valid"] & ~(has_R & ~bad_R & (iR % 19 != 0))).any() and pts["valid"].sum() > 300
+    ok = pts["valid"] == 1
+    assert np.abs(pts["u"][ok] - (kR["x"][ok] + 9)).max() < 0.05 and np.abs(pts["v"][ok] - kR["y"][ok]).max() < 0.05   # the projection prologue
+    assert (np.abs(pts["level"][ok] - kR["octave"][ok]) <= 1).all()                                                       # PredictScale
+    exp, en = oracle.search_by_projection_keyframe(cur, pts, sf, 10.0, 100, 3)
+    before = np.where(iL % 13 == 0, -2, -1)
+    assert int(r["reloc_n"][0]) == en and (r["reloc_held"] == np.where(exp >= 0, exp, np.where(exp == -2, -1, before))).all() and en > 30
+    # ---- 2. SearchByProjection(pKF, Scw, vpPoints, vpMatched, th)
+    kf, pts = _cur(r, "sim3p_"), _pts(r, "sim3p_")
+    occ = (iL % 9 == 0); occ[1] = True
+    assert (kf["occupied"] == occ).all()
+    assert not (pts["valid"] & ~(~bad_R & (iR != 40) & (iR % 10 != 7) & (iR % 17 != 3))).any() and pts["valid"].sum() > 300
+    exp, en = oracle.search_by_projection_sim3(kf, pts, sf, 10.0)
+    before = np.where(iL % 9 == 0, -2, -1); before[1] = 40
+    assert int(r["sim3p_n"][0]) == en and (r["sim3p_held"] == np.where(exp >= 0, exp, before)).all() and en > 30
+    # ---- 3. Fuse(pKF, vpMapPoints, th): replay the adaptor's map surgery (src/ORBmatcher.cc:1011-1033) from the oracle's best keypoints
+    kf, pts = _cur(r, "fuse_"), _pts(r, "fuse_")
+    best, _bd, _nf = oracle.window_best(kf, pts, sf, inv2, 3.0, 1, 50)
+    in_kf = np.where((iR >= 5) & ((iR - 5) % 29 == 0), 0, -1)
+    assert not (pts["valid"] & ~((iR % 23 != 0) & ~bad_R & (in_kf < 0))).any()
+    badR, badL = bad_R.copy(), bad_L.copy()
+    obsR, obsL = 1 + iR % 4, 1 + iL % 5
+    repR, repL = np.full(nR, -1), np.full(nL, -1)
+    kfpt = [("L", j) if has_L[j] else None for j in range(nL)]
+    nfused = 0
+    for i in range(nR):
+        if best[i] < 0 or i % 23 == 0 or badR[i] or in_kf[i] >= 0:
+            continue
+        holder = kfpt[best[i]]
+        if holder is not None:
+            kind, j = holder
+            hbad = badL[j] if kind == "L" else badR[j]
+            if not hbad:
+                hobs = obsL[j] if kind == "L" else obsR[j]
+                if hobs > obsR[i]:
+                    badR[i] = True; repR[i] = -2 if kind == "L" else j
+                elif kind == "L":
+                    badL[j] = True; repL[j] = -2
+                else:
+                    badR[j] = True; repR[j] = i
+        else:
+            in_kf[i] = best[i]; obsR[i] += 1; kfpt[best[i]] = ("R", i)
+        nfused += 1
+    assert int(r["fuse_n"][0]) == nfused and nfused > 30
+    gR, gL = r["fuse_ptsR"].reshape(-1, 4), r["fuse_ptsL"].reshape(-1, 4)
+    assert (gR[:, 0] == badR).all() and (gR[:, 1] == repR).all() and (gR[:, 2] == in_kf).all() and (gR[:, 3] == obsR).all()
+    assert (gL[:, 0] == badL).all() and (gL[:, 1] == repL).all()
+    assert (r["fuse_kf_points"] == np.array([-1 if p_ is None else (-2 if p_[0] == "L" else p_[1]) for p_ in kfpt])).all()
+    # ---- 4. Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)
+    kf, pts = _cur(r, "fuse2_"), _pts(r, "fuse2_")
+    best, _bd, _nf = oracle.window_best(kf, pts, sf, None, 4.0, 0, 50)
+    in_kf = np.full(nR, -1); obsR = 1 + iR % 4
+    kfpt = [("L", j) if has_L[j] else None for j in range(nL)]
+    repl = np.full(nR, -1)
+    nfused = 0
+    for i in range(nR):
+        if best[i] < 0:
+            continue
+        holder = kfpt[best[i]]
+        if holder is not None:
+            kind, j = holder
+            if not (bad_L[j] if kind == "L" else bad_R[j]):
+                repl[i] = j if kind == "L" else -2
+        else:
+            in_kf[i] = best[i]; obsR[i] += 1; kfpt[best[i]] = ("R", i)
+        nfused += 1
+    assert int(r["fuse2_n"][0]) == nfused and nfused > 30 and (r["fuse2_replace"] == repl).all()
+    gR = r["fuse2_ptsR"].reshape(-1, 4)
+    assert (gR[:, 2] == in_kf).all() and (gR[:, 3] == obsR).all()
+    assert (r["fuse2_kf_points"] == np.array([-1 if p_ is None else (-2 if p_[0] == "L" else p_[1]) for p_ in kfpt])).all()
+    # ---- 5. SearchBySim3: slot 0 = (KF2 features, KF1's points projected into KF2), slot 1 = (KF1 features, KF2's points projected into KF1)
+    kf2, p12 = _cur(r, "sim3_12_"), _pts(r, "sim3_12_")
+    kf1, p21 = _cur(r, "sim3_21_"), _pts(r, "sim3_21_")
+    assert kf1["desc"].tobytes() == dL.tobytes() and kf2["desc"].tobytes() == dR.tobytes()
+    pre = np.where((iL % 31 == 0) & has_L, (iL * 3) % nR, -1)
+    assert not (p12["valid"] & ~(has_L & ~bad_L & (pre < 0))).any() and p12["valid"].sum() > 200 and p21["valid"].sum() > 200
+    exp, en = oracle.search_by_sim3(kf1, kf2, p12, p21, sf, sf, 7.5)
+    assert int(r["sim3_n"][0]) == en and (r["sim3_held"] == np.where(exp >= 0, exp, pre)).all() and en > 20
