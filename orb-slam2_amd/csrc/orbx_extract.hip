@@ -694,12 +694,34 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
     const int N = L.quota;
     for (int k = tid; k < L.n_ini; k += NT) cc[k] = 0;
     __syncthreads();
-    FOR_POINTS({
-        int r = (int)((float)(p & 0xFFF) / L.hx);
-        r = r < 0 ? 0 : r >= L.n_ini ? L.n_ini - 1 : r;
-        atomicAdd(&cc[r], 1);
-        nd = (unsigned)r;
-    });
+    // With a handful of roots (3 for a 1241 x 376 level) every point of the level would hit one of 3 LDS addresses: same-address LDS
+    // atomics serialise lane by lane, and this pass and the first classification were 27 % of a level-0 tree (36 k cycles).  A thread
+    // owns at most 15 points per pass, so it counts them in 4-bit fields of one 64-bit register; the fields are summed over the wave
+    // on the DPP path and lane 0 adds each total once: T atomics per wave instead of one per point.
+    auto add_packed = [&](unsigned long long acc, int T, int *dst) {
+        for (int t = 0; t < T; t++) {                                   // T <= 16, wave-uniform
+            const int s = wave_sum((int)((acc >> (4 * t)) & 15ull));
+            if ((tid & 63) == 0 && s) atomicAdd(&dst[t], s);
+        }
+    };
+    const bool few_pts_per_thread = in_regs ? RP <= 15 : (n + NT - 1) / NT <= 15;
+    if (L.n_ini <= 16 && few_pts_per_thread) {
+        unsigned long long acc = 0;
+        FOR_POINTS({
+            int r = (int)((float)(p & 0xFFF) / L.hx);
+            r = r < 0 ? 0 : r >= L.n_ini ? L.n_ini - 1 : r;
+            acc += 1ull << (4 * r);
+            nd = (unsigned)r;
+        });
+        add_packed(acc, L.n_ini, cc);
+    } else {
+        FOR_POINTS({
+            int r = (int)((float)(p & 0xFFF) / L.hx);
+            r = r < 0 ? 0 : r >= L.n_ini ? L.n_ini - 1 : r;
+            atomicAdd(&cc[r], 1);
+            nd = (unsigned)r;
+        });
+    }
     __syncthreads();
     for (int k = tid; k < L.n_ini; k += NT) a1[k] = cc[k] > 0;
     __syncthreads();
@@ -730,7 +752,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
     };
     for (int k = tid; k < 4 * m; k += NT) cc[k] = 0;
     __syncthreads();
-    FOR_POINTS({ const int id = (int)nd; nd = (unsigned)(id | (classify(id, p, cnt, box, cc) << NB)); });
+    if (4 * m <= 16 && few_pts_per_thread) {       // the same for the first classification: at most 16 (root, child) counters
+        unsigned long long acc = 0;
+        FOR_POINTS({
+            const int id = (int)nd;
+            int c = 0;
+            if (cnt[id] > 1) {
+                const uint2 bx = box[id];
+                const int x0 = bx.x & 0xFFFF, x1 = bx.x >> 16, y0 = bx.y & 0xFFFF, y1 = bx.y >> 16;
+                const int x = p & 0xFFF, y = (p >> 12) & 0xFFF;
+                const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
+                c = (x >= x0 + hx ? 1 : 0) + (y >= y0 + hy ? 2 : 0);
+                acc += 1ull << (4 * (id * 4 + c));
+            }
+            nd = (unsigned)(id | (c << NB));
+        });
+        add_packed(acc, 4 * m, cc);
+    } else {
+        FOR_POINTS({ const int id = (int)nd; nd = (unsigned)(id | (classify(id, p, cnt, box, cc) << NB)); });
+    }
     bool phase2 = false;
     TSTAMP(1);  // roots + first classification
     for (;;) {

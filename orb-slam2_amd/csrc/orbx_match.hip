@@ -618,7 +618,7 @@ static size_t side_bytes(int mp, bool geom) { return (size_t)mp * (geom ? 48 : 4
 
 // device-resident keyframe / frame
 struct orbx_kf {
-    int device, n, nnodes, m, mp, geom;
+    int device, n, nnodes, m, mp, geom, max_octave;
     uint8_t *d_block;
     std::vector<uint32_t> node_id, feat;
     std::vector<int32_t> node_off;
@@ -639,8 +639,11 @@ extern "C" int orbx_kf_create(int device, const orbx_featset *fs, orbx_kf **out)
     k->m = fs->nnodes ? fs->node_off[fs->nnodes] : 0;
     k->mp = m_pad4(k->m);
     k->d_block = nullptr;
-    if (geom) for (int i = 0; i < fs->n; i++)
+    k->max_octave = 0;
+    if (geom) for (int i = 0; i < fs->n; i++) {
         if (fs->octave[i] < 0 || fs->octave[i] >= ORBX_MAX_LEVELS) { delete k; orbx_set_error("orbx_kf_create: octave out of range"); return ORBX_E_INVALID; }
+        if (fs->octave[i] > k->max_octave) k->max_octave = fs->octave[i];
+    }
     k->node_id.assign(fs->node_id, fs->node_id + fs->nnodes);
     if (fs->nnodes) k->node_off.assign(fs->node_off, fs->node_off + fs->nnodes + 1); else k->node_off.assign(1, 0);
     k->feat.assign(fs->feat, fs->feat + k->m);
@@ -1042,7 +1045,10 @@ extern "C" int orbx_kf_search_for_triangulation(const orbx_kf *k1, const uint8_t
     int rc = kf_sides(k1, flag1, k2s, flags2, n2, sides, pa, pb, who);
     if (rc) return rc;
     if (!k1->geom) { orbx_set_error("%s: keyframe made without positions / octaves / u_right", who); return ORBX_E_INVALID; }
-    for (int i = 0; i < n2; i++) if (!k2s[i]->geom) { orbx_set_error("%s: keyframe %d made without positions / octaves / u_right", who, i); return ORBX_E_INVALID; }
+    for (int i = 0; i < n2; i++) {
+        if (!k2s[i]->geom) { orbx_set_error("%s: keyframe %d made without positions / octaves / u_right", who, i); return ORBX_E_INVALID; }
+        if (k2s[i]->max_octave >= nlevels2) { orbx_set_error("%s: keyframe %d has octave %d, tables have %d levels", who, i, k2s[i]->max_octave, nlevels2); return ORBX_E_INVALID; }
+    }
     rc = match_call(2, k1->device, sides.data(), n2 + 1, pa.data(), pb.data(), n2, F12s, epipoles, sf2, sig2, nlevels2, 0.f, check_orientation, only_stereo,
                     cap, pairs, 2 * (size_t)cap, npairs);
     if (rc) return rc;
