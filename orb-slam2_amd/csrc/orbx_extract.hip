@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
                 const unsigned any = (dark | bright) & vmask;
                 // bits 7, 15, 23, 31 -> one nibble: the multiplier routes bit 8k of (any >> 7) to bit 24 + k, no carries
                 const unsigned nib = (((any >> 7) * 0x01020408u) >> 24) << bm_sh;
-                atomicOr(pb, nib);   // rows >= dh of the last iteration land in bitmap rows that are never read
+                if (nib) atomicOr(pb, nib);   // rows >= dh of the last iteration land in bitmap rows that are never read
             }
         }
         __syncthreads();
@@ -452,13 +452,14 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
         auto mark_maxima = [&](int n) {
             for (int i0 = 0; i0 < n; i0 += 64) {
                 const int i = i0 + lane;
-                const int e = list[min(i, n - 1)], py = e >> 6, px = e & 63;
-                const uint8_t *c = sc + (py + 1) * SP + px + 1;
-                const int s = c[0];
-                const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)c[-SP - 1], (int)c[-SP])),
-                                   max(max((int)c[-SP + 1], (int)c[SP - 1]), max((int)c[SP], (int)c[SP + 1])));
-                const bool is_max = (i < n) & (s > nb);   // s > nb >= 0 implies a corner at th_cur
-                atomicOr(sv + 2 * py + (px >> 5), is_max ? 1u << (px & 31) : 0u);
+                if (i < n) {          // lanes without an entry issue no LDS traffic at all (an LDS atomic costs per active lane, also one that ORs a zero)
+                    const int e = list[i], py = e >> 6, px = e & 63;
+                    const uint8_t *c = sc + (py + 1) * SP + px + 1;
+                    const int s = c[0];
+                    const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)c[-SP - 1], (int)c[-SP])),
+                                       max(max((int)c[-SP + 1], (int)c[SP - 1]), max((int)c[SP], (int)c[SP + 1])));
+                    if (s > nb) atomicOr(sv + 2 * py + (px >> 5), 1u << (px & 31));   // s > nb >= 0 implies a corner at th_cur
+                }
             }
         };
         if (nlist <= ORBX_FAST_LIST_CAP) {
