@@ -74,6 +74,11 @@ void orbx_extractor_destroy(orbx_extractor *e);
 int orbx_extractor_set_cv_profile(orbx_extractor *e, int profile);
 int orbx_gaussian_taps(int profile, int taps[7]);
 
+/* Tuning, no effect on results: extractions of at most `max_images` images per launch build the pyramid (ComputePyramid,
+ * src/ORBextractor.cc:1347-1370) with two launches that each produce several levels (a single frame's time is its chain of dependent
+ * launches); larger batches keep one launch per level, which moves fewer bytes.  Default 8; 0 = always one launch per level. */
+int orbx_extractor_set_pyramid_group_limit(orbx_extractor *e, int max_images);
+
 /* getters: GetLevels / GetScaleFactor / GetScaleFactors / GetInverseScaleFactors /
  * GetScaleSigmaSquares / GetInverseScaleSigmaSquares (include/ORBextractor.h:78-98).
  * Each output array has nlevels entries; NULL pointers are skipped. */
@@ -431,6 +436,9 @@ int orbx_distinctive_descriptors(int device, const uint8_t *desc, const int32_t 
 
 enum { ORBX_STAGE_RESIZE = 0, ORBX_STAGE_FAST = 1, ORBX_STAGE_TREE = 2, ORBX_STAGE_DESC = 3,
        ORBX_STAGE_STEREO = 4, ORBX_STAGE_STEREO_CUT = 5, ORBX_STAGE_COUNT = 6 };
+/* (ORBX_STAGE_STEREO_CUT is kept for the numbering only: the median cut of src/Frame.cc:737-750 now runs inside the stereo launch,
+ * in the last workgroup of each pair, and the row table of :584-604 inside the descriptor launch -- their times are part of
+ * ORBX_STAGE_STEREO / ORBX_STAGE_DESC and this stage reads 0.) */
 /* enable: record HIP events around every kernel launch of this handle (on the launch stream) */
 int orbx_profile_enable(orbx_extractor *e, int enable);
 /* Which stages record events while profiling is enabled: bit ORBX_STAGE_* (default: all).  An event between two kernels costs a

@@ -190,6 +190,84 @@ __global__ __launch_bounds__(256) void k_resize_direct(const Geom *__restrict__ 
     *reinterpret_cast<uint32_t *>(dst + (long long)y * D.pitch + x4) = out;
 }
 
+// ---------------------------------------------------------------- K1g: several pyramid levels per launch (small launches)
+// A single frame's pyramid is seven dependent launches of a few microseconds of work each: its time is the launch chain (7 x 5 us), not
+// the pixels.  k_pyr_group shortens the chain: a workgroup owns one tile of the LAST level of a group of consecutive levels and computes,
+// level by level through two LDS buffers, every pixel of the earlier levels that tile depends on (host tables: per tile column / row and
+// level the region [lo, hi) and the part [lo, own_hi) it also writes to the pyramid -- the regions of neighbouring tiles overlap by the
+// interpolation halo, the owned parts tile each level exactly).  The halo pixels are computed twice (1.4 x the pixels for five levels on
+// 32 x 16 tiles), which is why batches keep k_resize; the arithmetic per pixel is k_resize's, from the same coefficient tables.
+#define ORBX_PYR_GROUP_MAX 7
+#define PG_TW 32
+#define PG_TH 16
+#define PG_NT 512
+#define PG_LDS_LIMIT (64 * 1024)
+struct PyrGroupLevel { int w, h, pitch, tab_x, tab_y, pad; long long pyr_off; };
+struct PyrGroupArgs {
+    int n, s_level0, s_w, s_h, s_pitch, tab_cx, tab_cy, lds_b;
+    long long s_off;
+    PyrGroupLevel lv[ORBX_PYR_GROUP_MAX];
+};
+#define PG_CX_REC 8     // int16 units per (tile column, step): lo, hi, own_hi, dwords per source row (step 0), magic lo, magic hi, 0, 0
+#define PG_CY_REC 4     // per (tile row, step): lo, hi, own_hi, 0
+
+extern __shared__ __align__(16) uint8_t pg_smem[];
+
+__global__ __launch_bounds__(PG_NT) void k_pyr_group(const PyrGroupArgs A, PyrRef pr, uint8_t *__restrict__ pyr_w, const int16_t *__restrict__ tabs)
+{
+    const int b = blockIdx.z, tid = threadIdx.x;
+    const int16_t *cx = tabs + A.tab_cx + (int)blockIdx.x * PG_CX_REC * (A.n + 1);
+    const int16_t *cy = tabs + A.tab_cy + (int)blockIdx.y * PG_CY_REC * (A.n + 1);
+    const int spitch = A.s_level0 ? pr.img0_pitch : A.s_pitch;
+    const uint8_t *src = A.s_level0 ? pr.img0 + (long long)b * pr.img0_stride : pr.pyr + (long long)b * pr.pyr_stride + A.s_off;
+    uint8_t *cur = pg_smem, *nxt = pg_smem + A.lds_b;
+    int ox = cx[0], oy = cy[0], cp;             // origin and pitch of the region in `cur`
+    {
+        const int rows = cy[1] - oy, ndw = cx[3];
+        const unsigned magic = (unsigned)(uint16_t)cx[4] | ((unsigned)(uint16_t)cx[5] << 16);
+        cp = 4 * ndw;
+        if ((((uintptr_t)src | (unsigned)spitch) & 3) == 0) {       // ox is a multiple of 4: whole aligned dwords, never past the row's pitch
+            for (int i = tid; i < rows * ndw; i += PG_NT) {
+                const int r = ndw == 1 ? i : (int)__umulhi((unsigned)i, magic), c = i - r * ndw;   // (2^32 / 1 has no 32-bit magic)
+                reinterpret_cast<uint32_t *>(cur)[i] = *reinterpret_cast<const uint32_t *>(src + (long long)(oy + r) * spitch + ox + 4 * c);
+            }
+        } else {                                                     // a caller's level-0 image at an odd address or pitch: bytes inside the row only
+            const int wb = min(cp, A.s_w - ox);
+            for (int i = tid; i < rows * cp; i += PG_NT) {
+                const int r = i / cp, c = i - r * cp;
+                if (c < wb) cur[i] = src[(long long)(oy + r) * spitch + ox + c];
+            }
+        }
+    }
+    __syncthreads();
+    int s_w = A.s_w, s_h = A.s_h;
+    for (int k = 1; k <= A.n; k++) {
+        const PyrGroupLevel &L = A.lv[k - 1];
+        const int16_t *qx_ = cx + PG_CX_REC * k, *qy_ = cy + PG_CY_REC * k;
+        const int lx = qx_[0], hx = qx_[1], own_x = qx_[2], ly = qy_[0], hy = qy_[1], own_y = qy_[2];
+        const unsigned magic = (unsigned)(uint16_t)qx_[4] | ((unsigned)(uint16_t)qx_[5] << 16);
+        const int rw = hx - lx, rh = hy - ly, dp = (rw + 3) & ~3;
+        const int16_t *tx = tabs + L.tab_x, *ty = tabs + L.tab_y;
+        uint8_t *dst = pyr_w + (long long)b * pr.pyr_stride + L.pyr_off;
+        const bool keep = k < A.n;               // the last level of the group is only written out
+        for (int i = tid; i < rw * rh; i += PG_NT) {
+            const int yy = rw == 1 ? i : (int)__umulhi((unsigned)i, magic), xx = i - yy * rw;
+            const int x = lx + xx, y = ly + yy;
+            const short4 qx = *reinterpret_cast<const short4 *>(tx + 4 * x), qy = *reinterpret_cast<const short4 *>(ty + 4 * y);
+            const int sx0 = qx.x, sx1 = min(sx0 + 1, s_w - 1), sy0 = qy.x, sy1 = min(sy0 + 1, s_h - 1);
+            const uint8_t *r0 = cur + (sy0 - oy) * cp - ox, *r1 = cur + (sy1 - oy) * cp - ox;
+            const int t0 = r0[sx0] * qx.y + r0[sx1] * qx.z;
+            const int t1 = r1[sx0] * qx.y + r1[sx1] * qx.z;
+            const int v = (((qy.y * (t0 >> 4)) >> 16) + ((qy.z * (t1 >> 4)) >> 16) + 2) >> 2;   // in [0, 255], see k_resize
+            if (keep) nxt[yy * dp + xx] = (uint8_t)v;
+            if (x < own_x && y < own_y) dst[(long long)y * L.pitch + x] = (uint8_t)v;
+        }
+        __syncthreads();
+        { uint8_t *t = cur; cur = nxt; nxt = t; }
+        ox = lx; oy = ly; cp = dp; s_w = L.w; s_h = L.h;
+    }
+}
+
 // ================================================================ K2: FAST per cell (E3)
 // cornerScore<16> without a threshold: with x_k the 16 ring pixels, A = max over the 16 arcs of 9
 // contiguous ring pixels of min(v - x) = v - min_arcs(max_arc x) and B = max_arcs(min_arc x) - v.
@@ -951,25 +1029,117 @@ struct DescArgs {
 };
 
 // NL = 8 or ORBX_MAX_LEVELS: the level search and the count sums below are unrolled over NL levels (ORB-SLAM2 uses 8)
+// The row table of Frame::ComputeStereoMatches (vRowIndices, src/Frame.cc:584-604) as a by-product of the extraction: it depends only
+// on the keypoints' rows, octaves and columns, which the quadtree has already fixed, so ONE extra wave per image builds it inside the
+// k_desc launch while the other waves compute descriptors (a launch of its own, k_stereo_prep, was 10 us of a single frame's 124 us
+// chain).  orbx_stereo_match_batch_device uses it when it is handed the very keypoint buffer this extraction wrote; any other caller
+// of the stereo matcher still gets k_stereo_prep.  Layout (see orbx_stereo.hip): CSR by the keypoint's centre row, row_off[rows + 1],
+// one entry (iR | octave << 16, x, minr | maxr << 16, 0) per keypoint.
+struct RowTabArgs { int *row_off; uint4 *entries; int ent_cap, rows, on, pad; };
+#define ORBX_ROWTAB_MAX_ROWS 600    // a 256-byte level table + two int arrays of rows + 4 entries in k_desc's 5096 bytes of LDS
+
+template <int NL>
+__device__ __forceinline__ void desc_rowtab(const DescArgs &da, const int *__restrict__ lc, const uint32_t *__restrict__ kp_img, int cap,
+                                            const RowTabArgs &rt, int b, int *cnt, int *cur, int4 *lvtab)
+{
+    // The wave is alone on its critical path (it must not outlast the descriptor waves of its launch, ~12 us for a single frame), so
+    // everything is arranged for few dependent steps: all staging slots are fetched at once (CH per lane, in registers for both
+    // passes), the per-level constants come from one LDS read per slot instead of an 8-way select, one LDS atomic per keypoint and pass.
+    const int lane = threadIdx.x, rows = rt.rows;
+    constexpr int CH = 24;              // 1536 staging slots per trip: every ORB-SLAM2 setting up to ~1400 features in one
+    uint32_t pk[CH];
+#pragma unroll
+    for (int k = 0; k < CH; k++) { const int s = 64 * k + lane; pk[k] = s < da.kp_total ? kp_img[s] : 0u; }
+    for (int i = lane; i < rows; i += 64) { cnt[i] = 0; cur[i] = 0; }
+    if (lane < NL) {                    // per level: keypoints kept, output index of its first one (= counts of the lower levels), first slot, scale
+        int off = 0, c = 0, ko = 0;
+        float sc = 1.0f;
+#pragma unroll
+        for (int i = 0; i < NL; i++) {      // (static indices into the kernel-argument struct: a lane-indexed access would go through scratch)
+            const int ci = lc[i];
+            if (i < lane) off += ci;
+            if (i == lane) { c = ci; ko = da.lv[i].kp_off; sc = da.lv[i].scale; }
+        }
+        lvtab[lane] = make_int4(c, off, ko, __float_as_int(sc));
+    }
+    __syncthreads();                    // a one-wave workgroup: orders the LDS passes
+    // A slot of level l, position j is output index off[l] + j; x, y = (float)x_l * scale_l, band radius 2 * scale_l (:588-596):
+    // exactly the floats k_desc writes into the keypoint record and k_stereo_prep reads back from it.
+#define FOR_KEYPOINTS(RELOAD, ...) do { \
+        for (int base_ = 0; base_ < da.kp_total; base_ += 64 * CH) { \
+            if ((RELOAD) || base_) { \
+                _Pragma("unroll") for (int k_ = 0; k_ < CH; k_++) { const int s_ = base_ + 64 * k_ + lane; pk[k_] = s_ < da.kp_total ? kp_img[s_] : 0u; } \
+            } \
+            _Pragma("unroll") for (int k_ = 0; k_ < CH; k_++) { \
+                const int s_ = base_ + 64 * k_ + lane; \
+                if (base_ + 64 * k_ < da.kp_total) {    /* wave-uniform */ \
+                    int l_ = 0; \
+                    _Pragma("unroll") for (int i_ = 1; i_ < NL; i_++) l_ += s_ >= da.kp_off[i_]; \
+                    const int4 lv_ = lvtab[l_]; \
+                    const float sc_ = __int_as_float(lv_.w); \
+                    const int j_ = s_ - lv_.z, ir = lv_.y + j_; \
+                    if (s_ < da.kp_total && j_ < lv_.x && ir < cap && ir < rt.ent_cap) { \
+                        const uint32_t p_ = pk[k_]; \
+                        float fx = (float)(int)(p_ & 0xFFF), fy = (float)(int)((p_ >> 12) & 0xFFF); \
+                        if (l_ != 0) { fx *= sc_; fy *= sc_; } \
+                        const int crow = min(max((int)floorf(fy), 0), rows - 1); \
+                        const int oct = l_; (void)fx; (void)oct; (void)ir; (void)sc_; \
+                        __VA_ARGS__; \
+                    } \
+                } \
+            } \
+        } } while (0)
+    FOR_KEYPOINTS(false, { atomicAdd(&cnt[crow], 1); });
+    __syncthreads();
+    int carry = 0;
+    int *ro = rt.row_off + (long long)b * (rows + 1);
+    for (int base = 0; base < rows; base += 64) {       // exclusive scan of the row counts by the wave
+        const int i = base + lane, v = i < rows ? cnt[i] : 0;
+        const int inc = wave_incl_scan(v);
+        if (i < rows) { cnt[i] = carry + inc - v; ro[i] = carry + inc - v; }
+        carry += __builtin_amdgcn_readlane(inc, 63);
+    }
+    if (lane == 0) ro[rows] = carry;
+    __syncthreads();
+    uint4 *en = rt.entries + (long long)b * rt.ent_cap;
+    FOR_KEYPOINTS(da.kp_total > 64 * CH, {
+        const float r_ = 2.0f * sc_;
+        const int maxr = min((int)ceilf(fy + r_), rows - 1), minr = max((int)floorf(fy - r_), 0);
+        en[cnt[crow] + atomicAdd(&cur[crow], 1)] = make_uint4((unsigned)ir | ((unsigned)oct << 16), __float_as_uint(fx),
+                                                              (unsigned)minr | ((unsigned)maxr << 16), 0u);
+    });
+#undef FOR_KEYPOINTS
+}
+
 template <int NL>
 __global__ __launch_bounds__(64) void k_desc(const DescArgs da, PyrRef pr, const int *__restrict__ lvl_cnt,
                                              const uint32_t *__restrict__ lvl_kp, orbx_keypoint *__restrict__ out_kps,
-                                             uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap, int nimg)
+                                             uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap, int nimg, const RowTabArgs rt)
 {
     // LDS pitches: raw bytes (11 dwords per row), row-pass u16 (column-major, 43 rows per column, 37 columns).  1908 + 3188 bytes
     // round to 5120 = 160 KB / 32: the CU holds its maximum of 32 waves (the kernel is latency bound: with 5600 bytes, 29 waves
     // per CU, it ran 3 % slower; every KB more costs 7 %)
     constexpr int RP = 44, HR = 43;
-    __shared__ __align__(16) uint8_t raw[43 * RP + 16];
-    __shared__ __align__(4) uint16_t hb[37 * HR + 3];   // + the zero-tap row "43" of the last column, read as part of a dword
+    constexpr int RAW_BYTES = 43 * RP + 16;              // 1908
+    __shared__ __align__(16) uint8_t desc_smem[RAW_BYTES + (37 * HR + 3) * 2];
+    uint8_t *raw = desc_smem;
+    uint16_t *hb = reinterpret_cast<uint16_t *>(desc_smem + RAW_BYTES);   // + the zero-tap row "43" of the last column, read as part of a dword
+    static_assert(RAW_BYTES % 4 == 0 && sizeof(desc_smem) >= 16 * ORBX_MAX_LEVELS + 2 * (ORBX_ROWTAB_MAX_ROWS + 4) * sizeof(int), "row table workspace");
     // Workgroups are dealt round-robin over the 8 XCDs (linear id % 8, speed only): XCD x walks the images x, x + 8, x + 16, ...
     // one after the other, so the patches its waves fetch at any time come from one or two images (1.4 MB of pyramid each)
     // instead of from every image in flight on the chip: the per-XCD L2 (4 MB) then holds them
     const int lane = threadIdx.x;
     // grid = (8 * kp_total, ceil(images / 8)): blockIdx.x = 8 * slot + XCD, blockIdx.y = group of eight images; the linear
     // workgroup id (dispatch order) then has the XCD in its low three bits and the slot running fastest within an XCD
-    const int slot = (int)(blockIdx.x >> 3), b = (int)(blockIdx.y * 8u + (blockIdx.x & 7u));
+    // (with the row table on, slot "-1" -- the first workgroups dispatched -- is the table wave of each image)
+    const int slot = (int)(blockIdx.x >> 3) - rt.on, b = (int)(blockIdx.y * 8u + (blockIdx.x & 7u));
     if (b >= nimg) return;
+    if (slot < 0) {
+        desc_rowtab<NL>(da, lvl_cnt + (long long)b * ORBX_MAX_LEVELS, lvl_kp + (long long)b * da.kp_total, cap, rt, b,
+                        reinterpret_cast<int *>(desc_smem) + 4 * ORBX_MAX_LEVELS, reinterpret_cast<int *>(desc_smem) + 4 * ORBX_MAX_LEVELS + ((rt.rows + 4) & ~3),
+                        reinterpret_cast<int4 *>(desc_smem));
+        return;
+    }
     int l = 0;
 #pragma unroll
     for (int i = 1; i < NL; i++) l += slot >= da.kp_off[i];
@@ -1221,6 +1391,96 @@ static size_t tree_launch_lds(const Geom &G)
     return std::max(tree_tab_bytes(G), (size_t)ORBX_TREE_REG_PTS * 4) + tree_fixed_lds(G);
 }
 
+
+// Host tables of k_pyr_group: for every group, per tile column (row) of its last level and per step k = 0 (the source level) .. n
+// the region [lo, hi) the workgroup holds and the part [lo, own_hi) it writes out.  Appends to `tabs`; returns false when a region does
+// not fit the LDS (the geometry then keeps per-level launches).
+static bool build_pyr_groups(orbx_extractor *e, const Geom &G, std::vector<int16_t> &tabs)
+{
+    e->n_pyr_groups = 0;
+    int sizes[ORBX_MAX_LEVELS], nsizes = 0;
+    {
+        const char *env = getenv("ORBX_PYR_GROUPS");        // experiments: "2,5" = levels 1-2, then 3-7; "0" = per-level launches only
+        const char *p = env && *env ? env : "2,5";
+        while (*p && nsizes < ORBX_MAX_LEVELS) {
+            const int v = atoi(p);
+            if (v < 1) return false;
+            sizes[nsizes++] = std::min(v, ORBX_PYR_GROUP_MAX);
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+        if (!nsizes) return false;
+    }
+    for (int l = 1; l < G.nlevels; l++) if (G.lv[l].resize_lds == 2) return false;     // exact 2x levels are area averages
+    int first = 1, gi = 0;
+    while (first < G.nlevels) {
+        const int n = std::min(sizes[std::min(gi, nsizes - 1)], G.nlevels - first);
+        orbx_extractor::PyrGroup &P = e->pyr_groups[gi];
+        P.first = first; P.n = n;
+        size_t lds[2] = { 0, 0 };
+        std::vector<int> ext_axis[2];
+        for (int axis = 0; axis < 2; axis++) {
+            const int T = axis ? PG_TH : PG_TW;
+            auto dim = [&](int lvl) { return axis ? G.lv[lvl].h : G.lv[lvl].w; };
+            const int last = first + n - 1, tiles = (dim(last) + T - 1) / T, rec = axis ? PG_CY_REC : PG_CX_REC;
+            std::vector<int> lo((size_t)(n + 1) * tiles), hi(lo.size()), own(lo.size());
+            for (int t = 0; t < tiles; t++) { lo[(size_t)n * tiles + t] = t * T; hi[(size_t)n * tiles + t] = own[(size_t)n * tiles + t] = std::min(t * T + T, dim(last)); }
+            for (int k = n - 1; k >= 0; k--) {
+                const int lvl = first - 1 + k, D = dim(lvl);                    // the level of step k; step k + 1 reads it through its table
+                const int16_t *tb = &tabs[axis ? G.lv[lvl + 1].tab_y : G.lv[lvl + 1].tab_x];
+                std::vector<int> nlo(tiles), nhi(tiles);
+                for (int t = 0; t < tiles; t++) {
+                    nlo[t] = tb[4 * lo[(size_t)(k + 1) * tiles + t]];
+                    nhi[t] = std::min(tb[4 * (hi[(size_t)(k + 1) * tiles + t] - 1)] + 1, D - 1) + 1;
+                    if (nlo[t] < 0 || nhi[t] <= nlo[t] || (t && nlo[t] < nlo[t - 1])) return false;   // not a monotone down-scaling table
+                }
+                for (int t = 0; t < tiles; t++) {
+                    size_t i = (size_t)k * tiles + t;
+                    if (k == 0) { lo[i] = nlo[t] & ~3; hi[i] = nhi[t]; own[i] = nhi[t]; }
+                    else {
+                        lo[i] = t ? nlo[t] : 0;
+                        own[i] = t + 1 < tiles ? nlo[t + 1] : D;
+                        hi[i] = std::max(nhi[t], own[i]);
+                    }
+                }
+            }
+            // records + the LDS need of the even / odd steps
+            const int off = (int)tabs.size();
+            (axis ? P.tab_cy : P.tab_cx) = off;
+            tabs.resize(tabs.size() + (size_t)tiles * rec * (n + 1), 0);
+            std::vector<int> ext(n + 1, 0);                                    // largest extent of a step over the tiles (x: LDS pitch, y: rows)
+            for (int t = 0; t < tiles; t++)
+                for (int k = 0; k <= n; k++) {
+                    const size_t i = (size_t)k * tiles + t;
+                    int16_t *r = &tabs[off + ((size_t)t * (n + 1) + k) * rec];
+                    if (hi[i] > 32767) return false;
+                    r[0] = (int16_t)lo[i]; r[1] = (int16_t)hi[i]; r[2] = (int16_t)own[i];
+                    int extent = hi[i] - lo[i];
+                    if (!axis) {
+                        int div;
+                        if (k == 0) {
+                            const int pitch_lim = lo[i] + (((dim(first - 1) - lo[i]) + 3) & ~3);      // align4(w) as seen from lo: never past the pitch
+                            const int ndw = (std::min(lo[i] + ((hi[i] - lo[i] + 3) & ~3), pitch_lim) - lo[i]) / 4;
+                            r[3] = (int16_t)ndw; div = ndw; extent = 4 * ndw;
+                        } else { div = extent; extent = (extent + 3) & ~3; }
+                        const unsigned magic = (unsigned)((0x100000000ull + (unsigned)div - 1) / (unsigned)div);
+                        r[4] = (int16_t)(magic & 0xFFFF); r[5] = (int16_t)(magic >> 16);
+                    }
+                    ext[k] = std::max(ext[k], extent);
+                }
+            if (!axis) P.tiles_x = tiles; else P.tiles_y = tiles;
+            ext_axis[axis] = ext;
+        }
+        for (int k = 0; k < n; k++) lds[k & 1] = std::max(lds[k & 1], (size_t)ext_axis[0][k] * ext_axis[1][k]);   // pitch x rows; step n is not kept
+        P.lds_b = (int)align_up(lds[0], 16);
+        P.lds_bytes = P.lds_b + (int)align_up(lds[1], 16);
+        if (P.lds_bytes > PG_LDS_LIMIT) return false;
+        first += n; gi++;
+    }
+    e->n_pyr_groups = gi;
+    return true;
+}
+
 int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
 {
     if (e->geom.w == w && e->geom.h == h) return ORBX_OK;
@@ -1372,6 +1632,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
             r[0] = (int16_t)sx_min; r[1] = (int16_t)nfull; r[2] = (int16_t)tail; r[3] = 0;
         }
     }
+    if (!build_pyr_groups(e, G, tabs)) e->n_pyr_groups = 0;
     std::vector<CellRec> cells(G.total_cells);
     for (int l = 0; l < e->nlevels; l++) {
         const LevelGeom &L = G.lv[l];
@@ -1421,6 +1682,15 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
     }
     if ((rc = ensure(&e->d_lvl_kp, &e->lvl_kp_cap, (size_t)G.kp_total * B * 4))) return rc;
     if (!tree_tab_in_lds(G) && (rc = ensure(&e->d_tree_tab, &e->tree_tab_cap, align_up(tree_tab_bytes(G), 256) * e->nlevels * B))) return rc;
+    e->rt_kps = nullptr;
+    if (G.lv[0].h <= ORBX_ROWTAB_MAX_ROWS && !getenv("ORBX_NO_ROWTAB")) {
+        // row table by-product of k_desc: one 16-byte entry per keypoint (orbx_stereo.hip)
+        e->rt_ent_cap = G.kp_total;
+        if ((rc = ensure(&e->d_rt_off, &e->rt_off_cap, (size_t)(G.lv[0].h + 1) * B * sizeof(int)))) return rc;
+        if ((rc = ensure(&e->d_rt_entries, &e->rt_entries_cap, (size_t)e->rt_ent_cap * B * 16))) return rc;
+    } else if (e->d_rt_off) {
+        ORBX_HIP(hipFree(e->d_rt_off)); e->d_rt_off = nullptr; e->rt_off_cap = 0;
+    }
     ORBX_HIP(hipMemcpy(e->d_tabs, tabs.data(), tabs.size() * 2, hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(e->d_cells, cells.data(), cells.size() * sizeof(CellRec), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(e->d_geom, &G, sizeof G, hipMemcpyHostToDevice));
@@ -1499,6 +1769,14 @@ extern "C" int orbx_extractor_set_cv_profile(orbx_extractor *e, int profile)
     return ORBX_OK;
 }
 
+extern "C" int orbx_extractor_set_pyramid_group_limit(orbx_extractor *e, int max_images)
+{
+    if (!e || max_images < 0) { orbx_set_error("orbx_extractor_set_pyramid_group_limit: invalid argument"); return ORBX_E_INVALID; }
+    e->pyr_group_max_images = max_images;       // a launch constant of later extractions; results do not depend on it
+    if (e->lane2) e->lane2->pyr_group_max_images = max_images;
+    return ORBX_OK;
+}
+
 extern "C" int orbx_extractor_create(orbx_extractor **out, int nfeatures, float scale_factor, int nlevels,
                                      int ini_th, int min_th, int device, int max_w, int max_h, int max_batch)
 {
@@ -1520,6 +1798,10 @@ extern "C" int orbx_extractor_create(orbx_extractor **out, int nfeatures, float 
     orbx_extractor_set_cv_profile(e, ORBX_CV_PROFILE_3_2);   // the OpenCV the reference was tested with (README.md:68)
     e->device = device; e->nfeatures = nfeatures; e->nlevels = nlevels; e->ini_th = ini_th; e->min_th = min_th;
     e->scale_factor = scale_factor; e->max_w = max_w; e->max_h = max_h; e->max_batch = max_batch;
+    {   // launches of up to this many images build the pyramid with k_pyr_group (2 launches instead of 7); more: k_resize per level
+        const char *env = getenv("ORBX_PYR_GROUP_MAX_IMAGES");
+        e->pyr_group_max_images = env && *env ? atoi(env) : 8;
+    }
     // src/ORBextractor.cc:436-461
     e->sf[0] = 1.0f; e->sig2[0] = 1.0f;
     for (int i = 1; i < nlevels; i++) { e->sf[i] = (float)(e->sf[i - 1] * e->scale_factor); e->sig2[i] = e->sf[i] * e->sf[i]; }
@@ -1562,7 +1844,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *e)
     for (auto ev : e->prof_pool) hipEventDestroy(ev);
     if (e->ev_switch) hipEventDestroy(e->ev_switch);
     void *ptrs[] = { e->d_cand_prim, e->d_tree_tab, e->d_cells, e->d_geom, e->d_tabs, e->d_pyr, e->d_stage_in, e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid,
-                     e->d_lvl_cnt, e->d_lvl_kp, e->d_out_kps, e->d_out_desc, e->d_out_n, e->d_out_ur, e->d_out_depth, e->d_st_dist, e->d_st_entries };
+                     e->d_lvl_cnt, e->d_lvl_kp, e->d_out_kps, e->d_out_desc, e->d_out_n, e->d_out_ur, e->d_out_depth, e->d_st_dist, e->d_st_entries, e->d_rt_off, e->d_rt_entries, e->d_st_arrive };
     for (void *p : ptrs) if (p) hipFree(p);
     for (void *p : e->scratch) if (p) hipFree(p);
     for (PipeSlot &s : e->pipe) {
@@ -1655,7 +1937,23 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
     pr.pyr = e->d_pyr; pr.pyr_stride = G.pyr_bytes;
     e->last_img0 = pr.img0; e->last_img_stride = img_stride; e->last_pitch = pitch; e->last_batch = batch;
 
-    for (int l = 1; l < G.nlevels; l++) {
+    const bool grouped = e->n_pyr_groups > 0 && batch <= e->pyr_group_max_images;
+    for (int gi = 0; grouped && gi < e->n_pyr_groups; gi++) {
+        const orbx_extractor::PyrGroup &P = e->pyr_groups[gi];
+        const LevelGeom &S = G.lv[P.first - 1];
+        PyrGroupArgs ga;
+        memset(&ga, 0, sizeof ga);
+        ga.n = P.n; ga.s_level0 = P.first == 1; ga.s_w = S.w; ga.s_h = S.h; ga.s_pitch = S.pitch; ga.s_off = S.pyr_off;
+        ga.tab_cx = P.tab_cx; ga.tab_cy = P.tab_cy; ga.lds_b = P.lds_b;
+        for (int k = 0; k < P.n; k++) {
+            const LevelGeom &L = G.lv[P.first + k];
+            ga.lv[k].w = L.w; ga.lv[k].h = L.h; ga.lv[k].pitch = L.pitch; ga.lv[k].tab_x = L.tab_x; ga.lv[k].tab_y = L.tab_y; ga.lv[k].pyr_off = L.pyr_off;
+        }
+        orbx_prof_begin(e, ORBX_STAGE_RESIZE, s);
+        hipLaunchKernelGGL(k_pyr_group, dim3(P.tiles_x, P.tiles_y, batch), dim3(PG_NT), (size_t)P.lds_bytes, s, ga, pr, e->d_pyr, e->d_tabs);
+        orbx_prof_end(e, s);
+    }
+    for (int l = 1; l < G.nlevels && !grouped; l++) {
         const LevelGeom &L = G.lv[l];
         orbx_prof_begin(e, ORBX_STAGE_RESIZE, s);
         if (L.resize_lds == 1)
@@ -1712,8 +2010,15 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
             da.lv[i].scale = L.scale; da.lv[i].patch_size = L.patch_size;
         }
     }
-    hipLaunchKernelGGL((G.nlevels <= 8 ? k_desc<8> : k_desc<ORBX_MAX_LEVELS>), dim3(8 * G.kp_total, (batch + 7) / 8), dim3(64), 0, s, da, pr, e->d_lvl_cnt, e->d_lvl_kp,
-                       (orbx_keypoint *)d_kps, (uint8_t *)d_desc, (int *)d_n_out, cap, batch);
+    RowTabArgs rt;
+    memset(&rt, 0, sizeof rt);
+    e->rt_kps = nullptr;
+    if (e->d_rt_off && cap < 65536) {          // the stereo row table rides along (see desc_rowtab)
+        rt.row_off = e->d_rt_off; rt.entries = (uint4 *)e->d_rt_entries; rt.ent_cap = e->rt_ent_cap; rt.rows = G.lv[0].h; rt.on = 1;
+        e->rt_kps = d_kps; e->rt_cap = cap; e->rt_batch = batch;
+    }
+    hipLaunchKernelGGL((G.nlevels <= 8 ? k_desc<8> : k_desc<ORBX_MAX_LEVELS>), dim3(8 * (G.kp_total + rt.on), (batch + 7) / 8), dim3(64), 0, s, da, pr, e->d_lvl_cnt, e->d_lvl_kp,
+                       (orbx_keypoint *)d_kps, (uint8_t *)d_desc, (int *)d_n_out, cap, batch, rt);
     orbx_prof_end(e, s);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
@@ -2064,6 +2369,7 @@ static int pipe_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t
         }
         x = e->lane2;
         if (x->cv_profile != e->cv_profile) orbx_extractor_set_cv_profile(x, e->cv_profile);
+        x->pyr_group_max_images = e->pyr_group_max_images;
     }
     int rc = orbx_prepare_geometry(x, w, h);   // waits for everything in flight only when the image size changes
     if (rc) return rc;

@@ -114,13 +114,22 @@ struct orbx_extractor {
     float *d_out_ur, *d_out_depth;
     // stereo scratch
     int *d_st_dist; size_t st_cap;         // SAD per left keypoint (or -1)
-    void *d_st_entries; size_t st_ent_cap;  // row table entries (vRowIndices): (iR | octave<<16, x)
+    void *d_st_entries; size_t st_ent_cap;  // row table entries of k_stereo_prep (one uint4 per right keypoint, see orbx_stereo.hip)
     void *scratch[8]; size_t scratch_cap[8]; // host-API upload buffers
     // pipelined stereo frames: copies ride their own streams so that frame i+1 uploads and frame i-1 downloads while frame i computes
     PipeSlot pipe[ORBX_PIPE_DEPTH]; hipStream_t copy_in, copy_out; unsigned pipe_next;
     bool pipe_counted;               // this handle is counted in the process-wide number of pipelined handles
     orbx_extractor *lane2;           // second kernel lane of the pipelined forms: odd submissions run on its stream and workspaces, so the
                                      // launch chains of neighbouring frames overlap (a frame alone fills a few percent of the chip)
+    // grouped pyramid of small launches (k_pyr_group): group i builds levels first .. first + n - 1 in one launch
+    struct PyrGroup { int first, n, tiles_x, tiles_y, tab_cx, tab_cy, lds_b, lds_bytes; } pyr_groups[ORBX_MAX_LEVELS];
+    int n_pyr_groups;                // 0: this geometry has no grouped form (per-level launches at every batch size)
+    int pyr_group_max_images;        // launches of at most this many images take the grouped form
+    // stereo row table written by the most recent extraction as a by-product of k_desc (desc_rowtab): valid for the keypoint buffer
+    // rt_kps (capacity rt_cap per image, rt_batch images); d_rt_off == nullptr: this geometry has none (more rows than k_desc's LDS holds)
+    int *d_rt_off; size_t rt_off_cap; uint8_t *d_rt_entries; size_t rt_entries_cap; int rt_ent_cap;
+    const void *rt_kps; int rt_cap, rt_batch;
+    int *d_st_arrive;                // per stereo pair: workgroups of k_stereo that have finished (the last one applies the median cut)
     // state of the most recent extract
     const uint8_t *last_img0; size_t last_img_stride, last_pitch; int last_batch;
     // profiling

@@ -7,7 +7,10 @@
 // ascending iR" (:654-658).  Fine stage: 11x11
 // centre-subtracted L1 SAD over 11 shifts on the unblurred pyramids (:666-703), parabola (:709-716),
 // disparity / depth (:719-733) by the same wave.
-// K6 k_stereo_cut: per pair, radix-select the median SAD and drop matches >= 1.5*1.4*median (:737-750).
+// K6 median cut: per pair, radix-select the median SAD and drop matches >= 1.5*1.4*median (:737-750) -- run by the LAST workgroup of
+// k_stereo to finish a pair (device-scope arrival counter), not by a launch of its own.
+// The row table normally comes with the extraction (desc_rowtab in orbx_extract.hip); k_stereo_prep is the form for keypoints that
+// did not come from the right extractor's last launch.
 #include "orbx_device.h"
 
 struct StereoTabs { float sf[ORBX_MAX_LEVELS]; float isf[ORBX_MAX_LEVELS]; };
@@ -18,45 +21,122 @@ __device__ __forceinline__ int lvl_px(const uint8_t *img, int pitch, int w, int 
     return img[(long long)reflect101(y, h) * pitch + reflect101(x, w)];
 }
 
-// Row table of src/Frame.cc:584-604 (vRowIndices), built per stereo pair by one workgroup: right
-// keypoint iR is listed in every image row of its band [floor(y-r), ceil(y+r)], r = 2*scale[octave].
-// CSR in HBM: row_off[rows+1] + entries (order inside a row is irrelevant: the coarse stage reduces
-// with min(dist<<16 | iR), which is "first minimum in ascending iR").
+// a keypoint's results as write-through stores (sc1): visible to the pair's last workgroup on another XCD once acknowledged
+__device__ __forceinline__ void st_store(float *u_right, float *depth, int *st_dist, long long og, float u, float z, int sad)
+{
+    __hip_atomic_store(&u_right[og], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&depth[og], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&st_dist[og], sad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Row table of src/Frame.cc:584-604 (vRowIndices).  The reference lists right keypoint iR in every image row of its band
+// [minr, maxr] = [floor(y - r), ceil(y + r)], r = 2 * scale[octave] (7000-17000 list entries for 1000 keypoints).  Here a keypoint is
+// listed ONCE, under the row of its centre, with its band in the entry (iR | octave << 16, x, minr | maxr << 16, 0): CSR by centre row,
+// row_off[rows + 1] + one 16-byte entry per keypoint.  The coarse stage scans the contiguous run of centre rows that can reach the left
+// keypoint's row (+- ceil(2 * scale[top]) + 1) and tests minr <= row <= maxr -- the same candidate set as the reference's per-row lists
+// (order is irrelevant: the stage reduces with min(dist << 16 | iR), "first minimum in ascending iR"), built with one LDS atomic per
+// keypoint instead of one per (keypoint, row).
+// k_stereo_prep builds it for keypoints handed in by the caller; keypoints that come straight from the right extractor's last launch
+// already have theirs (desc_rowtab in orbx_extract.hip: same layout).
 extern __shared__ __align__(16) int prep_smem[];
 
 __global__ __launch_bounds__(256) void k_stereo_prep(const Geom *__restrict__ g, const orbx_keypoint *__restrict__ kR,
                                                      const int *__restrict__ nR, int cap, StereoTabs tabs,
-                                                     int *__restrict__ row_off, uint2 *__restrict__ entries, int ent_cap)
+                                                     int *__restrict__ row_off, uint4 *__restrict__ entries, int ent_cap)
 {
     __shared__ int s_w[4];
     const int p = blockIdx.x, tid = threadIdx.x;
-    const int rows = g->lv[0].h, n_r = nR[p];
+    const int rows = g->lv[0].h, n_r = min(nR[p], ent_cap);
     int *cnt = prep_smem, *cur = prep_smem + ((rows + 4) & ~3);
     const orbx_keypoint *kr = kR + (long long)p * cap;
     for (int i = tid; i < rows; i += 256) { cnt[i] = 0; cur[i] = 0; }
     __syncthreads();
-    for (int ir = tid; ir < n_r; ir += 256) {
-        const float y = kr[ir].y, r = 2.0f * tabs.sf[kr[ir].octave & (ORBX_MAX_LEVELS - 1)];
-        const int maxr = min((int)ceilf(y + r), rows - 1), minr = max((int)floorf(y - r), 0);
-        for (int yi = minr; yi <= maxr; yi++) atomicAdd(&cnt[yi], 1);
-    }
+    for (int ir = tid; ir < n_r; ir += 256) atomicAdd(&cnt[min(max((int)floorf(kr[ir].y), 0), rows - 1)], 1);
     __syncthreads();
     const int total = lds_excl_scan(cnt, rows, s_w);
     int *ro = row_off + (long long)p * (rows + 1);
-    for (int i = tid; i < rows; i += 256) ro[i] = min(cnt[i], ent_cap);
-    if (tid == 0) ro[rows] = min(total, ent_cap);
-    // an entry carries what the coarse stage tests (index, octave, x): the 28-byte keypoint record of every candidate
-    // is not gathered again per left keypoint, and the winner's x is known without another round trip
-    uint2 *en = entries + (long long)p * ent_cap;
+    for (int i = tid; i < rows; i += 256) ro[i] = cnt[i];
+    if (tid == 0) ro[rows] = total;
+    uint4 *en = entries + (long long)p * ent_cap;
     for (int ir = tid; ir < n_r; ir += 256) {
         const orbx_keypoint q = kr[ir];
         const float y = q.y, r = 2.0f * tabs.sf[q.octave & (ORBX_MAX_LEVELS - 1)];
         const int maxr = min((int)ceilf(y + r), rows - 1), minr = max((int)floorf(y - r), 0);
-        const uint2 ent = make_uint2((unsigned)ir | ((unsigned)q.octave << 16), __float_as_uint(q.x));
-        for (int yi = minr; yi <= maxr; yi++) {
-            const int pos = cnt[yi] + atomicAdd(&cur[yi], 1);
-            if (pos < ent_cap) en[pos] = ent;
-        }
+        const int c = min(max((int)floorf(y), 0), rows - 1);
+        en[cnt[c] + atomicAdd(&cur[c], 1)] = make_uint4((unsigned)ir | ((unsigned)q.octave << 16), __float_as_uint(q.x),
+                                                        (unsigned)minr | ((unsigned)maxr << 16), 0u);
+    }
+}
+
+// Median cut of one stereo pair by one 256-thread workgroup.  The SADs are fetched once (device-scope loads: they were written by
+// workgroups on other XCDs) and stay in registers for the three passes; the two 256-bin radix steps are resolved by wave 0 in parallel
+// (a serial walk of the histogram by one thread was a chain of up to 256 dependent LDS reads).
+__device__ __forceinline__ void hist_select(const int *hist, int k, int *sel, int *rem)   // called by wave 0: first bin whose cumulative count exceeds k
+{
+    const int lane = threadIdx.x;
+    const int4 v = reinterpret_cast<const int4 *>(hist)[lane];
+    const int s = v.x + v.y + v.z + v.w, inc = wave_incl_scan(s);
+    const unsigned long long m = __ballot(inc > k);
+    const int L = m ? __builtin_ctzll(m) : 63;
+    if (lane == L) {
+        int acc = inc - s, b = 0;
+        if (acc + v.x > k) b = 0;
+        else if (acc + v.x + v.y > k) { b = 1; acc += v.x; }
+        else if (acc + v.x + v.y + v.z > k) { b = 2; acc += v.x + v.y; }
+        else { b = 3; acc += v.x + v.y + v.z; }
+        *sel = 4 * L + b; *rem = k - acc;
+    }
+}
+
+__device__ __forceinline__ void stereo_cut(int n_l, long long o, float *__restrict__ u_right, float *__restrict__ depth, int *__restrict__ st_dist)
+{
+    __shared__ __align__(16) int hist[256];
+    __shared__ int s_sel, s_rem, s_cnt;
+    const int tid = threadIdx.x;
+    constexpr int K = 8;                        // keypoints per thread held in registers (n_l <= 2048: every ORB-SLAM2 setting)
+    int d[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int i = tid + 256 * k;
+        d[k] = i < n_l ? __hip_atomic_load(&st_dist[o + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+    }
+    hist[tid] = 0;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    int local = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) if (d[k] >= 0) { atomicAdd(&hist[d[k] >> 8], 1); local++; }
+    for (int i = tid + 256 * K; i < n_l; i += 256) {
+        const int v = __hip_atomic_load(&st_dist[o + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= 0) { atomicAdd(&hist[v >> 8], 1); local++; }
+    }
+    if (local) atomicAdd(&s_cnt, local);
+    __syncthreads();
+    const int nvd = s_cnt;
+    if (nvd == 0) return; // reference indexes an empty vector here (SURVEY.md A.7); nothing to cut
+    if (tid < 64) hist_select(hist, nvd / 2, &s_sel, &s_rem);   // vDistIdx[size/2] of the ascending sort
+    __syncthreads();
+    const int hi = s_sel, rem = s_rem;
+    __syncthreads();
+    hist[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) if (d[k] >= 0 && (d[k] >> 8) == hi) atomicAdd(&hist[d[k] & 255], 1);
+    for (int i = tid + 256 * K; i < n_l; i += 256) {
+        const int v = __hip_atomic_load(&st_dist[o + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= 0 && (v >> 8) == hi) atomicAdd(&hist[v & 255], 1);
+    }
+    __syncthreads();
+    if (tid < 64) hist_select(hist, rem, &s_sel, &s_rem);
+    __syncthreads();
+    const float median = (float)((hi << 8) | s_sel);
+    const float th_dist = 1.5f * 1.4f * median;
+#pragma unroll
+    for (int k = 0; k < K; k++)
+        if (d[k] >= 0 && !((float)d[k] < th_dist)) { u_right[o + tid + 256 * k] = -1.0f; depth[o + tid + 256 * k] = -1.0f; }
+    for (int i = tid + 256 * K; i < n_l; i += 256) {
+        const int v = __hip_atomic_load(&st_dist[o + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= 0 && !((float)v < th_dist)) { u_right[o + i] = -1.0f; depth[o + i] = -1.0f; }
     }
 }
 
@@ -66,7 +146,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                 const uint32_t *__restrict__ dR, const int *__restrict__ nR, int cap,
                                                 float bf, float max_d, StereoTabs tabs, float *__restrict__ u_right,
                                                 float *__restrict__ depth, int *__restrict__ st_dist,
-                                                const int *__restrict__ row_off, const uint2 *__restrict__ entries, int ent_cap)
+                                                const int *__restrict__ row_off, const uint4 *__restrict__ entries, int ent_cap, int reach,
+                                                int *__restrict__ arrive)
 {
     // A wave takes FOUR left keypoints.  Coarse stage: one keypoint per 16-lane row (a row of the table holds ~25
     // candidates, so a whole wave per keypoint left most lanes idle and paid the dependent load chain
@@ -78,7 +159,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int p = blockIdx.y, lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
     const int il_base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
     const int n_l = nL[p];
-    if (il_base >= n_l) return; // wave-uniform
+    if ((int)blockIdx.x * 16 >= n_l) return;    // the whole workgroup (the pair's last workgroup is counted among ceil(n_l / 16))
+    if (il_base < n_l) {                        // wave-uniform
     const int il = il_base + sub;
     const bool have = il < n_l;
     const long long ol = (long long)p * cap + (have ? il : il_base);
@@ -97,16 +179,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
         for (int i = 0; i < 8; i++) a[i] = dL[ol * 8 + i];
         const int *ro = row_off + (long long)p * (n_rows + 1);
-        const uint2 *en = entries + (long long)p * ent_cap;
-        const int rr = active ? row : 0;
-        const int b0 = active ? ro[rr] : 0, e1 = active ? ro[rr + 1] : 0;
+        const uint4 *en = entries + (long long)p * ent_cap;
+        // centre rows that can reach this row: one contiguous run of the table
+        const int b0 = active ? ro[max(row - reach, 0)] : 0, e1 = active ? ro[min(row + reach, n_rows - 1) + 1] : 0;
         for (int base = b0; __any(base < e1); base += 16) { // right keypoints whose row band holds this row (:622)
             const int j = base + sl;
             if (j < e1) {
-                const uint2 ent = en[j];
+                const uint4 ent = en[j];
                 const int ir = (int)(ent.x & 0xFFFFu), oct = (int)(short)(ent.x >> 16);
                 const float qx = __uint_as_float(ent.y);
-                if (oct >= level_l - 1 && oct <= level_l + 1 && qx >= min_u && qx <= max_u) {
+                const int minr = (int)(ent.z & 0xFFFFu), maxr = (int)(ent.z >> 16);
+                if (row >= minr && row <= maxr && oct >= level_l - 1 && oct <= level_l + 1 && qx >= min_u && qx <= max_u) {
                     uint32_t bq[8];
                     const uint4 *src = reinterpret_cast<const uint4 *>(dr + (long long)ir * 8);
                     const uint4 v0 = src[0], v1 = src[1];
@@ -133,7 +216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const int lvl = __builtin_amdgcn_readlane(level_l, gk * 16);
         const long long og = (long long)p * cap + il_base + gk;
         if (!(best_dist < 75)) { // thOrbDist = (TH_HIGH+TH_LOW)/2: no coarse match
-            if (lane == 0) { u_right[og] = -1.0f; depth[og] = -1.0f; st_dist[og] = -1; }
+            if (lane == 0) st_store(u_right, depth, st_dist, og, -1.0f, -1.0f, -1);
             continue;
         }
         float out_u = -1.0f, out_z = -1.0f;
@@ -243,59 +326,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 }
             }
         }
-        if (lane == 0) { u_right[og] = out_u; depth[og] = out_z; st_dist[og] = out_sad; }
+        if (lane == 0) st_store(u_right, depth, st_dist, og, out_u, out_z, out_sad);
     }
-}
-
-// one 256-thread workgroup per stereo pair
-__global__ __launch_bounds__(256) void k_stereo_cut(const int *__restrict__ nL, int cap, float *__restrict__ u_right,
-                                                    float *__restrict__ depth, const int *__restrict__ st_dist)
-{
-    __shared__ int hist[256];
-    __shared__ int s_sel, s_rem, s_cnt;
-    const int p = blockIdx.x, tid = threadIdx.x;
-    const int n_l = nL[p];
-    const long long o = (long long)p * cap;
-    hist[tid] = 0;
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    int local = 0;
-    for (int i = tid; i < n_l; i += 256) {
-        const int d = st_dist[o + i];
-        if (d >= 0) { atomicAdd(&hist[d >> 8], 1); local++; }
     }
-    if (local) atomicAdd(&s_cnt, local);
+    // ---- median cut (src/Frame.cc:737-750) by the pair's last workgroup: every workgroup's results went out as write-through
+    // stores; once they are acknowledged the workgroup counts itself in, and the one that completes the count sees them all
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int nvd = s_cnt;
-    if (nvd == 0) return; // reference indexes an empty vector here (SURVEY.md A.7); nothing to cut
-    const int kth = nvd / 2; // vDistIdx[size/2] of the ascending sort
-    if (tid == 0) {
-        int acc = 0, b = 0;
-        for (; b < 256; b++) { if (acc + hist[b] > kth) break; acc += hist[b]; }
-        s_sel = b; s_rem = kth - acc;
+    if (threadIdx.x == 0) {
+        const int nwg = (n_l + 15) / 16;
+        const int old = __hip_atomic_fetch_add(&arrive[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == nwg - 1;
+        if (old == nwg - 1) __hip_atomic_store(&arrive[p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
     }
     __syncthreads();
-    const int hi = s_sel, rem = s_rem;
-    __syncthreads();
-    hist[tid] = 0;
-    __syncthreads();
-    for (int i = tid; i < n_l; i += 256) {
-        const int d = st_dist[o + i];
-        if (d >= 0 && (d >> 8) == hi) atomicAdd(&hist[d & 255], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0, b = 0;
-        for (; b < 256; b++) { if (acc + hist[b] > rem) break; acc += hist[b]; }
-        s_sel = (hi << 8) | b;
-    }
-    __syncthreads();
-    const float median = (float)s_sel;
-    const float th_dist = 1.5f * 1.4f * median;
-    for (int i = tid; i < n_l; i += 256) {
-        const int d = st_dist[o + i];
-        if (d >= 0 && !((float)d < th_dist)) { u_right[o + i] = -1.0f; depth[o + i] = -1.0f; }
-    }
+    if (!s_last) return;
+    stereo_cut(n_l, (long long)p * cap, u_right, depth, st_dist);
 }
 
 static int same_geometry(const orbx_extractor *L, const orbx_extractor *R)
@@ -335,12 +382,21 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
     for (int i = 0; i < ORBX_MAX_LEVELS; i++) { tabs.sf[i] = L->sf[i]; tabs.isf[i] = L->isf[i]; }
     // row table: a right keypoint spans at most 2*r+3 rows, r = 2*scale[top level]
     const int rows = L->geom.lv[0].h;
-    const int ent_cap = cap * ((int)(4.0f * L->sf[L->nlevels - 1]) + 4);
+    const int ent_cap = cap;            // one entry per right keypoint
+    const int reach = (int)ceilf(2.0f * L->sf[L->nlevels - 1]) + 1;   // centre rows whose band can hold a given row: |c - row| <= ceil(r) + 1
     void *d_row_off, *d_entries;
-    {
+    int row_ent_cap = ent_cap;
+    // the right extractor's last launch wrote exactly these keypoints: its by-product row table serves (desc_rowtab)
+    const bool by_product = R->d_rt_off && R->rt_kps && cap == R->rt_cap && img_r0 + batch <= R->rt_batch &&
+                            (const char *)d_kR == (const char *)R->rt_kps + (size_t)img_r0 * cap * sizeof(orbx_keypoint);
+    if (by_product) {
+        d_row_off = R->d_rt_off + (size_t)img_r0 * (rows + 1);
+        d_entries = R->d_rt_entries + (size_t)img_r0 * R->rt_ent_cap * sizeof(uint4);
+        row_ent_cap = R->rt_ent_cap;
+    } else {
         int rc;
         if ((rc = orbx_scratch(L, 7, (size_t)batch * (rows + 1) * sizeof(int), &d_row_off))) return rc;
-        const size_t need_e = (size_t)batch * ent_cap * sizeof(uint2);
+        const size_t need_e = (size_t)batch * ent_cap * sizeof(uint4);
         if (need_e > L->st_ent_cap || !L->d_st_entries) {
             ORBX_HIP(hipStreamSynchronize(s));
             { const int qrc = orbx_quiesce(L); if (qrc) return qrc; }
@@ -358,17 +414,19 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
     pr.pyr = R->d_pyr; pr.pyr_stride = R->geom.pyr_bytes;
     { int urc = orbx_use_stream(L, s); if (urc) return urc; if (R != L && (urc = orbx_use_stream(R, s))) return urc; }
     const float max_d = bf / min_z; // src/Frame.cc:609
+    if (!L->d_st_arrive) {       // arrival counters of k_stereo's pairs: zero between launches (the last workgroup of a pair resets its own)
+        ORBX_HIP(hipMalloc((void **)&L->d_st_arrive, (size_t)L->max_batch * sizeof(int)));
+        ORBX_HIP(hipMemsetAsync(L->d_st_arrive, 0, (size_t)L->max_batch * sizeof(int), s));
+    }
     orbx_prof_begin(L, ORBX_STAGE_STEREO, s);
-    hipLaunchKernelGGL(k_stereo_prep, dim3(batch), dim3(256), (size_t)2 * ((rows + 4) & ~3) * sizeof(int), s, L->d_geom,
-                       (const orbx_keypoint *)d_kR, (const int *)d_nR, cap, tabs, (int *)d_row_off, (uint2 *)d_entries, ent_cap);
+    if (!by_product)
+        hipLaunchKernelGGL(k_stereo_prep, dim3(batch), dim3(256), (size_t)2 * ((rows + 4) & ~3) * sizeof(int), s, L->d_geom,
+                           (const orbx_keypoint *)d_kR, (const int *)d_nR, cap, tabs, (int *)d_row_off, (uint4 *)d_entries, ent_cap);
     hipLaunchKernelGGL(k_stereo, dim3((cap + 15) / 16, batch), dim3(256), 0, s, L->d_geom, pl, pr, img_l0, img_r0,
                        (const orbx_keypoint *)d_kL, (const uint32_t *)d_dL, (const int *)d_nL,
                        (const orbx_keypoint *)d_kR, (const uint32_t *)d_dR, (const int *)d_nR, cap, bf, max_d, tabs,
-                       (float *)d_u_right, (float *)d_depth, L->d_st_dist, (const int *)d_row_off, (const uint2 *)d_entries, ent_cap);
-    orbx_prof_end(L, s);
-    orbx_prof_begin(L, ORBX_STAGE_STEREO_CUT, s);
-    hipLaunchKernelGGL(k_stereo_cut, dim3(batch), dim3(256), 0, s, (const int *)d_nL, cap, (float *)d_u_right,
-                       (float *)d_depth, L->d_st_dist);
+                       (float *)d_u_right, (float *)d_depth, L->d_st_dist, (const int *)d_row_off, (const uint4 *)d_entries, row_ent_cap, reach,
+                       L->d_st_arrive);
     orbx_prof_end(L, s);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;

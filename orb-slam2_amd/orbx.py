@@ -59,6 +59,7 @@ def lib():
     L.orbx_device_count.restype = i
     L.orbx_extractor_create.argtypes = [C.POINTER(vp), i, f, i, i, i, i, i, i, i]
     L.orbx_extractor_set_cv_profile.argtypes = [vp, i]
+    L.orbx_extractor_set_pyramid_group_limit.argtypes = [vp, i]
     L.orbx_gaussian_taps.argtypes = [i, vp]
     L.orbx_extractor_destroy.argtypes = [vp]
     L.orbx_extractor_destroy.restype = None
@@ -234,6 +235,10 @@ class ORBextractor:
     def set_cv_profile(self, profile):
         """which OpenCV generation's GaussianBlur the descriptors are computed on: CV_PROFILE_3_2 (default) or CV_PROFILE_3_4_2"""
         _check(self._L.orbx_extractor_set_cv_profile(self._h, profile))
+
+    def set_pyramid_group_limit(self, max_images):
+        """tuning only (results do not change): launches of at most max_images images build several pyramid levels per launch; 0 = never"""
+        _check(self._L.orbx_extractor_set_pyramid_group_limit(self._h, int(max_images)))
 
     def GetLevels(self): return self._L.orbx_get_levels(self._h)
     def GetScaleFactor(self): return self._L.orbx_get_scale_factor(self._h)

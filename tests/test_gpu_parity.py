@@ -71,6 +71,26 @@ def test_extract_stage_parity(pkg, oracle, w, h, nf, seed):
     _check_stages(ex, orc, img, f"{w}x{h}")
 
 
+@pytest.mark.parametrize("groups", ["2,5", "7", "1", "3,4", "1,2,4"])
+def test_pyramid_launch_forms(pkg, oracle, monkeypatch, groups):
+    """ComputePyramid (src/ORBextractor.cc:1347-1370) has two launch forms: one launch per level (batches) and several levels per launch
+    (k_pyr_group, small launches).  Every grouping and the per-level form give the oracle's pyramid and keypoints bit for bit, on sizes
+    whose tiles end in partial columns / rows, for other scale factors, and for a level-0 image at an odd address and pitch."""
+    monkeypatch.setenv("ORBX_PYR_GROUPS", groups)
+    for (w, h, nf, sf, nl) in [(1241, 376, 1000, 1.2, 8), (640, 480, 800, 1.2, 8), (333, 257, 300, 1.2, 6), (752, 480, 700, 1.5, 4),
+                               (517, 389, 500, 1.1, 8), (1000, 700, 900, 1.9, 3), (1920, 1080, 2000, 1.2, 8)]:
+        img = synth.image(w + h, w, h, nshapes=int(w * h / 400) + 50)
+        orc = oracle.Oracle(nf, sf, nl, 20, 7)
+        ex = pkg.ORBextractor(nf, sf, nl, 20, 7, device=0, max_size=(w, h))
+        ex.set_pyramid_group_limit(0)
+        k0, d0 = _check_stages(ex, orc, img, f"{w}x{h} sf {sf} per-level launches")
+        ex.set_pyramid_group_limit(64)
+        k1, d1 = _check_stages(ex, orc, img, f"{w}x{h} sf {sf} groups {groups}")
+        assert k0.tobytes() == k1.tobytes() and d0.tobytes() == d1.tobytes()
+    with pytest.raises(pkg.OrbxError):
+        ex.set_pyramid_group_limit(-1)
+
+
 def test_extract_fhd_4000(pkg, oracle):
     img = synth.image(5, 1920, 1080, nshapes=4000)
     ex = _extractor(pkg, 4000, 1920, 1080)
@@ -628,7 +648,7 @@ def test_extract_pipelined_mono_and_mixed(pkg, oracle):
 
 def test_profile_stage_selection(pkg):
     """orbx_profile_enable / orbx_profile_stages: events are recorded for the selected stages only, one launch each per call
-    (seven k_resize launches), and the outputs do not depend on profiling"""
+    (seven k_resize launches, or the two grouped pyramid launches of a small batch), and the outputs do not depend on profiling"""
     w, h = 640, 480
     img = synth.image(5, w, h)
     ex = _extractor(pkg, 800, w, h)
@@ -636,9 +656,16 @@ def test_profile_stage_selection(pkg):
     ex.profile_read(reset=True)
     ex.profile_enable(True)
     k1, d1 = ex(img)
+    ex.set_pyramid_group_limit(0)
+    k2, d2 = ex(img)
     ex.profile_enable(False)
     prof = ex.profile_read(reset=True)
-    assert k1.tobytes() == k0.tobytes() and (d1 == d0).all()
+    assert k1.tobytes() == k0.tobytes() and (d1 == d0).all() and k2.tobytes() == k0.tobytes() and (d2 == d0).all()
+    assert prof["resize"][1] == 2 + 7 and prof["fast"][1] == 2 and prof["tree"][1] == 2 and prof["desc"][1] == 2
+    ex.profile_enable(True)
+    k1, d1 = ex(img)
+    ex.profile_enable(False)
+    prof = ex.profile_read(reset=True)
     assert prof["resize"][1] == 7 and prof["fast"][1] == 1 and prof["tree"][1] == 1 and prof["desc"][1] == 1
     assert all(prof[s][0] > 0 for s in ("resize", "fast", "tree", "desc"))
     ex.profile_stages(1 << pkg.orbx.STAGES.index("fast"))

@@ -4,7 +4,7 @@ fs = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=T
 f = max(fs, key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 rows = [r for r in rows if r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "") in
-        ("k_resize", "k_fast", "k_tree", "k_desc", "k_stereo_prep", "k_stereo", "k_stereo_cut")]
+        ("k_resize", "k_pyr_group", "k_fast", "k_tree", "k_desc", "k_stereo_prep", "k_stereo", "k_stereo_cut")]
 seq = rows[-40:-14]
 prev = None; tot_gap = 0; t0 = None
 for r in seq:
