@@ -208,7 +208,7 @@ struct PyrGroupArgs {
     long long s_off;
     PyrGroupLevel lv[ORBX_PYR_GROUP_MAX];
 };
-#define PG_CX_REC 8     // int16 units per (tile column, step): lo, hi, own_hi, dwords per source row (step 0), magic lo, magic hi, 0, 0
+#define PG_CX_REC 8     // int16 units per (tile column, step): lo, hi, own_hi, dwords per source row (step 0), magic of the dwords / 4-pixel groups per row (lo, hi), 0, 0
 #define PG_CY_REC 4     // per (tile row, step): lo, hi, own_hi, 0
 
 extern __shared__ __align__(16) uint8_t pg_smem[];
@@ -250,17 +250,42 @@ __global__ __launch_bounds__(PG_NT) void k_pyr_group(const PyrGroupArgs A, PyrRe
         const int16_t *tx = tabs + L.tab_x, *ty = tabs + L.tab_y;
         uint8_t *dst = pyr_w + (long long)b * pr.pyr_stride + L.pyr_off;
         const bool keep = k < A.n;               // the last level of the group is only written out
-        for (int i = tid; i < rw * rh; i += PG_NT) {
-            const int yy = rw == 1 ? i : (int)__umulhi((unsigned)i, magic), xx = i - yy * rw;
+        // a thread takes four adjacent pixels of a row: one row record, the four column records as two 16-byte loads, one packed
+        // LDS store (the region's rows are dword aligned in `nxt`) and one dword store to the pyramid
+        const int ng = (rw + 3) >> 2;
+        for (int i = tid; i < ng * rh; i += PG_NT) {
+            const int yy = ng == 1 ? i : (int)__umulhi((unsigned)i, magic), xx = 4 * (i - yy * ng);
             const int x = lx + xx, y = ly + yy;
-            const short4 qx = *reinterpret_cast<const short4 *>(tx + 4 * x), qy = *reinterpret_cast<const short4 *>(ty + 4 * y);
-            const int sx0 = qx.x, sx1 = min(sx0 + 1, s_w - 1), sy0 = qy.x, sy1 = min(sy0 + 1, s_h - 1);
+            const short4 qy = *reinterpret_cast<const short4 *>(ty + 4 * y);
+            const int sy0 = qy.x, sy1 = min(sy0 + 1, s_h - 1);
             const uint8_t *r0 = cur + (sy0 - oy) * cp - ox, *r1 = cur + (sy1 - oy) * cp - ox;
-            const int t0 = r0[sx0] * qx.y + r0[sx1] * qx.z;
-            const int t1 = r1[sx0] * qx.y + r1[sx1] * qx.z;
-            const int v = (((qy.y * (t0 >> 4)) >> 16) + ((qy.z * (t1 >> 4)) >> 16) + 2) >> 2;   // in [0, 255], see k_resize
-            if (keep) nxt[yy * dp + xx] = (uint8_t)v;
-            if (x < own_x && y < own_y) dst[(long long)y * L.pitch + x] = (uint8_t)v;
+            short4 qx[4];
+            if (xx + 3 < rw) {           // the four records are contiguous (8 bytes each, 8-byte aligned)
+                const uint2 *tp = reinterpret_cast<const uint2 *>(tx + 4 * x);
+                const uint2 t0_ = tp[0], t1_ = tp[1], t2_ = tp[2], t3_ = tp[3];
+                qx[0] = *reinterpret_cast<const short4 *>(&t0_); qx[1] = *reinterpret_cast<const short4 *>(&t1_);
+                qx[2] = *reinterpret_cast<const short4 *>(&t2_); qx[3] = *reinterpret_cast<const short4 *>(&t3_);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) qx[j] = *reinterpret_cast<const short4 *>(tx + 4 * min(x + j, hx - 1));
+            }
+            uint32_t out = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int sx0 = qx[j].x, sx1 = min(sx0 + 1, s_w - 1);
+                const int t0 = r0[sx0] * qx[j].y + r0[sx1] * qx[j].z;
+                const int t1 = r1[sx0] * qx[j].y + r1[sx1] * qx[j].z;
+                const int v = (((qy.y * (t0 >> 4)) >> 16) + ((qy.z * (t1 >> 4)) >> 16) + 2) >> 2;   // in [0, 255], see k_resize
+                out |= (uint32_t)v << (8 * j);
+            }
+            if (keep) *reinterpret_cast<uint32_t *>(nxt + yy * dp + xx) = out;
+            if (y < own_y) {
+                uint8_t *d = dst + (long long)y * L.pitch + x;
+                if (x + 3 < own_x) *reinterpret_cast<uint32_t *>(d) = out;      // (any byte alignment: global memory takes unaligned dwords)
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; j++) if (x + j < own_x) d[j] = (uint8_t)(out >> (8 * j));
+            }
         }
         __syncthreads();
         { uint8_t *t = cur; cur = nxt; nxt = t; }
@@ -355,12 +380,24 @@ struct FastArgs {
 __device__ unsigned long long g_fast_stamp[4096 * 8]; // diagnostic build only: summed phase cycles of k_fast, 4096 slots
 __device__ unsigned long long g_desc_stamp[4096 * 8]; // same for k_desc
 __device__ unsigned long long g_tree_stamp[4096 * 8]; // same for the level-0 workgroups of k_tree (slot 6 = phase-2 sweeps, 7 = workgroups)
+#ifdef ORBX_DIAG_SPANS_ONLY     // the phase stamps perturb the waves they measure (an atomic per phase): off when only the spans are wanted
+#define STAMP_TO(arr, k) do { (void)_t_prev; } while (0)
+#else
 #define STAMP_TO(arr, k) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
     if (threadIdx.x == 0) atomicAdd(&arr[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + (k)], _t - _t_prev); _t_prev = _t; } while (0)
+#endif
+// wall-clock life of every wave of a launch (s_memrealtime, 100 MHz): (start, end) in the wave's own slot -- no atomics, nothing shared
+#define SPAN_SLOTS 16384
+__device__ uint2 g_span[2][SPAN_SLOTS];
+#define SPAN_BEGIN() const unsigned _sp0 = (unsigned)__builtin_amdgcn_s_memrealtime()
+#define SPAN_END(K) do { if ((threadIdx.x & 63) == 0) { const unsigned _id = blockIdx.x + gridDim.x * blockIdx.y; \
+    if (_id < SPAN_SLOTS) g_span[K][_id] = make_uint2(_sp0, (unsigned)__builtin_amdgcn_s_memrealtime()); } } while (0)
 #define STAMP(k) STAMP_TO(g_fast_stamp, k)
 #define DSTAMP(k) STAMP_TO(g_desc_stamp, k)
 #define TSTAMP(k) do { if (blockIdx.y == 0) STAMP_TO(g_tree_stamp, k); } while (0)
 #else
+#define SPAN_BEGIN() do { } while (0)
+#define SPAN_END(K) do { } while (0)
 #define STAMP(k) do { } while (0)
 #define DSTAMP(k) do { } while (0)
 #define TSTAMP(k) do { } while (0)
@@ -395,6 +432,7 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
 #ifdef ORBX_DIAG
     unsigned long long _t_prev = __builtin_amdgcn_s_memtime();
 #endif
+    SPAN_BEGIN();
     // the 40-byte record as ten dwords (scalar loads; 16-bit fields fetched by themselves become vector loads on gfx950)
     CellRec rec;
     {
@@ -609,12 +647,24 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
         if (lane == 0) *my_cnt = min(total, rec.cand_cap);
     }
     STAMP(4);
+    SPAN_END(0);
 #ifdef ORBX_DIAG
     if (lane == 0) atomicAdd(&g_fast_stamp[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + 7], 1ull);
 #endif
 }
 
 #ifdef ORBX_DIAG
+extern "C" int orbx_diag_spans(unsigned *out /*[2][SPAN_SLOTS][2]*/, int reset)
+{
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(uint2) * 2 * SPAN_SLOTS));
+    if (reset) {
+        static uint2 z[2][SPAN_SLOTS];
+        ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_span), z, sizeof z));
+    }
+    return ORBX_OK;
+}
+
 extern "C" int orbx_diag_desc_stamps(unsigned long long *out, int reset)
 {
     ORBX_HIP(hipDeviceSynchronize());
@@ -1132,7 +1182,12 @@ __global__ __launch_bounds__(64) void k_desc(const DescArgs da, PyrRef pr, const
     // grid = (8 * kp_total, ceil(images / 8)): blockIdx.x = 8 * slot + XCD, blockIdx.y = group of eight images; the linear
     // workgroup id (dispatch order) then has the XCD in its low three bits and the slot running fastest within an XCD
     // (with the row table on, slot "-1" -- the first workgroups dispatched -- is the table wave of each image)
-    const int slot = (int)(blockIdx.x >> 3) - rt.on, b = (int)(blockIdx.y * 8u + (blockIdx.x & 7u));
+    // A launch of fewer than eight images (a single stereo frame: two) has no empty XCD columns in its grid: blockIdx.x = xg * slot +
+    // image, xg = min(8, images) -- dispatching the 6 800 empty workgroups of an 8-wide grid took longer than the 2 000 waves that
+    // had work (their starts spread over 6.5 us).
+    const unsigned xg = gridDim.y == 1 && nimg < 8 ? (unsigned)nimg : 8u;
+    const unsigned sx = xg == 8 ? blockIdx.x >> 3 : blockIdx.x / xg;
+    const int slot = (int)sx - rt.on, b = (int)(blockIdx.y * 8u + (blockIdx.x - sx * xg));
     if (b >= nimg) return;
     if (slot < 0) {
         desc_rowtab<NL>(da, lvl_cnt + (long long)b * ORBX_MAX_LEVELS, lvl_kp + (long long)b * da.kp_total, cap, rt, b,
@@ -1151,6 +1206,7 @@ __global__ __launch_bounds__(64) void k_desc(const DescArgs da, PyrRef pr, const
 #ifdef ORBX_DIAG
     unsigned long long _t_prev = __builtin_amdgcn_s_memtime();
 #endif
+    SPAN_BEGIN();
     const uint32_t p = lvl_kp[(long long)b * da.kp_total + slot];
     // the lane's four pattern words (lane-indexed constant data = vector loads) are requested here, with the first
     // memory round trip, not in the sampling phase where they would cost a round trip of their own
@@ -1322,6 +1378,7 @@ __global__ __launch_bounds__(64) void k_desc(const DescArgs da, PyrRef pr, const
         out_kps[(long long)b * cap + idx] = kp;
     }
     DSTAMP(4);
+    SPAN_END(1);
 #ifdef ORBX_DIAG
     if (lane == 0) atomicAdd(&g_desc_stamp[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + 7], 1ull);
 #endif
@@ -1462,7 +1519,7 @@ static bool build_pyr_groups(orbx_extractor *e, const Geom &G, std::vector<int16
                             const int pitch_lim = lo[i] + (((dim(first - 1) - lo[i]) + 3) & ~3);      // align4(w) as seen from lo: never past the pitch
                             const int ndw = (std::min(lo[i] + ((hi[i] - lo[i] + 3) & ~3), pitch_lim) - lo[i]) / 4;
                             r[3] = (int16_t)ndw; div = ndw; extent = 4 * ndw;
-                        } else { div = extent; extent = (extent + 3) & ~3; }
+                        } else { div = (extent + 3) >> 2; extent = (extent + 3) & ~3; }     // groups of four pixels per row
                         const unsigned magic = (unsigned)((0x100000000ull + (unsigned)div - 1) / (unsigned)div);
                         r[4] = (int16_t)(magic & 0xFFFF); r[5] = (int16_t)(magic >> 16);
                     }
@@ -2017,7 +2074,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
         rt.row_off = e->d_rt_off; rt.entries = (uint4 *)e->d_rt_entries; rt.ent_cap = e->rt_ent_cap; rt.rows = G.lv[0].h; rt.on = 1;
         e->rt_kps = d_kps; e->rt_cap = cap; e->rt_batch = batch;
     }
-    hipLaunchKernelGGL((G.nlevels <= 8 ? k_desc<8> : k_desc<ORBX_MAX_LEVELS>), dim3(8 * (G.kp_total + rt.on), (batch + 7) / 8), dim3(64), 0, s, da, pr, e->d_lvl_cnt, e->d_lvl_kp,
+    hipLaunchKernelGGL((G.nlevels <= 8 ? k_desc<8> : k_desc<ORBX_MAX_LEVELS>), dim3((batch < 8 ? batch : 8) * (G.kp_total + rt.on), (batch + 7) / 8), dim3(64), 0, s, da, pr, e->d_lvl_cnt, e->d_lvl_kp,
                        (orbx_keypoint *)d_kps, (uint8_t *)d_desc, (int *)d_n_out, cap, batch, rt);
     orbx_prof_end(e, s);
     ORBX_HIP(hipGetLastError());

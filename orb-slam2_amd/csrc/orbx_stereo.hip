@@ -12,6 +12,7 @@
 // The row table normally comes with the extraction (desc_rowtab in orbx_extract.hip); k_stereo_prep is the form for keypoints that
 // did not come from the right extractor's last launch.
 #include "orbx_device.h"
+#include <stdlib.h>
 
 struct StereoTabs { float sf[ORBX_MAX_LEVELS]; float isf[ORBX_MAX_LEVELS]; };
 
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                 float bf, float max_d, StereoTabs tabs, float *__restrict__ u_right,
                                                 float *__restrict__ depth, int *__restrict__ st_dist,
                                                 const int *__restrict__ row_off, const uint4 *__restrict__ entries, int ent_cap, int reach,
-                                                int *__restrict__ arrive)
+                                                int *__restrict__ arrive, int kpw)
 {
     // A wave takes FOUR left keypoints.  Coarse stage: one keypoint per 16-lane row (a row of the table holds ~25
     // candidates, so a whole wave per keypoint left most lanes idle and paid the dependent load chain
@@ -156,13 +157,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // keypoints (0..4) one at a time with all 64 lanes on the 11x11x11 SAD.
     constexpr int SW_BYTES = 11 * 16 + 11 * 28 + 4; // per wave: left window rows (16 B) + right window rows (28 B)
     __shared__ __align__(16) uint8_t s_win[4 * ((SW_BYTES + 15) & ~15)];
+    // kpw = keypoints per wave: 4 for batches; 1 when the launch has few pairs (a single frame leaves most of the chip idle, and the
+    // fine stages of a wave's keypoints run one after the other: with one keypoint per wave they all run side by side)
     const int p = blockIdx.y, lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
-    const int il_base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    const int il_base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kpw;
     const int n_l = nL[p];
-    if ((int)blockIdx.x * 16 >= n_l) return;    // the whole workgroup (the pair's last workgroup is counted among ceil(n_l / 16))
+    if ((int)blockIdx.x * 4 * kpw >= n_l) return;    // the whole workgroup (the pair's last workgroup is counted among ceil(n_l / (4 kpw)))
     if (il_base < n_l) {                        // wave-uniform
     const int il = il_base + sub;
-    const bool have = il < n_l;
+    const bool have = il < n_l && sub < kpw;
     const long long ol = (long long)p * cap + (have ? il : il_base);
     const uint32_t *dr = dR + (long long)p * cap * 8;
     const orbx_keypoint kp = kL[ol];
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     const unsigned best_row = row16_min_u32(mine);                                   // per 16-lane row
     const unsigned bx_row = row16_or_u32(mine == best_row && mine != 0xFFFFFFFFu ? __float_as_uint(mine_x) : 0u); // the key holds iR: one owner
-    for (int gk = 0; gk < 4; gk++) { // fine stage, one keypoint at a time (all values wave-uniform from here)
+    for (int gk = 0; gk < kpw; gk++) { // fine stage, one keypoint at a time (all values wave-uniform from here)
         if (il_base + gk >= n_l) break;
         const unsigned best = (unsigned)__builtin_amdgcn_readlane((int)best_row, gk * 16);
         const int best_dist = best == 0xFFFFFFFFu ? 100 : (int)(best >> 16);
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int nwg = (n_l + 15) / 16;
+        const int nwg = (n_l + 4 * kpw - 1) / (4 * kpw);
         const int old = __hip_atomic_fetch_add(&arrive[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = old == nwg - 1;
         if (old == nwg - 1) __hip_atomic_store(&arrive[p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
@@ -422,11 +425,14 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
     if (!by_product)
         hipLaunchKernelGGL(k_stereo_prep, dim3(batch), dim3(256), (size_t)2 * ((rows + 4) & ~3) * sizeof(int), s, L->d_geom,
                            (const orbx_keypoint *)d_kR, (const int *)d_nR, cap, tabs, (int *)d_row_off, (uint4 *)d_entries, ent_cap);
-    hipLaunchKernelGGL(k_stereo, dim3((cap + 15) / 16, batch), dim3(256), 0, s, L->d_geom, pl, pr, img_l0, img_r0,
+    const char *kpw_env = getenv("ORBX_STEREO_KPW");                     // tests: both forms on the same input
+    const int kpw_forced = kpw_env && (*kpw_env == '1' || *kpw_env == '4') ? *kpw_env - '0' : 0;
+    const int kpw = kpw_forced ? kpw_forced : (long long)batch * cap <= 16384 ? 1 : 4;    // few pairs: one keypoint per wave (see k_stereo)
+    hipLaunchKernelGGL(k_stereo, dim3((cap + 4 * kpw - 1) / (4 * kpw), batch), dim3(256), 0, s, L->d_geom, pl, pr, img_l0, img_r0,
                        (const orbx_keypoint *)d_kL, (const uint32_t *)d_dL, (const int *)d_nL,
                        (const orbx_keypoint *)d_kR, (const uint32_t *)d_dR, (const int *)d_nR, cap, bf, max_d, tabs,
                        (float *)d_u_right, (float *)d_depth, L->d_st_dist, (const int *)d_row_off, (const uint4 *)d_entries, row_ent_cap, reach,
-                       L->d_st_arrive);
+                       L->d_st_arrive, kpw);
     orbx_prof_end(L, s);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;

@@ -317,6 +317,23 @@ def test_stereo_parity(pkg, oracle, seed, w, h, nf):
     assert (np.abs((kL["x"] - ur)[ok] - d_true[ok]) < 2.0).mean() > 0.8
 
 
+@pytest.mark.parametrize("kpw,rowtab", [("1", True), ("4", True), ("1", False), ("4", False)])
+def test_stereo_launch_forms(pkg, oracle, monkeypatch, kpw, rowtab):
+    """ComputeStereoMatches has two wave shapes (one / four left keypoints per wave: single frames / batches) and two sources of the
+    row table (built inside the descriptor launch of the right image, or by k_stereo_prep for keypoints handed in by the caller):
+    all four combinations give the oracle's uRight / depth bit for bit, through the host API and through the single-call form"""
+    monkeypatch.setenv("ORBX_STEREO_KPW", kpw)
+    if not rowtab:
+        monkeypatch.setenv("ORBX_NO_ROWTAB", "1")
+    for seed, w, h, nf in [(63, 1241, 376, 1000), (64, 640, 480, 1200)]:
+        ur, dp, our, odp, kL, disp = _stereo_case(pkg, oracle, seed, w, h, nf)
+        assert ur.tobytes() == our.tobytes() and dp.tobytes() == odp.tobytes() and (ur >= 0).sum() > 50
+        left, right, _ = synth.stereo_pair(seed, w, h)
+        ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7, device=0, max_size=(w, h), max_batch=2)
+        r = ex.extract_stereo(left, right, 386.1448, 386.1448 / 718.856)
+        assert r[4].tobytes() == our.tobytes() and r[5].tobytes() == odp.tobytes()
+
+
 def test_stereo_rejects_bad_octave(pkg):
     w, h = 640, 480
     exL, exR = _extractor(pkg, 300, w, h), _extractor(pkg, 300, w, h)

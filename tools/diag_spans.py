@@ -1,0 +1,42 @@
+"""Wall-clock span of the waves of ONE k_fast / k_desc launch (diagnostic build, s_memrealtime 100 MHz): first wave start -> last wave
+end, the longest wave, the mean wave.  Compare with the kernel's duration in a rocprofv3 trace: the difference is launch overhead,
+the longest wave is the floor of the launch.   python tools/diag_spans.py [frames per launch]"""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["ORBX_SO"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diag", "liborbx_spans.so")   # g.build_diag(("-DORBX_DIAG", "-DORBX_DIAG_SPANS_ONLY"), "liborbx_spans.so")
+import numpy as np, torch
+import __graft_entry__ as ge
+from tools import synth
+pkg = ge.load_pkg(); L = pkg.lib()
+W, H, B = 1241, 376, (int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+pairs = [synth.stereo_pair(1000 + i, W, H)[:2] for i in range(4)]
+pitch = 1280; host = np.zeros((2 * B, H, pitch), np.uint8)
+for i in range(B): host[i, :, :W] = pairs[i % 4][0]; host[B + i, :, :W] = pairs[i % 4][1]
+imgs = torch.from_numpy(host).cuda()
+ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7, device=0, max_size=(W, H), max_batch=2 * B)
+cap = ex.max_keypoints(W, H)
+kps = torch.zeros((2 * B, cap, 7), device='cuda'); desc = torch.zeros((2 * B, cap, 32), dtype=torch.uint8, device='cuda'); n = torch.zeros(2 * B, dtype=torch.int32, device='cuda')
+def step(): ex.extract_batch_device(imgs.data_ptr(), H * pitch, pitch, 2 * B, W, H, kps.data_ptr(), desc.data_ptr(), cap, n.data_ptr(), None)
+for _ in range(3): step()
+ex.sync()
+SL = 16384
+out = (C.c_uint32 * (2 * SL * 2))()
+L.orbx_diag_spans(out, 1)
+N = 20
+res = {0: [], 1: []}
+worst = {0: [], 1: []}
+for _ in range(N):
+    step(); ex.sync()
+    L.orbx_diag_spans(out, 1)
+    o = np.frombuffer(out, dtype=np.uint32).reshape(2, SL, 2).astype(np.int64)
+    for k in range(2):
+        v = o[k][o[k, :, 1] != 0]
+        life = (v[:, 1] - v[:, 0]) / 100.0
+        res[k].append([(v[:, 1].max() - v[:, 0].min()) / 100.0, life.max(), life.mean(), np.percentile(life, 50), np.percentile(life, 90), np.percentile(life, 99), len(v),
+                       (v[:, 0].max() - v[:, 0].min()) / 100.0])
+        ids = np.nonzero(o[k, :, 1] != 0)[0]
+        worst[k].append(ids[np.argsort(-life)[:5]].tolist())
+for k, nm in enumerate(("k_fast", "k_desc")):
+    r = np.array(res[k]).mean(axis=0)
+    print(f"{nm}: first start -> last end {r[0]:.1f} us (last start {r[7]:.1f} us after the first); wave life: longest {r[1]:.1f}, mean {r[2]:.1f}, p50 {r[3]:.1f}, p90 {r[4]:.1f}, p99 {r[5]:.1f} us; waves {r[6]:.0f}")
+    print("   slowest workgroup ids of the last launches:", worst[k][-3:])
