@@ -373,6 +373,7 @@ struct FastArgs {
     int lds_sc, lds_list, lds_bm;   // LDS carve: score tile, candidate list, candidate bitmap (the survivor bitmap follows it)
     int bm_rows;                    // bitmap rows (u64 each): tallest detect area plus the row overrun of the last pretest iteration
     int ini_th, min_th;
+    int list_cap;                   // entries of the candidate list (used by the several-waves-per-cell form; one wave: ORBX_FAST_LIST_CAP)
     long long cand_total;
 };
 
@@ -380,8 +381,11 @@ struct FastArgs {
 __device__ unsigned long long g_fast_stamp[4096 * 8]; // diagnostic build only: summed phase cycles of k_fast, 4096 slots
 __device__ unsigned long long g_desc_stamp[4096 * 8]; // same for k_desc
 __device__ unsigned long long g_tree_stamp[4096 * 8]; // same for the level-0 workgroups of k_tree (slot 6 = phase-2 sweeps, 7 = workgroups)
-#ifdef ORBX_DIAG_SPANS_ONLY     // the phase stamps perturb the waves they measure (an atomic per phase): off when only the spans are wanted
-#define STAMP_TO(arr, k) do { (void)_t_prev; } while (0)
+#ifdef ORBX_DIAG_SPANS_ONLY     // the summed phase stamps perturb the waves they measure (an atomic per phase): here every wave of k_fast logs
+                                // the end of its phases in its own slot instead
+__device__ unsigned g_fast_phase[16384][8];
+#define STAMP_TO(arr, k) do { (void)_t_prev; if ((const void *)arr == (const void *)g_fast_stamp && threadIdx.x == 0) { \
+    const unsigned _id = blockIdx.x + gridDim.x * blockIdx.y; if (_id < 16384) g_fast_phase[_id][k] = (unsigned)__builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define STAMP_TO(arr, k) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
     if (threadIdx.x == 0) atomicAdd(&arr[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + (k)], _t - _t_prev); _t_prev = _t; } while (0)
@@ -407,8 +411,13 @@ __device__ uint2 g_span[2][SPAN_SLOTS];
 // (one direct load = 5 tile rows of 12 dwords, 60 lanes), else (80, 64) (3 rows of 20 dwords).  Both tile pitches put rows
 // r and r + 8 (and no closer pair) on the same LDS banks: candidates line up along vertical image edges, and with a
 // 64-byte pitch (rows r, r + 2 on the same banks) the byte reads of the score network ran 3.4x the bank-conflict cycles.
-template <int P, int SP>
-__global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *__restrict__ cells, PyrRef pr,
+// NW = waves per cell: 1 for batches (above).  A launch of a frame or two leaves most of the chip idle and lasts as long as its
+// fullest cell (a cell with 5x the candidates of the median one ran 15.6 us against 5.3 us: the score and maximum loops walk the
+// candidate list 64 at a time): there NW waves share the cell -- tile rows, pretest rows and list entries are dealt round-robin to
+// the waves, the bitmaps and tiles are the workgroup's, list and emission stay with wave 0.  Same results by construction: every
+// phase writes disjoint bytes or ORs bits, and the phases are separated by the barriers the one-wave form already has.
+template <int P, int SP, int NW>
+__global__ __launch_bounds__(64 * NW) void k_fast(const FastArgs fa, const CellRec *__restrict__ cells, PyrRef pr,
                                              int *__restrict__ cell_cnt, uint32_t *__restrict__ cand, uint32_t *__restrict__ cand_prim)
 {
     constexpr int DWR = P / 4;      // dwords per tile row = lanes per row of one direct load
@@ -419,7 +428,7 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
     uint32_t *bm = reinterpret_cast<uint32_t *>(fast_smem + fa.lds_bm); // candidate bitmap, then survivor bitmap: u64 per row
     uint32_t *sv = bm + 2 * fa.bm_rows;
     const int ini_th = fa.ini_th, min_th = fa.min_th;
-    const int b = blockIdx.y, lane = threadIdx.x;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = NW == 1 ? 0 : (int)(threadIdx.x >> 6), tid = threadIdx.x;
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8, speed only): remap so that FAST_XG
     // horizontally adjacent cells land on the same XCD (their halos share cache lines in that XCD's L2) while each
     // XCD's work stays spread over the whole image (contiguous runs per XCD were measured slower).
@@ -469,17 +478,20 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
         const unsigned voff = (unsigned)(lr0 * pitch + 4 * lc);
         const int full = th / RPL;
         if (lc < ndw && lr0 < RPL) {
-            for (int k = 0; k < full; k++, base += (long long)RPL * pitch)
+            base += (long long)wv * RPL * pitch;
+            for (int k = wv; k < full; k += NW, base += (long long)NW * RPL * pitch)
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(base + voff), reinterpret_cast<uint32_t *>(tile + RPL * P * k), 4, 0, 0);
-            if (full * RPL + lr0 < th)                  // the last, partial group of rows never reads below the cell
+            // the last, partial group of rows never reads below the cell (after the loop `base` stands at this wave's next group:
+            // the partial group is `full`, taken by the wave whose turn it is)
+            if ((NW == 1 || full % NW == wv) && full * RPL + lr0 < th)
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(base + voff), reinterpret_cast<uint32_t *>(tile + RPL * P * full), 4, 0, 0);
         }
     }
     {   // meanwhile: zero score tile (1-px zero rim included) and both bitmaps
         uint4 *z = reinterpret_cast<uint4 *>(sc);
-        for (int i = lane; i < ((dh + 2) * SP + 15) / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < ((dh + 2) * SP + 15) / 16; i += 64 * NW) z[i] = make_uint4(0, 0, 0, 0);
         uint4 *zb = reinterpret_cast<uint4 *>(bm);
-        for (int i = lane; i < fa.bm_rows; i += 64) zb[i] = make_uint4(0, 0, 0, 0);   // 2 bitmaps x 8 bytes per row
+        for (int i = tid; i < fa.bm_rows; i += 64 * NW) zb[i] = make_uint4(0, 0, 0, 0);   // 2 bitmaps x 8 bytes per row
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the direct loads have landed in LDS
     __syncthreads();
@@ -512,9 +524,9 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
         // KB = (RB | 0x80) - 0x7f.  Corner candidates: (N | S) & (E | W) on either side.
         {
             const unsigned s7 = (unsigned)((th_cur + 1) >> 1) * 0x01010101u;
-            const uint8_t *pc = tile + (lr + 3) * P + 4 * (1 + gq);
-            uint32_t *pb = bm + lr * 2 + (gq >> 3);
-            for (int r0 = 0; r0 < dh; r0 += rpi, pc += rpi * P, pb += rpi * 2) {
+            const uint8_t *pc = tile + (lr + 3 + wv * rpi) * P + 4 * (1 + gq);
+            uint32_t *pb = bm + (lr + wv * rpi) * 2 + (gq >> 3);
+            for (int r0 = wv * rpi; r0 < dh; r0 += NW * rpi, pc += NW * rpi * P, pb += NW * rpi * 2) {
                 const uint32_t *rc = reinterpret_cast<const uint32_t *>(pc);
                 const unsigned C = rc[0], Wd = rc[-1], Ed = rc[1], N = rc[3 * DWR], S = rc[-3 * DWR];
                 const unsigned Wv = __builtin_amdgcn_alignbyte(C, Wd, 1), Ev = __builtin_amdgcn_alignbyte(Ed, C, 3);
@@ -547,7 +559,7 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
         // maximum search below then takes one iteration where the full list took two or three.  Returns their number.
         auto score_entries = [&](int n, bool compact) -> int {
             int n2 = 0;
-            for (int i0 = 0; i0 < n; i0 += 64) {
+            for (int i0 = 64 * wv; i0 < n; i0 += 64 * NW) {
                 const int i = i0 + lane;
                 int e = 0, s = 0;
                 if (i < n) {
@@ -556,17 +568,17 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
                     s = fast_score_full<P>(t0 + py * P + px, th_cur);
                     sc[(py + 1) * SP + px + 1] = (uint8_t)s;
                 }
-                if (compact) {
+                if (NW == 1 && compact) {     // (in place, ordered: one wave only)
                     const unsigned long long m = __ballot(s > 0);
                     if (s > 0) list[n2 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (uint16_t)e;
                     n2 += __popcll(m);
                 }
             }
-            return n2;
+            return NW == 1 ? n2 : n;        // several waves: the maximum search walks the whole list (entries that are no corners have score 0)
         };
         // ---- 5. strict 3x3 maximum of the listed pixels (only they can score > 0) -> survivor bitmap
         auto mark_maxima = [&](int n) {
-            for (int i0 = 0; i0 < n; i0 += 64) {
+            for (int i0 = 64 * wv; i0 < n; i0 += 64 * NW) {
                 const int i = i0 + lane;
                 if (i < n) {          // lanes without an entry issue no LDS traffic at all (an LDS atomic costs per active lane, also one that ORs a zero)
                     const int e = list[i], py = e >> 6, px = e & 63;
@@ -578,37 +590,55 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
                 }
             }
         };
-        if (nlist <= ORBX_FAST_LIST_CAP) {
-            {
+        const int list_cap = NW == 1 ? ORBX_FAST_LIST_CAP : fa.list_cap;     // several waves: a whole cell, always one round
+        if (nlist <= list_cap) {
+            if (NW == 1) {
                 unsigned lo = c_lo, hi = c_hi;
                 uint16_t *lp = list + (c_incl - c_cnt);
                 while (lo) { *lp++ = (uint16_t)(rowbits | (unsigned)__builtin_ctz(lo)); lo &= lo - 1; }
                 while (hi) { *lp++ = (uint16_t)(rowbits | 32u | (unsigned)__builtin_ctz(hi)); hi &= hi - 1; }
+            } else {
+                // every wave has the same segments and offsets: wave w unrolls bits [16 w / NW * ..) of each 16-bit quarter -- the bit
+                // walk is as long as the fullest piece, and a piece is 1 / NW of what one wave walked
+                constexpr int PIECE = 64 / 4;                        // a 64-bit row in four 16-bit quarters, each cut in NW pieces
+                const unsigned long long rowm = (unsigned long long)c_lo | ((unsigned long long)c_hi << 32);
+                uint16_t *lp0 = list + (c_incl - c_cnt);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int b0 = q * PIECE + (PIECE * wv) / NW, b1 = q * PIECE + (PIECE * (wv + 1)) / NW;
+                    const unsigned long long below0 = (1ull << b0) - 1ull, below1 = b1 >= 64 ? ~0ull : (1ull << b1) - 1ull;   // b0 < 64 always
+                    unsigned long long m = rowm & below1 & ~below0;
+                    uint16_t *lp = lp0 + __popcll(rowm & below0);
+                    while (m) { *lp++ = (uint16_t)(rowbits | (unsigned)__builtin_ctzll(m)); m &= m - 1; }
+                }
             }
             __syncthreads();
+            STAMP(5);
             const int ncorner = score_entries(nlist, true);
+            STAMP(6);
             __syncthreads();
             STAMP(2);
             mark_maxima(ncorner);
             __syncthreads();
         } else {
             auto list_round = [&](int base) {   // the candidates of rank base .. base + CAP - 1
+                if (wv != 0) return;
                 unsigned lo = c_lo, hi = c_hi;
                 int r = c_incl - c_cnt - base;
-                while (lo) { if ((unsigned)r < (unsigned)ORBX_FAST_LIST_CAP) list[r] = (uint16_t)(rowbits | (unsigned)__builtin_ctz(lo)); r++; lo &= lo - 1; }
-                while (hi) { if ((unsigned)r < (unsigned)ORBX_FAST_LIST_CAP) list[r] = (uint16_t)(rowbits | 32u | (unsigned)__builtin_ctz(hi)); r++; hi &= hi - 1; }
+                while (lo) { if ((unsigned)r < (unsigned)list_cap) list[r] = (uint16_t)(rowbits | (unsigned)__builtin_ctz(lo)); r++; lo &= lo - 1; }
+                while (hi) { if ((unsigned)r < (unsigned)list_cap) list[r] = (uint16_t)(rowbits | 32u | (unsigned)__builtin_ctz(hi)); r++; hi &= hi - 1; }
             };
-            for (int base = 0; base < nlist; base += ORBX_FAST_LIST_CAP) {
+            for (int base = 0; base < nlist; base += list_cap) {
                 list_round(base);
                 __syncthreads();
-                score_entries(min(ORBX_FAST_LIST_CAP, nlist - base), false);
+                score_entries(min(list_cap, nlist - base), false);
                 __syncthreads();
             }
             STAMP(2);
-            for (int base = 0; base < nlist; base += ORBX_FAST_LIST_CAP) {
+            for (int base = 0; base < nlist; base += list_cap) {
                 list_round(base);
                 __syncthreads();
-                mark_maxima(min(ORBX_FAST_LIST_CAP, nlist - base));
+                mark_maxima(min(list_cap, nlist - base));
                 __syncthreads();
             }
         }
@@ -624,7 +654,7 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
         th_cur = min_th;
     }
     // ---- ordered (row-major) emission into the cell's candidate slots: lane = bitmap segment (row, or half a row)
-    {
+    if (wv == 0) {
         unsigned lo = 0, hi = 0;
         if (brow < dh) { const uint2 m = *reinterpret_cast<const uint2 *>(sv + 2 * brow); lo = half_mode ? (m.x >> bsh) & 0xFFFFu : m.x; hi = half_mode ? 0u : m.y; }
         const int incl = wave_incl_scan(nsurv);
@@ -654,6 +684,15 @@ __global__ __launch_bounds__(64) void k_fast(const FastArgs fa, const CellRec *_
 }
 
 #ifdef ORBX_DIAG
+#ifdef ORBX_DIAG_SPANS_ONLY
+extern "C" int orbx_diag_fast_phases(unsigned *out /*[16384][8]*/)
+{
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fast_phase), sizeof(unsigned) * 16384 * 8));
+    return ORBX_OK;
+}
+#endif
+
 extern "C" int orbx_diag_spans(unsigned *out /*[2][SPAN_SLOTS][2]*/, int reset)
 {
     ORBX_HIP(hipDeviceSynchronize());
@@ -1622,6 +1661,10 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         G.fast_lds_bm = G.fast_lds_list + (int)align_up((size_t)std::min(max_npx, ORBX_FAST_LIST_CAP) * 2 + 16, 16);
         G.fast_bm_rows = (max_dh + 9 + 1) & ~1;          // even: the two bitmaps are zeroed as one run of 16-byte stores
         G.fast_lds_bytes = G.fast_lds_bm + 2 * G.fast_bm_rows * 8;
+        // several waves per cell (small launches: LDS is no limit there): the list holds every pixel of the largest cell -- one round always
+        G.fast_list_cap_big = std::max(max_npx, ORBX_FAST_LIST_CAP);
+        G.fast_lds_bm_big = G.fast_lds_list + (int)align_up((size_t)G.fast_list_cap_big * 2 + 16, 16);
+        G.fast_lds_bytes_big = G.fast_lds_bm_big + 2 * G.fast_bm_rows * 8;
     }
     // resize tables
     std::vector<int16_t> tabs(tab_units);
@@ -1858,6 +1901,8 @@ extern "C" int orbx_extractor_create(orbx_extractor **out, int nfeatures, float 
     {   // launches of up to this many images build the pyramid with k_pyr_group (2 launches instead of 7); more: k_resize per level
         const char *env = getenv("ORBX_PYR_GROUP_MAX_IMAGES");
         e->pyr_group_max_images = env && *env ? atoi(env) : 8;
+        const char *fw = getenv("ORBX_FAST_WAVES");      // tests / experiments: force k_fast's waves per cell
+        e->fast_waves = fw && *fw >= '1' && *fw <= '4' ? *fw - '0' : 0;
     }
     // src/ORBextractor.cc:436-461
     e->sf[0] = 1.0f; e->sig2[0] = 1.0f;
@@ -2031,12 +2076,21 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
     {
         FastArgs fa;
         fa.total_cells = G.total_cells; fa.lds_sc = G.fast_lds_sc; fa.lds_list = G.fast_lds_list; fa.lds_bm = G.fast_lds_bm;
-        fa.bm_rows = G.fast_bm_rows; fa.ini_th = e->ini_th; fa.min_th = e->min_th; fa.cand_total = G.cand_total;
+        fa.bm_rows = G.fast_bm_rows; fa.ini_th = e->ini_th; fa.min_th = e->min_th; fa.cand_total = G.cand_total; fa.list_cap = ORBX_FAST_LIST_CAP;
         const dim3 grid((G.total_cells + 8 * FAST_XG - 1) / (8 * FAST_XG) * (8 * FAST_XG), batch);
         if (G.fast_small)
-            hipLaunchKernelGGL((k_fast<48, 40>), grid, dim3(64), G.fast_lds_bytes, s, fa, e->d_cells, pr, e->d_cell_cnt, e->d_cand, e->d_cand_prim);
+        {
+            // a frame or two: several waves per cell (the launch lasts as long as its fullest cell); batches: one
+            const long long waves1 = (long long)G.total_cells * batch;
+            const int nw = e->fast_waves ? e->fast_waves : waves1 * 4 <= 16384 ? 4 : waves1 * 2 <= 8192 ? 2 : 1;
+            int lds_bytes = G.fast_lds_bytes;
+            if (nw > 1) { fa.list_cap = G.fast_list_cap_big; fa.lds_bm = G.fast_lds_bm_big; lds_bytes = G.fast_lds_bytes_big; }
+#define LAUNCH_FAST(NW_) hipLaunchKernelGGL((k_fast<48, 40, NW_>), grid, dim3(64 * NW_), lds_bytes, s, fa, e->d_cells, pr, e->d_cell_cnt, e->d_cand, e->d_cand_prim)
+            if (nw == 4) LAUNCH_FAST(4); else if (nw == 3) LAUNCH_FAST(3); else if (nw == 2) LAUNCH_FAST(2); else LAUNCH_FAST(1);
+#undef LAUNCH_FAST
+        }
         else
-            hipLaunchKernelGGL((k_fast<ORBX_TILE_PITCH, ORBX_SCORE_PITCH>), grid, dim3(64), G.fast_lds_bytes, s, fa, e->d_cells, pr, e->d_cell_cnt,
+            hipLaunchKernelGGL((k_fast<ORBX_TILE_PITCH, ORBX_SCORE_PITCH, 1>), grid, dim3(64), G.fast_lds_bytes, s, fa, e->d_cells, pr, e->d_cell_cnt,
                                e->d_cand, e->d_cand_prim);
     }
     orbx_prof_end(e, s);

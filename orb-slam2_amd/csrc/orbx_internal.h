@@ -47,6 +47,7 @@ struct Geom {
     int max_node_cap;
     int fast_lds_sc, fast_lds_list, fast_lds_bm, fast_bm_rows, fast_lds_bytes; // LDS carve of k_fast
     int fast_small;         // 1: k_fast<48,40> (every cell <= 38 px wide), 0: k_fast<80,64>
+    int fast_list_cap_big, fast_lds_bm_big, fast_lds_bytes_big;   // the carve with a candidate list that holds a whole cell (several waves per cell)
     LevelGeom lv[ORBX_MAX_LEVELS];
 };
 
@@ -125,6 +126,7 @@ struct orbx_extractor {
     struct PyrGroup { int first, n, tiles_x, tiles_y, tab_cx, tab_cy, lds_b, lds_bytes; } pyr_groups[ORBX_MAX_LEVELS];
     int n_pyr_groups;                // 0: this geometry has no grouped form (per-level launches at every batch size)
     int pyr_group_max_images;        // launches of at most this many images take the grouped form
+    int fast_waves;                  // waves per FAST cell: 0 = by launch size (several for a frame or two, one for batches); 1-4 forces (ORBX_FAST_WAVES)
     // stereo row table written by the most recent extraction as a by-product of k_desc (desc_rowtab): valid for the keypoint buffer
     // rt_kps (capacity rt_cap per image, rt_batch images); d_rt_off == nullptr: this geometry has none (more rows than k_desc's LDS holds)
     int *d_rt_off; size_t rt_off_cap; uint8_t *d_rt_entries; size_t rt_entries_cap; int rt_ent_cap;

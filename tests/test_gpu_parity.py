@@ -91,6 +91,25 @@ def test_pyramid_launch_forms(pkg, oracle, monkeypatch, groups):
         ex.set_pyramid_group_limit(-1)
 
 
+@pytest.mark.parametrize("nw", ["1", "2", "3", "4"])
+def test_fast_waves_per_cell(pkg, oracle, monkeypatch, nw):
+    """k_fast runs a cell on one wave (batches) or on several (a frame or two: the launch lasts as long as its fullest cell): every
+    split gives the oracle's candidates, in order, incl. cells fuller than the candidate list (rounds) and the minThFAST fallback"""
+    monkeypatch.setenv("ORBX_FAST_WAVES", nw)
+    for (w, h, nf, kind) in [(1241, 376, 1000, "scene"), (640, 480, 800, "checker"), (333, 257, 300, "scene"), (640, 480, 500, "lowcontrast")]:
+        if kind == "scene":
+            img = synth.image(w + int(nw), w, h, nshapes=int(w * h / 300) + 50)
+        elif kind == "checker":          # dense corners: candidate lists beyond ORBX_FAST_LIST_CAP
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = (((xx // 3 + yy // 3) & 1) * 200 + 20).astype(np.uint8)
+        else:                            # contrast between minThFAST and iniThFAST: every cell takes the second pass
+            rng = np.random.Generator(np.random.PCG64(5))
+            img = (100 + (synth.image(9, w, h).astype(np.int32) - 100) // 14).astype(np.uint8)
+        orc = oracle.Oracle(nf, 1.2, 8, 20, 7)
+        ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7, device=0, max_size=(w, h))
+        _check_stages(ex, orc, img, f"{w}x{h} {kind} fast waves {nw}")
+
+
 def test_extract_fhd_4000(pkg, oracle):
     img = synth.image(5, 1920, 1080, nshapes=4000)
     ex = _extractor(pkg, 4000, 1920, 1080)

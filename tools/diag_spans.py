@@ -40,3 +40,23 @@ for k, nm in enumerate(("k_fast", "k_desc")):
     r = np.array(res[k]).mean(axis=0)
     print(f"{nm}: first start -> last end {r[0]:.1f} us (last start {r[7]:.1f} us after the first); wave life: longest {r[1]:.1f}, mean {r[2]:.1f}, p50 {r[3]:.1f}, p90 {r[4]:.1f}, p99 {r[5]:.1f} us; waves {r[6]:.0f}")
     print("   slowest workgroup ids of the last launches:", worst[k][-3:])
+
+# phases of the slowest k_fast waves of the last launch (end of: load+zero, pretest, fullscore, nms, emit), and their cells' candidate counts
+ph = (C.c_uint32 * (16384 * 8))()
+L.orbx_diag_fast_phases(ph)
+ph = np.frombuffer(ph, dtype=np.uint32).reshape(16384, 8).astype(np.int64)
+o = np.frombuffer(out, dtype=np.uint32).reshape(2, SL, 2).astype(np.int64)
+ids = np.nonzero(o[0, :, 1] != 0)[0]
+life = (o[0, ids, 1] - o[0, ids, 0]) / 100.0
+order = ids[np.argsort(-life)]
+def show(i):
+    t0 = o[0, i, 0]
+    d = [(ph[i, k] - (ph[i, k - 1] if k else t0)) / 100.0 for k in range(5)]
+    extra = ""
+    if ph[i, 5] and ph[i, 6]:    # one-round cells: list built at [5], wave 0's score loop done at [6], everybody's at [2]
+        extra = " (score: list %.1f, loop of wave 0 %.1f, wait %.1f)" % ((ph[i, 5] - ph[i, 1]) / 100.0, (ph[i, 6] - ph[i, 5]) / 100.0, (ph[i, 2] - ph[i, 6]) / 100.0)
+    return "id %5d life %5.1f us: load %.1f pretest %.1f score %.1f nms %.1f emit %.1f" % (i, (o[0, i, 1] - t0) / 100.0, *d) + extra
+print("slowest k_fast waves:")
+for i in order[:8]: print("  ", show(i))
+print("median-ish waves:")
+for i in order[len(order) // 2: len(order) // 2 + 3]: print("  ", show(i))
