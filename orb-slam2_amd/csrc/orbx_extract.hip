@@ -788,8 +788,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
                              : reinterpret_cast<int *>(tree_smem + (reg_pts && tab_bytes < (size_t)ORBX_TREE_REG_PTS * 4 ? (size_t)ORBX_TREE_REG_PTS * 4 : tab_bytes));
     uint32_t *lpts = reinterpret_cast<uint32_t *>(cellpref + ((g->max_cells_level + 4) & ~3));
     uint16_t *lnid = reinterpret_cast<uint16_t *>(lpts + lds_pts_cap);
-    __shared__ int s_w[NT / 64];
+    __shared__ int s_w[2 * (NT / 64)];  // wave totals of the block scans; the one-barrier sweeps alternate between the halves
     __shared__ int s_acc;
+    __shared__ int s_acc2[2];           // n_to_expand of the one-barrier sweeps, alternating (the idle one is zeroed a sweep ahead)
 
     int *out_cnt = lvl_cnt + (long long)b * ORBX_MAX_LEVELS + l;
 #ifdef ORBX_DIAG
@@ -860,8 +861,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
     TSTAMP(0);  // cell counts, prefix, gather
     // ---- roots (src/ORBextractor.cc:627-705)
     const int N = L.quota;
-    for (int k = tid; k < L.n_ini; k += NT) cc[k] = 0;
-    __syncthreads();
+    int m;
     // With a handful of roots (3 for a 1241 x 376 level) every point of the level would hit one of 3 LDS addresses: same-address LDS
     // atomics serialise lane by lane, and this pass and the first classification were 27 % of a level-0 tree (36 k cycles).  A thread
     // owns at most 15 points per pass, so it counts them in 4-bit fields of one 64-bit register; the fields are summed over the wave
@@ -873,37 +873,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         }
     };
     const bool few_pts_per_thread = in_regs ? RP <= 15 : (n + NT - 1) / NT <= 15;
-    if (L.n_ini <= 16 && few_pts_per_thread) {
-        unsigned long long acc = 0;
-        FOR_POINTS({
-            int r = (int)((float)(p & 0xFFF) / L.hx);
-            r = r < 0 ? 0 : r >= L.n_ini ? L.n_ini - 1 : r;
-            acc += 1ull << (4 * r);
-            nd = (unsigned)r;
-        });
-        add_packed(acc, L.n_ini, cc);
-    } else {
-        FOR_POINTS({
-            int r = (int)((float)(p & 0xFFF) / L.hx);
-            r = r < 0 ? 0 : r >= L.n_ini ? L.n_ini - 1 : r;
-            atomicAdd(&cc[r], 1);
-            nd = (unsigned)r;
-        });
-    }
-    __syncthreads();
-    for (int k = tid; k < L.n_ini; k += NT) a1[k] = cc[k] > 0;
-    __syncthreads();
-    int m = lds_excl_scan_nt<NT>(a1, L.n_ini, s_w);
-    for (int k = tid; k < L.n_ini; k += NT)
-        if (cc[k] > 0) {
-            const int id = a1[k];
-            const unsigned x0 = (unsigned)(int)(L.hx * (float)k), x1 = (unsigned)(int)(L.hx * (float)(k + 1));
-            box[id] = make_uint2(x0 | (x1 << 16), 0u | ((unsigned)L.tree_h << 16));
-            cnt[id] = cc[k];
-        }
-    FOR_POINTS({ nd = (unsigned)a1[nd]; });
-    __syncthreads();
-
     // ---- sweeps.  Invariant at the top of the loop: cc[0..4m) holds the child counts of the current
     // table (cnt/box) and every point label is (node id | child << NB).
     auto classify = [&](int id, uint32_t p, const int *cn, const uint2 *bx_tab, int *cct) -> int {
@@ -918,16 +887,40 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         }
         return c;
     };
-    for (int k = tid; k < 4 * m; k += NT) cc[k] = 0;
-    __syncthreads();
-    if (4 * m <= 16 && few_pts_per_thread) {       // the same for the first classification: at most 16 (root, child) counters
+    if (L.n_ini <= 4 && few_pts_per_thread) {
+        // Up to four roots (every usual aspect ratio: 3 for 1241 x 376, 1 for 640 x 480): counting them, dropping the empty ones and
+        // the first classification are two barrier-to-barrier steps.  The root counts go to a scratch array that every thread then
+        // reads whole, so the id of a root (= non-empty roots before it) and the table size need no scan, and a root's box is
+        // arithmetic on its index, so the first classification does not wait for the table entries other threads write.
+        if (tid < 16) { a3[tid] = 0; cc[tid] = 0; }
+        __syncthreads();
+        {
+            unsigned long long acc = 0;
+            FOR_POINTS({
+                int r = (int)((float)(p & 0xFFF) / L.hx);
+                r = r < 0 ? 0 : r >= L.n_ini ? L.n_ini - 1 : r;
+                acc += 1ull << (4 * r);
+                nd = (unsigned)r;
+            });
+            add_packed(acc, L.n_ini, a3);
+        }
+        __syncthreads();
+        const int4 rc = *reinterpret_cast<const int4 *>(a3);          // counts of roots 0..3 (zero beyond n_ini)
+        const unsigned nz = (rc.x > 0 ? 1u : 0u) | (rc.y > 0 ? 2u : 0u) | (rc.z > 0 ? 4u : 0u) | (rc.w > 0 ? 8u : 0u);
+        m = __popc(nz);
+        if (tid < L.n_ini && ((nz >> tid) & 1u)) {
+            const int id = __popc(nz & ((1u << tid) - 1u));
+            const unsigned x0 = (unsigned)(int)(L.hx * (float)tid), x1 = (unsigned)(int)(L.hx * (float)(tid + 1));
+            box[id] = make_uint2(x0 | (x1 << 16), 0u | ((unsigned)L.tree_h << 16));
+            cnt[id] = tid == 0 ? rc.x : tid == 1 ? rc.y : tid == 2 ? rc.z : rc.w;
+        }
         unsigned long long acc = 0;
         FOR_POINTS({
-            const int id = (int)nd;
+            const int r = (int)nd, id = __popc(nz & ((1u << r) - 1u));
+            const int rcnt = r == 0 ? rc.x : r == 1 ? rc.y : r == 2 ? rc.z : rc.w;
             int c = 0;
-            if (cnt[id] > 1) {
-                const uint2 bx = box[id];
-                const int x0 = bx.x & 0xFFFF, x1 = bx.x >> 16, y0 = bx.y & 0xFFFF, y1 = bx.y >> 16;
+            if (rcnt > 1) {
+                const int x0 = (int)(L.hx * (float)r), x1 = (int)(L.hx * (float)(r + 1)), y0 = 0, y1 = L.tree_h;
                 const int x = p & 0xFFF, y = (p >> 12) & 0xFFF;
                 const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
                 c = (x >= x0 + hx ? 1 : 0) + (y >= y0 + hy ? 2 : 0);
@@ -937,14 +930,92 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         });
         add_packed(acc, 4 * m, cc);
     } else {
-        FOR_POINTS({ const int id = (int)nd; nd = (unsigned)(id | (classify(id, p, cnt, box, cc) << NB)); });
+        for (int k = tid; k < L.n_ini; k += NT) cc[k] = 0;
+        __syncthreads();
+        if (L.n_ini <= 16 && few_pts_per_thread) {
+            unsigned long long acc = 0;
+            FOR_POINTS({
+                int r = (int)((float)(p & 0xFFF) / L.hx);
+                r = r < 0 ? 0 : r >= L.n_ini ? L.n_ini - 1 : r;
+                acc += 1ull << (4 * r);
+                nd = (unsigned)r;
+            });
+            add_packed(acc, L.n_ini, cc);
+        } else {
+            FOR_POINTS({
+                int r = (int)((float)(p & 0xFFF) / L.hx);
+                r = r < 0 ? 0 : r >= L.n_ini ? L.n_ini - 1 : r;
+                atomicAdd(&cc[r], 1);
+                nd = (unsigned)r;
+            });
+        }
+        __syncthreads();
+        for (int k = tid; k < L.n_ini; k += NT) a1[k] = cc[k] > 0;
+        __syncthreads();
+        m = lds_excl_scan_nt<NT>(a1, L.n_ini, s_w);
+        for (int k = tid; k < L.n_ini; k += NT)
+            if (cc[k] > 0) {
+                const int id = a1[k];
+                const unsigned x0 = (unsigned)(int)(L.hx * (float)k), x1 = (unsigned)(int)(L.hx * (float)(k + 1));
+                box[id] = make_uint2(x0 | (x1 << 16), 0u | ((unsigned)L.tree_h << 16));
+                cnt[id] = cc[k];
+            }
+        FOR_POINTS({ nd = (unsigned)a1[nd]; });
+        __syncthreads();
+
+        for (int k = tid; k < 4 * m; k += NT) cc[k] = 0;
+        __syncthreads();
+        if (4 * m <= 16 && few_pts_per_thread) {       // the same for the first classification: at most 16 (root, child) counters
+            unsigned long long acc = 0;
+            FOR_POINTS({
+                const int id = (int)nd;
+                int c = 0;
+                if (cnt[id] > 1) {
+                    const uint2 bx = box[id];
+                    const int x0 = bx.x & 0xFFFF, x1 = bx.x >> 16, y0 = bx.y & 0xFFFF, y1 = bx.y >> 16;
+                    const int x = p & 0xFFF, y = (p >> 12) & 0xFFF;
+                    const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
+                    c = (x >= x0 + hx ? 1 : 0) + (y >= y0 + hy ? 2 : 0);
+                    acc += 1ull << (4 * (id * 4 + c));
+                }
+                nd = (unsigned)(id | (c << NB));
+            });
+            add_packed(acc, 4 * m, cc);
+        } else {
+            FOR_POINTS({ const int id = (int)nd; nd = (unsigned)(id | (classify(id, p, cnt, box, cc) << NB)); });
+        }
+
     }
     bool phase2 = false;
+    if (tid < 2) s_acc2[tid] = 0;
     TSTAMP(1);  // roots + first classification
-    for (;;) {
+    for (int sweep = 0;; sweep++) {
         const int prev = m;
         __syncthreads();
         int nsplit = 0, S, U;
+        // Phase-1 sweep of a table that fits one node per thread (every ORB-SLAM2 setting on 1024 threads, the small levels on 256):
+        // node k stays with thread k from its child counts to its children's table entries, so the split flags, the packed scan input
+        // and the scan result never go through LDS, and the sweep needs three workgroup barriers instead of six (a level-0 tree of a
+        // single frame is a chain of ~50 barrier-to-barrier steps of ~0.4 us each: that chain, not the work, is its 35 us).
+        const bool one_per_thread = !phase2 && m <= NT;
+        int my_nc = 0, my_run = 0;
+        if (one_per_thread) {
+            const int par = sweep & 1;
+            int v = 0;
+            if (tid < m) {
+                const int sp = cnt[tid] > 1;
+                my_nc = sp ? (cc[4 * tid] > 0) + (cc[4 * tid + 1] > 0) + (cc[4 * tid + 2] > 0) + (cc[4 * tid + 3] > 0) : 0;
+                v = sp ? my_nc : (1 << 16);
+            }
+            const int inc = wave_incl_scan(v);
+            if ((tid & 63) == 63) s_w[par * (NT / 64) + (tid >> 6)] = inc;
+            __syncthreads();
+            int base = 0, tot = 0;
+#pragma unroll
+            for (int i = 0; i < NT / 64; i++) { const int t = s_w[par * (NT / 64) + i]; if (i < (tid >> 6)) base += t; tot += t; }
+            my_run = base + inc - v;
+            S = tot & 0xFFFF; U = tot >> 16;
+        } else
         if (!phase2) {
             // processing order == list order: one packed scan gives both the children offset of every split
             // node (low 16 bits) and the rank of every unsplit node (high 16 bits)
@@ -1017,11 +1088,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         // ---- apply: build the next table, turn cc into child positions, zero the next table's counters
         int expand_local = 0;
         for (int k = tid; k < m; k += NT) {
-            if (ncarr[k] > 0) {
+            if ((one_per_thread ? my_nc : ncarr[k]) > 0) {
                 const uint2 bx = box[k];
                 const int x0 = bx.x & 0xFFFF, x1 = bx.x >> 16, y0 = bx.y & 0xFFFF, y1 = bx.y >> 16;
                 const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
-                int pos = S - 1 - (phase2 ? a2[a1[k]] : (a2[k] & 0xFFFF));
+                int pos = S - 1 - (one_per_thread ? (my_run & 0xFFFF) : phase2 ? a2[a1[k]] : (a2[k] & 0xFFFF));
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const int q = cc[4 * k + c];
@@ -1037,21 +1108,30 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
                     }
                 }
             } else {
-                const int pos = S + (phase2 ? a3[k] : (a2[k] >> 16));
+                const int pos = S + (one_per_thread ? (my_run >> 16) : phase2 ? a3[k] : (a2[k] >> 16));
                 box_n[pos] = box[k];
                 cnt_n[pos] = cnt[k];
                 reinterpret_cast<int4 *>(cc_n)[pos] = make_int4(0, 0, 0, 0);
                 cc[4 * k] = cc[4 * k + 1] = cc[4 * k + 2] = cc[4 * k + 3] = pos;
             }
         }
-        if (expand_local) atomicAdd(&s_acc, expand_local);
+        if (expand_local) atomicAdd(one_per_thread ? &s_acc2[sweep & 1] : &s_acc, expand_local);
         __syncthreads();
         m = S + U;
-        const int n_to_expand = s_acc;
+        const int n_to_expand = one_per_thread ? s_acc2[sweep & 1] : s_acc;
+        if (tid == 0) s_acc2[(sweep & 1) ^ 1] = 0;    // the other accumulator: next used after the next sweep's barriers
         const bool done = m >= N || m == prev;                     // :803-806, :883-884
         if (!phase2 && !done && m + 3 * n_to_expand > N) phase2 = true; // :814
         if (done) {
-            FOR_POINTS({ const int v = (int)nd; nd = (unsigned)cc[(v & NMASK) * 4 + (v >> NB)]; });
+            // final relabel fused with "one keypoint per leaf: max response, first in list order wins ties" (:895-912): the next
+            // table's counters (cc_n) were zeroed by the apply step above for every leaf, so they serve as the per-leaf maxima
+            // without a clearing pass and its barrier
+            unsigned *bestn = reinterpret_cast<unsigned *>(cc_n);
+            FOR_POINTS({
+                const int v = (int)nd;
+                nd = (unsigned)cc[(v & NMASK) * 4 + (v >> NB)];
+                atomicMax(&bestn[nd], ((p >> 24) << 24) | (0xFFFFFFu - (unsigned)i));
+            });
             __syncthreads();
             break;
         }
@@ -1069,11 +1149,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
     }
 
     // ---- one keypoint per leaf: max response, first in list order wins ties (:895-912)
-    unsigned *best = reinterpret_cast<unsigned *>(cc);
-    for (int k = tid; k < m; k += NT) best[k] = 0;
-    __syncthreads();
-    FOR_POINTS({ atomicMax(&best[nd & NMASK], ((p >> 24) << 24) | (0xFFFFFFu - (unsigned)i)); });
-    __syncthreads();
+    const unsigned *best = reinterpret_cast<const unsigned *>(cc_n);
     uint32_t *okp = lvl_kp + (long long)b * g->kp_total + L.kp_off;
     if (in_regs) {      // the winner of a leaf is written by the thread that holds it
         FOR_POINTS({
