@@ -399,7 +399,12 @@ __device__ uint2 g_span[2][SPAN_SLOTS];
 #define STAMP(k) STAMP_TO(g_fast_stamp, k)
 #define DSTAMP(k) STAMP_TO(g_desc_stamp, k)
 #define TSTAMP(k) do { if (blockIdx.y == 0) STAMP_TO(g_tree_stamp, k); } while (0)
+// timeline of the level-0 tree of image 0: (tag, m, cycles since the previous entry)
+__device__ unsigned g_tree_tl[256][4];
+#define TLOG(tag, mval) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && _tl_n < 256) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+    g_tree_tl[_tl_n][0] = (tag); g_tree_tl[_tl_n][1] = (unsigned)(mval); g_tree_tl[_tl_n][2] = (unsigned)(_t - _tl_prev); g_tree_tl[_tl_n][3] = 1; _tl_n++; _tl_prev = _t; } } while (0)
 #else
+#define TLOG(tag, mval) do { } while (0)
 #define SPAN_BEGIN() do { } while (0)
 #define SPAN_END(K) do { } while (0)
 #define STAMP(k) do { } while (0)
@@ -714,6 +719,15 @@ extern "C" int orbx_diag_desc_stamps(unsigned long long *out, int reset)
     return ORBX_OK;
 }
 
+extern "C" int orbx_diag_tree_timeline(unsigned *out /*[256][4]*/)
+{
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tree_tl), sizeof(unsigned) * 1024));
+    static unsigned z[1024];
+    ORBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tree_tl), z, sizeof z));
+    return ORBX_OK;
+}
+
 extern "C" int orbx_diag_tree_stamps(unsigned long long *out, int reset)
 {
     ORBX_HIP(hipDeviceSynchronize());
@@ -795,6 +809,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
     int *out_cnt = lvl_cnt + (long long)b * ORBX_MAX_LEVELS + l;
 #ifdef ORBX_DIAG
     unsigned long long _t_prev = __builtin_amdgcn_s_memtime();
+    unsigned long long _tl_prev = _t_prev; int _tl_n = 0;
 #endif
     // ---- gather this level's candidates (cell-row-major, in-cell row-major)
     const int *ccnt = cell_cnt + (long long)b * g->total_cells + L.cell_base;
@@ -811,6 +826,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
     // (level, image) workgroups per CU: 4 -> 8), and no LDS round trip per point and sweep.  Bigger levels fall back to arrays
     // (LDS up to lds_pts_cap, else the HBM scratch).
     const bool in_regs = reg_pts && n <= ORBX_TREE_REG_PTS;
+    // Which points a thread keeps is free (a point's list index i travels with it); neighbouring LANES take points NT / 64 apart, not
+    // neighbours: the list is cell-row-major, neighbours fall into the same quadtree node, and 64 lanes adding to one node's LDS
+    // counter serialise (the relabel + classify passes of the first sweeps, 16-64 counters for ~3000 points, were 11 k of 72 k cycles)
+    const int pbase = (tid & 63) * (NT / 64) + (tid >> 6);
     uint32_t rp[RP];
     unsigned rn[RP];
 #pragma unroll
@@ -845,20 +864,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
     if (in_regs) {
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < RP; k++) { const int i = tid + NT * k; if (i < n) rp[k] = reinterpret_cast<const uint32_t *>(tree_smem)[i]; }
+        for (int k = 0; k < RP; k++) { const int i = pbase + NT * k; if (i < n) rp[k] = reinterpret_cast<const uint32_t *>(tree_smem)[i]; }
         __syncthreads();        // the staging area becomes the node tables
     }
     // one pass over the points: BODY sees the index i, the packed point p and its label nd (read / write)
 #define FOR_POINTS(...) do { \
         if (in_regs) { \
             _Pragma("unroll") for (int k_ = 0; k_ < RP; k_++) { \
-                const int i = tid + NT * k_; \
+                const int i = pbase + NT * k_; \
                 if (i < n) { const uint32_t p = rp[k_]; (void)p; unsigned nd = rn[k_]; __VA_ARGS__; rn[k_] = nd; } \
             } \
         } else { \
             for (int i = tid; i < n; i += NT) { const uint32_t p = pts[i]; (void)p; unsigned nd = nid[i]; __VA_ARGS__; nid[i] = (uint16_t)nd; } \
         } } while (0)
     TSTAMP(0);  // cell counts, prefix, gather
+    TLOG(0, n);
     // ---- roots (src/ORBextractor.cc:627-705)
     const int N = L.quota;
     int m;
@@ -989,9 +1009,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
     bool phase2 = false;
     if (tid < 2) s_acc2[tid] = 0;
     TSTAMP(1);  // roots + first classification
+    TLOG(1, m);
     for (int sweep = 0;; sweep++) {
         const int prev = m;
         __syncthreads();
+        TLOG(10, m);
         int nsplit = 0, S, U;
         // Phase-1 sweep of a table that fits one node per thread (every ORB-SLAM2 setting on 1024 threads, the small levels on 256):
         // node k stays with thread k from its child counts to its children's table entries, so the split flags, the packed scan input
@@ -1029,6 +1051,43 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
             __syncthreads();
             const int tot = lds_excl_scan_nt<NT>(a2, m, s_w);
             S = tot & 0xFFFF; U = tot >> 16;
+        } else if (m <= 64) {
+            // Phase 2 on a table of at most 64 nodes (1000-feature settings reach it at m = 64; it is the last sweep of nearly every
+            // tree): ONE wave orders the nodes, lane = node, everything in registers and DPP -- rank by (count desc, list position
+            // asc), gains in rank order, how many splits reach N, children offsets, unsplit ranks -- and publishes the tables the
+            // apply step reads.  The workgroup form below takes sixteen barrier-to-barrier steps for the same thing (18.8 k of a
+            // level-0 tree's 72 k cycles).
+            if (tid < 64) {
+                const int k = tid;
+                const int ck = k < m ? cnt[k] : 0;
+                const bool cand = ck > 1;
+                const int ncv = cand ? (cc[4 * k] > 0) + (cc[4 * k + 1] > 0) + (cc[4 * k + 2] > 0) + (cc[4 * k + 3] > 0) : 0;
+                int r = 0;
+                for (int k2 = 0; k2 < m; k2++) {                // wave-uniform k2: the other node's count comes over the scalar unit
+                    const int c2 = __builtin_amdgcn_readlane(ck, k2);
+                    r += (c2 > ck) || (c2 == ck && k2 < k);
+                }
+                const int ncand = __popcll(__ballot(cand));
+                if (cand) a4[r] = ncv - 1;                      // gains in processing (rank) order
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int g_r = k < ncand ? a4[k] : 0;          // lane = rank from here
+                const int px = wave_incl_scan(g_r) - g_r;
+                const int less = __popcll(__ballot(k < ncand && prev + px + g_r < N));
+                nsplit = min(ncand, less + 1);
+                const int nc_r = k < nsplit ? g_r + 1 : 0;      // children of the node of rank k, if it splits
+                const int inc = wave_incl_scan(nc_r);
+                if (k < nsplit) a2[k] = inc - nc_r;
+                const int s_tot = __builtin_amdgcn_readlane(inc, 63);
+                const bool sp = cand && r < nsplit;             // lane = node again
+                const int uns = k < m && !sp ? 1 : 0;
+                const int uinc = wave_incl_scan(uns);
+                if (k < m) { ncarr[k] = sp ? ncv : 0; a1[k] = cand ? r : -1; a3[k] = uinc - uns; }
+                if (k == 0) { s_w[0] = s_tot; s_w[1] = __builtin_amdgcn_readlane(uinc, 63); }
+            }
+            __syncthreads();
+            S = s_w[0]; U = s_w[1];
+            // (s_w[0..1] are next written by a block scan or by this branch, both behind the barrier at the end of the apply step)
         } else {
             // processing order: count desc, list position asc (src/ORBextractor.cc:832-834 with the
             // address tie-break defined as "created later first" == nearer the list front)
@@ -1039,8 +1098,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
                 const int ck = cnt[k];
                 int r = -1, ncv = 0;
                 if (ck > 1) {
+                    // rank = nodes that come before this one: four counts per LDS read, the reads independent of each other (one count
+                    // per dependent read made this loop 15 k of a level-0 tree's 72 k cycles)
                     r = 0;
-                    for (int k2 = 0; k2 < m; k2++) {
+                    const int m4 = m & ~3;
+                    for (int k2 = 0; k2 < m4; k2 += 4) {
+                        const int4 c4 = *reinterpret_cast<const int4 *>(cnt + k2);
+                        r += ((c4.x > ck) || (c4.x == ck && k2 < k)) + ((c4.y > ck) || (c4.y == ck && k2 + 1 < k)) +
+                             ((c4.z > ck) || (c4.z == ck && k2 + 2 < k)) + ((c4.w > ck) || (c4.w == ck && k2 + 3 < k));
+                    }
+                    for (int k2 = m4; k2 < m; k2++) {
                         const int c2 = cnt[k2];
                         r += (c2 > ck) || (c2 == ck && k2 < k);
                     }
@@ -1082,6 +1149,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
             return;
         }
         TSTAMP(2);  // order / scans of the sweep
+        TLOG(phase2 ? 12 : 11, S + U);
 #ifdef ORBX_DIAG
         if (phase2 && blockIdx.y == 0 && tid == 0) atomicAdd(&g_tree_stamp[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + 6], 1ull);
 #endif
@@ -1136,6 +1204,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
             break;
         }
         TSTAMP(3);  // apply
+        TLOG(13, m);
         // ---- relabel fused with the next sweep's classification (one pass over the points)
         FOR_POINTS({
             const int v = (int)nd;
@@ -1146,6 +1215,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         { uint2 *t = box; box = box_n; box_n = t; }
         { int *t = cc; cc = cc_n; cc_n = t; }
         TSTAMP(4);  // relabel + classify
+        TLOG(14, m);
     }
 
     // ---- one keypoint per leaf: max response, first in list order wins ties (:895-912)
@@ -1168,6 +1238,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
     }
 #undef FOR_POINTS
     TSTAMP(5);  // final relabel, best per leaf, output
+    TLOG(20, m);
 #ifdef ORBX_DIAG
     if (blockIdx.y == 0 && tid == 0) atomicAdd(&g_tree_stamp[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + 7], 1ull);
 #endif

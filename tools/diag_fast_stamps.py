@@ -48,3 +48,14 @@ names=["counts + prefix + gather","roots + first classification","sweep: order /
 tot=sum(out[i] for i in range(6))
 print("k_tree level-0 workgroups",w, "avg cycles (s_memtime, 100 MHz) per workgroup", tot/w, "phase-2 sweeps per workgroup", out[6]/w)
 for i,nm in enumerate(names): print(f"  {nm:40s} {out[i]/w:9.1f}  {100*out[i]/tot:5.1f}%")
+
+# timeline of the level-0 tree of image 0 (last launch): tag, table size, cycles since the previous entry
+tl = (C.c_uint32 * 1024)()
+L.orbx_diag_tree_timeline(tl)
+step(); ex.sync()
+L.orbx_diag_tree_timeline(tl)
+tl = np.frombuffer(tl, dtype=np.uint32).reshape(256, 4)
+names = {0: "gather done (n points)", 1: "roots + first classification done (m)", 10: "sweep: top barrier passed", 11: "  phase-1 order/scan done (new m)",
+         12: "  phase-2 order/scan done (new m)", 13: "  apply done", 14: "  relabel + classify done", 20: "output done"}
+for r in tl:
+    if r[3]: print("%-44s m=%5d  +%6d cycles" % (names.get(int(r[0]), str(r[0])), r[1], r[2]))
