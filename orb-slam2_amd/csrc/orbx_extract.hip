@@ -427,13 +427,19 @@ __global__ __launch_bounds__(64 * NW) void k_fast(const FastArgs fa, const CellR
 {
     constexpr int DWR = P / 4;      // dwords per tile row = lanes per row of one direct load
     constexpr int RPL = 64 / DWR;   // whole tile rows per direct load (lanes >= RPL * DWR stay idle)
+    // The kernel is VALU-issue bound and sensitive to where its code lies: shifted by an ODD number of dwords (its 8-byte instructions
+    // then straddle 8-byte fetch units) it runs 2.5 % slower, any even shift is the same (tools/ab_fast_only.py on -DORBX_FAST_PAD=1..15
+    // builds).  A one-instruction change near the top of the kernel had moved it by 4 bytes: when this kernel changes, compare both parities.
+#ifdef ORBX_FAST_PAD    // experiment: shift the kernel's code by ORBX_FAST_PAD dwords (s_nop 0)
+    asm volatile(".fill %0, 4, 0xBF800000" :: "n"(ORBX_FAST_PAD));
+#endif
     uint8_t *tile = fast_smem;
     uint8_t *sc = fast_smem + fa.lds_sc;
     uint16_t *list = reinterpret_cast<uint16_t *>(fast_smem + fa.lds_list);
     uint32_t *bm = reinterpret_cast<uint32_t *>(fast_smem + fa.lds_bm); // candidate bitmap, then survivor bitmap: u64 per row
     uint32_t *sv = bm + 2 * fa.bm_rows;
     const int ini_th = fa.ini_th, min_th = fa.min_th;
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = NW == 1 ? 0 : (int)(threadIdx.x >> 6), tid = threadIdx.x;
+    const int b = blockIdx.y, lane = NW == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63), wv = NW == 1 ? 0 : (int)(threadIdx.x >> 6), tid = threadIdx.x;
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8, speed only): remap so that FAST_XG
     // horizontally adjacent cells land on the same XCD (their halos share cache lines in that XCD's L2) while each
     // XCD's work stays spread over the whole image (contiguous runs per XCD were measured slower).
@@ -907,7 +913,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         }
         return c;
     };
-    if (L.n_ini <= 4 && few_pts_per_thread) {
+    // (1024-thread form only: with 256 threads, twelve points each, the extra arithmetic per point costs more than the barriers it saves:
+    // 0.126 against 0.116 ms per 512-image launch)
+    if (NT == 1024 && L.n_ini <= 4 && few_pts_per_thread) {
         // Up to four roots (every usual aspect ratio: 3 for 1241 x 376, 1 for 640 x 480): counting them, dropping the empty ones and
         // the first classification are two barrier-to-barrier steps.  The root counts go to a scratch array that every thread then
         // reads whole, so the id of a root (= non-empty roots before it) and the table size need no scan, and a root's box is

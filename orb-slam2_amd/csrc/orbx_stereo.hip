@@ -13,8 +13,13 @@
 // did not come from the right extractor's last launch.
 #include "orbx_device.h"
 #include <stdlib.h>
+#include <algorithm>
 
-struct StereoTabs { float sf[ORBX_MAX_LEVELS]; float isf[ORBX_MAX_LEVELS]; };
+struct StereoTabs {
+    float sf[ORBX_MAX_LEVELS]; float isf[ORBX_MAX_LEVELS];
+    unsigned long long reach_pk;    // 4 bits per left level l: centre rows within +- that many can hold a right keypoint of octave l - 1 .. l + 1
+                                    // whose band covers the row (15 = no bound below the launch's `reach`); packed: the level is a per-lane value
+};
 
 // pixel of the reference's padded pyramid image: the 19-px margin is BORDER_REFLECT_101 of the level
 __device__ __forceinline__ int lvl_px(const uint8_t *img, int pitch, int w, int h, int x, int y)
@@ -183,8 +188,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         for (int i = 0; i < 8; i++) a[i] = dL[ol * 8 + i];
         const int *ro = row_off + (long long)p * (n_rows + 1);
         const uint4 *en = entries + (long long)p * ent_cap;
-        // centre rows that can reach this row: one contiguous run of the table
-        const int b0 = active ? ro[max(row - reach, 0)] : 0, e1 = active ? ro[min(row + reach, n_rows - 1) + 1] : 0;
+        // centre rows that can reach this row: one contiguous run of the table.  Only octaves level_l - 1 .. level_l + 1 can match
+        // (:644-649), and their bands are at most 2 * scale[level_l + 1] wide: the run is as short as the left keypoint's level allows
+        const int rl = (int)((tabs.reach_pk >> (4 * level_l)) & 15ull);
+        const int rch = rl == 15 ? reach : min(reach, rl);
+        const int b0 = active ? ro[max(row - rch, 0)] : 0, e1 = active ? ro[min(row + rch, n_rows - 1) + 1] : 0;
         for (int base = b0; __any(base < e1); base += 16) { // right keypoints whose row band holds this row (:622)
             const int j = base + sl;
             if (j < e1) {
@@ -382,7 +390,13 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
         L->st_cap = need;
     }
     StereoTabs tabs;
-    for (int i = 0; i < ORBX_MAX_LEVELS; i++) { tabs.sf[i] = L->sf[i]; tabs.isf[i] = L->isf[i]; }
+    tabs.reach_pk = 0;
+    for (int i = 0; i < ORBX_MAX_LEVELS; i++) {
+        tabs.sf[i] = L->sf[i]; tabs.isf[i] = L->isf[i];
+        // |centre row - row| <= ceil(r) + 1 for a band of radius r (see k_stereo_prep); r = 2 * scale[octave], octave <= i + 1
+        const int rl = (int)ceilf(2.0f * L->sf[std::min(i + 1, L->nlevels - 1)]) + 1;
+        tabs.reach_pk |= (unsigned long long)std::min(rl, 15) << (4 * i);
+    }
     // row table: a right keypoint spans at most 2*r+3 rows, r = 2*scale[top level]
     const int rows = L->geom.lv[0].h;
     const int ent_cap = cap;            // one entry per right keypoint
