@@ -28,11 +28,14 @@ __device__ __forceinline__ int lvl_px(const uint8_t *img, int pitch, int w, int 
 }
 
 // a keypoint's results as write-through stores (sc1): visible to the pair's last workgroup on another XCD once acknowledged
+template <bool FOLD>
 __device__ __forceinline__ void st_store(float *u_right, float *depth, int *st_dist, long long og, float u, float z, int sad)
 {
-    __hip_atomic_store(&u_right[og], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&depth[og], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&st_dist[og], sad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (FOLD) {
+        __hip_atomic_store(&u_right[og], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&depth[og], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st_dist[og], sad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else { u_right[og] = u; depth[og] = z; st_dist[og] = sad; }     // the cut is a launch of its own: ordinary stores
 }
 
 // Row table of src/Frame.cc:584-604 (vRowIndices).  The reference lists right keypoint iR in every image row of its band
@@ -146,6 +149,10 @@ __device__ __forceinline__ void stereo_cut(int n_l, long long o, float *__restri
     }
 }
 
+// FOLD: the median cut runs in the pair's last workgroup (launches of few pairs: one launch less in a single frame's chain).  Batches
+// keep it a launch of its own (k_stereo_cut): the write-through stores and the arrival step at the end of EVERY workgroup cost a batch
+// more (0.156 against 0.149 ms per 256 pairs) than the extra launch.
+template <bool FOLD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_stereo(const Geom *__restrict__ g, PyrRef prL, PyrRef prR, int img_l0, int img_r0,
                                                 const orbx_keypoint *__restrict__ kL, const uint32_t *__restrict__ dL,
                                                 const int *__restrict__ nL, const orbx_keypoint *__restrict__ kR,
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const int lvl = __builtin_amdgcn_readlane(level_l, gk * 16);
         const long long og = (long long)p * cap + il_base + gk;
         if (!(best_dist < 75)) { // thOrbDist = (TH_HIGH+TH_LOW)/2: no coarse match
-            if (lane == 0) st_store(u_right, depth, st_dist, og, -1.0f, -1.0f, -1);
+            if (lane == 0) st_store<FOLD>(u_right, depth, st_dist, og, -1.0f, -1.0f, -1);
             continue;
         }
         float out_u = -1.0f, out_z = -1.0f;
@@ -337,11 +344,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 }
             }
         }
-        if (lane == 0) st_store(u_right, depth, st_dist, og, out_u, out_z, out_sad);
+        if (lane == 0) st_store<FOLD>(u_right, depth, st_dist, og, out_u, out_z, out_sad);
     }
     }
     // ---- median cut (src/Frame.cc:737-750) by the pair's last workgroup: every workgroup's results went out as write-through
     // stores; once they are acknowledged the workgroup counts itself in, and the one that completes the count sees them all
+    if (!FOLD) return;
     __shared__ int s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -354,6 +362,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __syncthreads();
     if (!s_last) return;
     stereo_cut(n_l, (long long)p * cap, u_right, depth, st_dist);
+}
+
+__global__ __launch_bounds__(256) void k_stereo_cut(const int *__restrict__ nL, int cap, float *__restrict__ u_right,
+                                                    float *__restrict__ depth, int *__restrict__ st_dist)
+{
+    stereo_cut(nL[blockIdx.x], (long long)blockIdx.x * cap, u_right, depth, st_dist);
 }
 
 static int same_geometry(const orbx_extractor *L, const orbx_extractor *R)
@@ -442,11 +456,13 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
     const char *kpw_env = getenv("ORBX_STEREO_KPW");                     // tests: both forms on the same input
     const int kpw_forced = kpw_env && (*kpw_env == '1' || *kpw_env == '4') ? *kpw_env - '0' : 0;
     const int kpw = kpw_forced ? kpw_forced : (long long)batch * cap <= 16384 ? 1 : 4;    // few pairs: one keypoint per wave (see k_stereo)
-    hipLaunchKernelGGL(k_stereo, dim3((cap + 4 * kpw - 1) / (4 * kpw), batch), dim3(256), 0, s, L->d_geom, pl, pr, img_l0, img_r0,
+    const bool fold = kpw == 1;
+    hipLaunchKernelGGL((fold ? k_stereo<true> : k_stereo<false>), dim3((cap + 4 * kpw - 1) / (4 * kpw), batch), dim3(256), 0, s, L->d_geom, pl, pr, img_l0, img_r0,
                        (const orbx_keypoint *)d_kL, (const uint32_t *)d_dL, (const int *)d_nL,
                        (const orbx_keypoint *)d_kR, (const uint32_t *)d_dR, (const int *)d_nR, cap, bf, max_d, tabs,
                        (float *)d_u_right, (float *)d_depth, L->d_st_dist, (const int *)d_row_off, (const uint4 *)d_entries, row_ent_cap, reach,
                        L->d_st_arrive, kpw);
+    if (!fold) hipLaunchKernelGGL(k_stereo_cut, dim3(batch), dim3(256), 0, s, (const int *)d_nL, cap, (float *)d_u_right, (float *)d_depth, L->d_st_dist);
     orbx_prof_end(L, s);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
