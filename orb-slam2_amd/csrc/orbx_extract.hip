@@ -2237,7 +2237,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
         {
             // a frame or two: several waves per cell (the launch lasts as long as its fullest cell); batches: one
             const long long waves1 = (long long)G.total_cells * batch;
-            const int nw = e->fast_waves ? e->fast_waves : waves1 * 4 <= 16384 ? 4 : waves1 * 2 <= 8192 ? 2 : 1;
+            const int nw = e->fast_waves ? e->fast_waves : waves1 * 4 <= 16384 ? 4 : waves1 * 2 <= 16384 ? 2 : 1;    // (tools/sweep_small.sh: one frame 4, two frames 2, more 1)
             int lds_bytes = G.fast_lds_bytes;
             if (nw > 1) { fa.list_cap = G.fast_list_cap_big; fa.lds_bm = G.fast_lds_bm_big; lds_bytes = G.fast_lds_bytes_big; }
 #define LAUNCH_FAST(NW_) hipLaunchKernelGGL((k_fast<48, 40, NW_>), grid, dim3(64 * NW_), lds_bytes, s, fa, e->d_cells, pr, e->d_cell_cnt, e->d_cand, e->d_cand_prim)
