@@ -771,7 +771,31 @@ extern __shared__ __align__(16) unsigned char tree_smem[];
 // TAB_LDS: node tables in LDS (every ORB-SLAM2 configuration) -- a compile-time fact, so that their accesses are ds_ instructions
 // and LDS atomics; behind a pointer chosen at run time they were FLAT instructions (300 per wave through the vector-memory path).
 template <int NT, bool TAB_LDS>
+__device__ __forceinline__ void tree_body(const Geom *__restrict__ g, const int *__restrict__ cell_cnt,
+                                              const uint32_t *__restrict__ cand, uint32_t *__restrict__ g_pts,
+                                              uint16_t *__restrict__ g_nid, int *__restrict__ lvl_cnt,
+                                              uint32_t *__restrict__ lvl_kp, int lds_pts_cap, int *__restrict__ err_flag,
+                                              unsigned char *__restrict__ g_tab, long long g_tab_stride, const uint32_t *__restrict__ cand_prim, int reg_pts);
+
+template <int NT, bool TAB_LDS>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_tree(const Geom *__restrict__ g, const int *__restrict__ cell_cnt,
+                                              const uint32_t *__restrict__ cand, uint32_t *__restrict__ g_pts,
+                                              uint16_t *__restrict__ g_nid, int *__restrict__ lvl_cnt,
+                                              uint32_t *__restrict__ lvl_kp, int lds_pts_cap, int *__restrict__ err_flag,
+                                              unsigned char *__restrict__ g_tab, long long g_tab_stride, const uint32_t *__restrict__ cand_prim, int reg_pts)
+{
+#ifdef ORBX_DIAG_TREE_TWICE     // experiment: the whole tree a second time on the same input (idempotent) -- the second pass runs from a warm instruction cache
+    for (int rep = 0; rep < 2; rep++) {
+        if (rep) __syncthreads();
+        tree_body<NT, TAB_LDS>(g, cell_cnt, cand, g_pts, g_nid, lvl_cnt, lvl_kp, lds_pts_cap, err_flag, g_tab, g_tab_stride, cand_prim, reg_pts);
+    }
+#else
+    tree_body<NT, TAB_LDS>(g, cell_cnt, cand, g_pts, g_nid, lvl_cnt, lvl_kp, lds_pts_cap, err_flag, g_tab, g_tab_stride, cand_prim, reg_pts);
+#endif
+}
+
+template <int NT, bool TAB_LDS>
+__device__ __forceinline__ void tree_body(const Geom *__restrict__ g, const int *__restrict__ cell_cnt,
                                               const uint32_t *__restrict__ cand, uint32_t *__restrict__ g_pts,
                                               uint16_t *__restrict__ g_nid, int *__restrict__ lvl_cnt,
                                               uint32_t *__restrict__ lvl_kp, int lds_pts_cap, int *__restrict__ err_flag,
@@ -819,6 +843,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
 #endif
     // ---- gather this level's candidates (cell-row-major, in-cell row-major)
     const int *ccnt = cell_cnt + (long long)b * g->total_cells + L.cell_base;
+    // Single-frame form (1024 threads, one cell per thread): the cell's dense candidate record is requested together with its count --
+    // its address does not depend on the counts -- so the gather is one global round trip, not two (the tree's time is a chain of such steps)
+    constexpr bool PREFETCH = NT == 1024;
+    const bool pre = PREFETCH && L.n_cells <= NT;
+    uint4 pq0 = make_uint4(0, 0, 0, 0), pq1 = pq0, pq2 = pq0, pq3 = pq0;
+    if (pre && tid < L.n_cells) {
+        const uint4 *pr = reinterpret_cast<const uint4 *>(cand_prim + ((long long)b * g->total_cells + L.cell_base + tid) * ORBX_CAND_PRIM);
+        pq0 = pr[0]; pq1 = pr[1]; pq2 = pr[2]; pq3 = pr[3];
+    }
     for (int c = tid; c < L.n_cells; c += NT) cellpref[c] = ccnt[c];
     __syncthreads();
     const int n = lds_excl_scan_nt<NT>(cellpref, L.n_cells, s_w);
@@ -859,7 +892,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
             const int cn = end - beg;
             if (cn > 0) {
                 static_assert(ORBX_CAND_PRIM == 16, "four uint4 per record");
-                const uint4 q0 = pr[0], q1 = pr[1], q2 = pr[2], q3 = pr[3];
+                uint4 q0, q1, q2, q3;
+                if (pre) { q0 = pq0; q1 = pq1; q2 = pq2; q3 = pq3; } else { q0 = pr[0]; q1 = pr[1]; q2 = pr[2]; q3 = pr[3]; }
                 const uint32_t v[16] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
 #pragma unroll
                 for (int e = 0; e < 16; e++) if (e < cn) pts[beg + e] = v[e];
@@ -922,6 +956,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         // arithmetic on its index, so the first classification does not wait for the table entries other threads write.
         if (tid < 16) { a3[tid] = 0; cc[tid] = 0; }
         __syncthreads();
+        TLOG(2, 0);
         {
             unsigned long long acc = 0;
             FOR_POINTS({
@@ -930,9 +965,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
                 acc += 1ull << (4 * r);
                 nd = (unsigned)r;
             });
+            TLOG(3, 0);
             add_packed(acc, L.n_ini, a3);
+            TLOG(4, 0);
         }
         __syncthreads();
+        TLOG(5, 0);
         const int4 rc = *reinterpret_cast<const int4 *>(a3);          // counts of roots 0..3 (zero beyond n_ini)
         const unsigned nz = (rc.x > 0 ? 1u : 0u) | (rc.y > 0 ? 2u : 0u) | (rc.z > 0 ? 4u : 0u) | (rc.w > 0 ? 8u : 0u);
         m = __popc(nz);
@@ -956,7 +994,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
             }
             nd = (unsigned)(id | (c << NB));
         });
+        TLOG(6, 0);
         add_packed(acc, 4 * m, cc);
+        TLOG(7, 0);
     } else {
         for (int k = tid; k < L.n_ini; k += NT) cc[k] = 0;
         __syncthreads();
@@ -1065,16 +1105,32 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void
             // asc), gains in rank order, how many splits reach N, children offsets, unsplit ranks -- and publishes the tables the
             // apply step reads.  The workgroup form below takes sixteen barrier-to-barrier steps for the same thing (18.8 k of a
             // level-0 tree's 72 k cycles).
+            // (the 64 x 64 comparisons of the ranks are dealt to the workgroup's waves first, 64 / waves "other nodes" each -- in one
+            // wave they were a 64-step dependent loop --, summed with one LDS atomic per lane and wave)
+            {
+                constexpr int NWV = NT / 64, PER = (64 + NWV - 1) / NWV;
+                const int k = tid & 63, wv_ = tid >> 6;
+                if (tid < 64) a1[tid] = 0;
+                __syncthreads();
+                const int ck = k < m ? cnt[k] : 0;
+                int part = 0;
+#pragma unroll
+                for (int j = 0; j < PER; j++) {
+                    const int k2 = wv_ * PER + j;
+                    if (k2 < m) {                               // wave-uniform
+                        const int c2 = __builtin_amdgcn_readlane(ck, k2 & 63);
+                        part += (c2 > ck) || (c2 == ck && k2 < k);
+                    }
+                }
+                if (part && ck > 1) atomicAdd(&a1[k], part);
+                __syncthreads();
+            }
             if (tid < 64) {
                 const int k = tid;
                 const int ck = k < m ? cnt[k] : 0;
                 const bool cand = ck > 1;
                 const int ncv = cand ? (cc[4 * k] > 0) + (cc[4 * k + 1] > 0) + (cc[4 * k + 2] > 0) + (cc[4 * k + 3] > 0) : 0;
-                int r = 0;
-                for (int k2 = 0; k2 < m; k2++) {                // wave-uniform k2: the other node's count comes over the scalar unit
-                    const int c2 = __builtin_amdgcn_readlane(ck, k2);
-                    r += (c2 > ck) || (c2 == ck && k2 < k);
-                }
+                const int r = a1[k];
                 const int ncand = __popcll(__ballot(cand));
                 if (cand) a4[r] = ncv - 1;                      // gains in processing (rank) order
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -55,7 +55,9 @@ L.orbx_diag_tree_timeline(tl)
 step(); ex.sync()
 L.orbx_diag_tree_timeline(tl)
 tl = np.frombuffer(tl, dtype=np.uint32).reshape(256, 4)
-names = {0: "gather done (n points)", 1: "roots + first classification done (m)", 10: "sweep: top barrier passed", 11: "  phase-1 order/scan done (new m)",
+names = {2: "  roots: counters zeroed, barrier", 3: "  roots: points counted into 4-bit fields", 4: "  roots: fields summed over the wave, added", 5: "  roots: barrier",
+         6: "  first classification: points classified", 7: "  first classification: fields summed, added",
+         0: "gather done (n points)", 1: "roots + first classification done (m)", 10: "sweep: top barrier passed", 11: "  phase-1 order/scan done (new m)",
          12: "  phase-2 order/scan done (new m)", 13: "  apply done", 14: "  relabel + classify done", 20: "output done"}
 for r in tl:
     if r[3]: print("%-44s m=%5d  +%6d cycles" % (names.get(int(r[0]), str(r[0])), r[1], r[2]))
