@@ -802,7 +802,10 @@ __device__ __forceinline__ void tree_body(const Geom *__restrict__ g, const int 
                                               unsigned char *__restrict__ g_tab, long long g_tab_stride, const uint32_t *__restrict__ cand_prim, int reg_pts)
 {
     constexpr int NB = ORBX_NODE_BITS, NMASK = (1 << NB) - 1;
-    constexpr int RP = ORBX_TREE_REG_PTS / NT;   // points per thread in the register form
+    // points per thread in the register form: 12 on 256 threads (3072 per level); the 1024-thread form of single frames takes 4 (4096: a
+    // textured 1241 x 376 level 0 has ~3300 candidates, and a level beyond the register capacity walks its points in the HBM scratch)
+    constexpr int REG_PTS = NT == 1024 ? ORBX_TREE_REG_PTS_BIG : ORBX_TREE_REG_PTS;
+    constexpr int RP = REG_PTS / NT;
     // x = image, y = level: workgroups are dealt to the 8 XCDs by linear id % 8, so every XCD gets the same mix of
     // levels (x = level would put all level-0 trees, the longest barrier chains, on one XCD), heaviest level first
     const int l = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
@@ -829,7 +832,7 @@ __device__ __forceinline__ void tree_body(const Geom *__restrict__ g, const int 
     // [max_cells_level + 4], always LDS; in the register form it sits behind the staging area the gather uses (which aliases the
     // node tables: they are not live yet)
     int *cellpref = !TAB_LDS ? reinterpret_cast<int *>(tree_smem)
-                             : reinterpret_cast<int *>(tree_smem + (reg_pts && tab_bytes < (size_t)ORBX_TREE_REG_PTS * 4 ? (size_t)ORBX_TREE_REG_PTS * 4 : tab_bytes));
+                             : reinterpret_cast<int *>(tree_smem + (reg_pts && tab_bytes < (size_t)REG_PTS * 4 ? (size_t)REG_PTS * 4 : tab_bytes));
     uint32_t *lpts = reinterpret_cast<uint32_t *>(cellpref + ((g->max_cells_level + 4) & ~3));
     uint16_t *lnid = reinterpret_cast<uint16_t *>(lpts + lds_pts_cap);
     __shared__ int s_w[2 * (NT / 64)];  // wave totals of the block scans; the one-barrier sweeps alternate between the halves
@@ -864,7 +867,7 @@ __device__ __forceinline__ void tree_body(const Geom *__restrict__ g, const int 
     // labels in registers -- no LDS for them at all (they were half of the workgroup's LDS, and LDS is what limits the
     // (level, image) workgroups per CU: 4 -> 8), and no LDS round trip per point and sweep.  Bigger levels fall back to arrays
     // (LDS up to lds_pts_cap, else the HBM scratch).
-    const bool in_regs = reg_pts && n <= ORBX_TREE_REG_PTS;
+    const bool in_regs = reg_pts && n <= REG_PTS;
     // Which points a thread keeps is free (a point's list index i travels with it); neighbouring LANES take points NT / 64 apart, not
     // neighbours: the list is cell-row-major, neighbours fall into the same quadtree node, and 64 lanes adding to one node's LDS
     // counter serialise (the relabel + classify passes of the first sweeps, 16-64 counters for ~3000 points, were 11 k of 72 k cycles)
@@ -926,13 +929,45 @@ __device__ __forceinline__ void tree_body(const Geom *__restrict__ g, const int 
     // atomics serialise lane by lane, and this pass and the first classification were 27 % of a level-0 tree (36 k cycles).  A thread
     // owns at most 15 points per pass, so it counts them in 4-bit fields of one 64-bit register; the fields are summed over the wave
     // on the DPP path and lane 0 adds each total once: T atomics per wave instead of one per point.
+    const bool few_pts_per_thread = in_regs ? RP <= 15 : (n + NT - 1) / NT <= 15;
+    const bool seven_pts_per_thread = (n + NT - 1) / NT <= 7;   // (the 1024-thread form: a thread holds at most 4 points)
     auto add_packed = [&](unsigned long long acc, int T, int *dst) {
+        if (seven_pts_per_thread) {
+            // all sixteen fields summed over the wave TOGETHER, widening as the partial sums grow: a field is at most 7, so two lanes'
+            // sum still fits its nibble (one DPP step on the packed words), a 16-lane row's fits a byte (three steps on four words of
+            // byte fields), the wave's a 16-bit field (the two cross-row steps on eight words).  Lane t then picks field t's total and
+            // ONE LDS atomic instruction adds them all (sixteen separate wave sums + atomics were 4 k of a level-0 tree's 60 k cycles)
+            unsigned lo = (unsigned)acc, hi = (unsigned)(acc >> 32);
+            lo += (unsigned)ORBX_DPP((int)lo, 0, 0x111, 0xf, 0xf); hi += (unsigned)ORBX_DPP((int)hi, 0, 0x111, 0xf, 0xf);
+            unsigned w[4] = { lo & 0x0F0F0F0Fu, (lo >> 4) & 0x0F0F0F0Fu, hi & 0x0F0F0F0Fu, (hi >> 4) & 0x0F0F0F0Fu };   // fields 0 2 4 6 | 1 3 5 7 | 8 10 12 14 | 9 11 13 15
+            unsigned x[8];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                w[q] += (unsigned)ORBX_DPP((int)w[q], 0, 0x112, 0xf, 0xf);
+                w[q] += (unsigned)ORBX_DPP((int)w[q], 0, 0x114, 0xf, 0xe);
+                w[q] += (unsigned)ORBX_DPP((int)w[q], 0, 0x118, 0xf, 0xc);
+                x[2 * q] = w[q] & 0x00FF00FFu; x[2 * q + 1] = (w[q] >> 8) & 0x00FF00FFu;      // bytes 0 2 | 1 3 of the word
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                x[q] += (unsigned)ORBX_DPP((int)x[q], 0, 0x142, 0xa, 0xf);
+                x[q] += (unsigned)ORBX_DPP((int)x[q], 0, 0x143, 0xc, 0xf);
+                x[q] = (unsigned)__builtin_amdgcn_readlane((int)x[q], 63);
+            }
+            // field t: word q = 2 * (t >> 3) + (t & 1), byte bi = (t & 7) >> 1 of it -> x[2 q + (bi & 1)], 16-bit slot bi >> 1
+            const int t = tid & 63, q = 2 * ((t >> 3) & 1) + (t & 1), bi = (t & 7) >> 1, xi = 2 * q + (bi & 1);
+            unsigned sel = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) sel = xi == j ? x[j] : sel;
+            const int val = (int)((sel >> (16 * (bi >> 1))) & 0xFFFFu);
+            if (t < T && val) atomicAdd(&dst[t], val);
+            return;
+        }
         for (int t = 0; t < T; t++) {                                   // T <= 16, wave-uniform
             const int s = wave_sum((int)((acc >> (4 * t)) & 15ull));
             if ((tid & 63) == 0 && s) atomicAdd(&dst[t], s);
         }
     };
-    const bool few_pts_per_thread = in_regs ? RP <= 15 : (n + NT - 1) / NT <= 15;
     // ---- sweeps.  Invariant at the top of the loop: cc[0..4m) holds the child counts of the current
     // table (cnt/box) and every point label is (node id | child << NB).
     auto classify = [&](int id, uint32_t p, const int *cn, const uint2 *bx_tab, int *cct) -> int {
@@ -1695,7 +1730,7 @@ static int tree_launch_pts_cap(const Geom &G) { return tree_reg_mode(G) ? 0 : ld
 static size_t tree_launch_lds(const Geom &G)
 {
     if (!tree_reg_mode(G)) return tree_lds_bytes(G, lds_pts_cap(G));
-    return std::max(tree_tab_bytes(G), (size_t)ORBX_TREE_REG_PTS * 4) + tree_fixed_lds(G);
+    return std::max(tree_tab_bytes(G), (size_t)ORBX_TREE_REG_PTS_BIG * 4) + tree_fixed_lds(G);   // (the 1024-thread form stages 4096 points)
 }
 
 
