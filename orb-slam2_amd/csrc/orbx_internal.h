@@ -14,7 +14,9 @@
 #define ORBX_MAX_DIM 4096     // packed candidate = x | y<<12 | score<<24
 #define ORBX_NODE_BITS 14     // quadtree node id bits inside the per-point label
 #define ORBX_CAND_PRIM 16      // a cell's first candidates live in a dense 64-byte record (cells contiguous); only the overflow uses its big slot block
+#ifndef ORBX_TREE_REG_PTS
 #define ORBX_TREE_REG_PTS 3072 // k_tree: a level with at most this many candidates keeps them in registers (12 per thread of 256)
+#endif
 #define ORBX_TREE_REG_PTS_BIG 4096 // the same for the 1024-thread form (4 per thread)
 #define ORBX_FAST_LIST_CAP 512 // k_fast: pretest candidates listed per round (u16 each); denser cells take several rounds
 
