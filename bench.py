@@ -615,6 +615,12 @@ def run_workload(ctx, args):
                 sweep[str(bs)] = round(bs * ks / (time.perf_counter() - t0), 1)
                 del r
             out["config"]["batch_sweep_frames_per_s"] = sweep
+            # B = 1 is the reference's operating point (one stereo frame at a time, Examples/Stereo/stereo_kitti.cc:68-117): its time is the
+            # chain of dependent launches of one frame
+            out["config"]["single_frame"] = {"us_per_frame": round(1e6 / sweep["1"], 1), "kernel_launches_per_stereo_frame": 6,
+                                             "launches": ["k_pyr_group (levels 1-2)", "k_pyr_group (levels 3-7)", "k_fast", "k_tree", "k_desc (+ stereo row table)",
+                                                          "k_stereo (+ median cut)"],
+                                             "trace": "profiles/r03_b1_launch_chain.txt (rocprofv3 --kernel-trace, tools/b1_chain.sh)"}
             torch.cuda.empty_cache()
             hf = {"batched": host_fed_batched(pkg, torch, dev, local, pairs, 64, 40)}
             torch.cuda.synchronize()

@@ -186,7 +186,11 @@ int orbx_stereo_match(orbx_extractor *L, orbx_extractor *R,
 /* Batched, device-resident: pair p uses image (imgL0+p) of handle L and (imgR0+p) of handle R
  * from their most recent extract_batch calls (L and R may be the same handle).  Keypoints /
  * descriptors / counts are the device outputs of orbx_extract_batch_device with capacity `cap`.
- * d_u_right, d_depth: [batch*cap] floats. */
+ * d_u_right, d_depth: [batch*cap] floats.
+ * The row table of src/Frame.cc:584-604 is a by-product of the right images' extraction: when d_kR is the very buffer
+ * (address and capacity) that R's most recent orbx_extract_batch_device wrote, that table is used, so the buffer must still
+ * hold what the extraction wrote -- a caller that edits the right keypoints in place must pass them from another buffer
+ * (any other address gets a table built from the keypoints handed in, as orbx_stereo_match always does). */
 int orbx_stereo_match_batch_device(orbx_extractor *L, int imgL0, orbx_extractor *R, int imgR0, int batch,
                                    const void *d_kL, const void *d_dL, const void *d_nL,
                                    const void *d_kR, const void *d_dR, const void *d_nR, int cap,
