@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 
 __constant__ uint32_t c_pat4[256];        // x0 | y0<<8 | x1<<16 | y1<<24, signed bytes (src/ORBextractor.cc:160-418, data)
 __constant__ uint4 c_omask[64];           // IC_Angle: per lane (row, half) the byte mask of its 16-pixel window inside the circular patch
@@ -1456,7 +1457,8 @@ __device__ __forceinline__ void desc_rowtab(const DescArgs &da, const int *__res
 template <int NL>
 __global__ __launch_bounds__(64) void k_desc(const DescArgs da, PyrRef pr, const int *__restrict__ lvl_cnt,
                                              const uint32_t *__restrict__ lvl_kp, orbx_keypoint *__restrict__ out_kps,
-                                             uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap, int nimg, const RowTabArgs rt)
+                                             uint8_t *__restrict__ out_desc, int *__restrict__ out_n, int cap, int nimg, const RowTabArgs rt,
+                                             const int *__restrict__ err_flag, int *__restrict__ flag_out)
 {
     // LDS pitches: raw bytes (11 dwords per row), row-pass u16 (column-major, 43 rows per column, 37 columns).  1908 + 3188 bytes
     // round to 5120 = 160 KB / 32: the CU holds its maximum of 32 waves (the kernel is latency bound: with 5600 bytes, 29 waves
@@ -1509,7 +1511,10 @@ __global__ __launch_bounds__(64) void k_desc(const DescArgs da, PyrRef pr, const
     int off = 0, total = 0;
 #pragma unroll
     for (int i = 0; i < NL; i++) { const int c = lc[i]; off += i < l ? c : 0; total += c; }
-    if (slot == 0 && lane == 0) out_n[b] = total < cap ? total : cap;
+    if (slot == 0 && lane == 0) {
+        out_n[b] = total < cap ? total : cap;
+        if (flag_out && b == 0) *flag_out = *err_flag;     // (pipelined frames: the quadtree's error flag rides in the frame's result block)
+    }
     const int j = slot - L.kp_off;
     if (j >= lc[l]) return;
     const int idx = off + j;
@@ -2126,7 +2131,7 @@ extern "C" int orbx_extractor_set_pyramid_group_limit(orbx_extractor *e, int max
 {
     if (!e || max_images < 0) { orbx_set_error("orbx_extractor_set_pyramid_group_limit: invalid argument"); return ORBX_E_INVALID; }
     e->pyr_group_max_images = max_images;       // a launch constant of later extractions; results do not depend on it
-    if (e->lane2) e->lane2->pyr_group_max_images = max_images;
+    for (orbx_extractor *x : e->lanes) if (x) x->pyr_group_max_images = max_images;
     return ORBX_OK;
 }
 
@@ -2154,6 +2159,13 @@ extern "C" int orbx_extractor_create(orbx_extractor **out, int nfeatures, float 
     {   // launches of up to this many images build the pyramid with k_pyr_group (2 launches instead of 7); more: k_resize per level
         const char *env = getenv("ORBX_PYR_GROUP_MAX_IMAGES");
         e->pyr_group_max_images = env && *env ? atoi(env) : 8;
+        const char *pl = getenv("ORBX_PIPE_LANES"), *pi = getenv("ORBX_PIPE_INLINE");
+        // defaults (examples/stereo_stream on one camera stream): four lanes, transport by copy kernel on the lane's stream: 19 k frames/s;
+        // copy engines on two copy streams: 15 k whatever the lanes; ORBX_PIPE_INLINE=0 / ORBX_PIPE_KCOPY=0 select the older forms
+        e->pipe_lanes = pl && *pl >= '1' && *pl <= '0' + ORBX_PIPE_DEPTH ? *pl - '0' : ORBX_PIPE_DEPTH;
+        e->pipe_inline = !(pi && *pi == '0');
+        const char *pk = getenv("ORBX_PIPE_KCOPY");
+        e->pipe_kcopy = !(pk && *pk == '0');
         const char *fw = getenv("ORBX_FAST_WAVES");      // tests / experiments: force k_fast's waves per cell
         e->fast_waves = fw && *fw >= '1' && *fw <= '4' ? *fw - '0' : 0;
     }
@@ -2188,11 +2200,13 @@ extern "C" int orbx_extractor_create(orbx_extractor **out, int nfeatures, float 
     return ORBX_OK;
 }
 
+extern "C" void orbx_debug_pipe_prof_print();
 extern "C" void orbx_extractor_destroy(orbx_extractor *e)
 {
     if (!e) return;
     hipSetDevice(e->device);
-    if (e->lane2) { orbx_extractor_destroy(e->lane2); e->lane2 = nullptr; }
+    if (e->pipe_counted) orbx_debug_pipe_prof_print();
+    for (orbx_extractor *&x : e->lanes) if (x) { orbx_extractor_destroy(x); x = nullptr; }
     if (e->pipe_counted) orbx_pipe_handle_released();
     if (e->stream) hipStreamSynchronize(e->stream);
     for (auto &ev : e->prof_ev) { if (ev.owns_a && ev.a) hipEventDestroy(ev.a); if (ev.b) hipEventDestroy(ev.b); }
@@ -2382,7 +2396,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
         e->rt_kps = d_kps; e->rt_cap = cap; e->rt_batch = batch;
     }
     hipLaunchKernelGGL((G.nlevels <= 8 ? k_desc<8> : k_desc<ORBX_MAX_LEVELS>), dim3((batch < 8 ? batch : 8) * (G.kp_total + rt.on), (batch + 7) / 8), dim3(64), 0, s, da, pr, e->d_lvl_cnt, e->d_lvl_kp,
-                       (orbx_keypoint *)d_kps, (uint8_t *)d_desc, (int *)d_n_out, cap, batch, rt);
+                       (orbx_keypoint *)d_kps, (uint8_t *)d_desc, (int *)d_n_out, cap, batch, rt, (const int *)err_flag, e->flag_out);
     orbx_prof_end(e, s);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
@@ -2406,7 +2420,7 @@ extern "C" int orbx_sync(orbx_extractor *e, void *stream)
 
 int orbx_quiesce(orbx_extractor *e)
 {
-    if (e->lane2) { const int lrc = orbx_quiesce(e->lane2); if (lrc) return lrc; }
+    for (orbx_extractor *x : e->lanes) if (x) { const int lrc = orbx_quiesce(x); if (lrc) return lrc; }
     ORBX_HIP(hipStreamSynchronize(e->stream));
     if (e->last_launch_stream && e->last_launch_stream != e->stream) ORBX_HIP(hipStreamSynchronize(e->last_launch_stream));
     if (e->copy_in) ORBX_HIP(hipStreamSynchronize(e->copy_in));
@@ -2668,11 +2682,12 @@ extern "C" void *orbx_pinned_alloc(size_t bytes)
 }
 extern "C" void orbx_pinned_free(void *p) { if (p) hipHostFree(p); }
 
-static bool is_pinned_host(const void *p)
+// the address a kernel reads pinned (page-locked, mapped) host memory at, or nullptr for anything else
+static const uint8_t *pinned_device_ptr(const void *p)
 {
     hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeHost;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return a.type == hipMemoryTypeHost ? (const uint8_t *)a.devicePointer : nullptr;
 }
 
 static int pipe_slot_prepare(orbx_extractor *e, PipeSlot &s, size_t in_bytes, int need)
@@ -2687,6 +2702,7 @@ static int pipe_slot_prepare(orbx_extractor *e, PipeSlot &s, size_t in_bytes, in
         if (s.d_in) ORBX_HIP(hipFree(s.d_in));
         s.h_in = nullptr; s.d_in = nullptr; s.in_cap = 0;
         ORBX_HIP(hipHostMalloc((void **)&s.h_in, in_bytes, hipHostMallocDefault));
+        ORBX_HIP(hipHostGetDevicePointer((void **)&s.h_in_dev, s.h_in, 0));
         ORBX_HIP(hipMalloc((void **)&s.d_in, in_bytes));
         s.in_cap = in_bytes;
     }
@@ -2702,6 +2718,7 @@ static int pipe_slot_prepare(orbx_extractor *e, PipeSlot &s, size_t in_bytes, in
         if (s.h_out) ORBX_HIP(hipHostFree(s.h_out));
         s.h_out = nullptr; s.h_out_cap = 0;
         ORBX_HIP(hipHostMalloc((void **)&s.h_out, out_bytes, hipHostMallocDefault));
+        ORBX_HIP(hipHostGetDevicePointer((void **)&s.h_out_dev, s.h_out, 0));
         s.h_out_cap = out_bytes;
     }
     // the views follow `need` (the layout of this frame), not the capacity the block was allocated for
@@ -2710,37 +2727,73 @@ static int pipe_slot_prepare(orbx_extractor *e, PipeSlot &s, size_t in_bytes, in
     return ORBX_OK;
 }
 
+// Frame transport of the pipelined forms by KERNEL: the caller's pinned images are read over PCIe by a copy kernel on the frame's own
+// lane stream, and the result block is written to the slot's pinned buffer the same way.  The copy engines move a 466 KB image in
+// ~25 us each (0.93 MB per stereo frame: a ceiling of ~15 k frames/s whatever the number of lanes) and need a stream hop with two
+// events each way; a kernel with enough loads in flight moves the frame in ~20 us and is just one more launch of the chain.
+__global__ __launch_bounds__(256) void k_copy_bytes(const uint8_t *__restrict__ src0, const uint8_t *__restrict__ src1, uint8_t *__restrict__ dst0,
+                                                    uint8_t *__restrict__ dst1, unsigned long long bytes)
+{
+    const uint8_t *src = blockIdx.y ? src1 : src0;
+    uint8_t *dst = blockIdx.y ? dst1 : dst0;
+    const unsigned long long n16 = bytes >> 4, stride = (unsigned long long)gridDim.x * 256;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) {
+        uint4 v;
+        __builtin_memcpy(&v, src + 16 * i, 16);             // any byte alignment (global memory takes unaligned dwordx4)
+        __builtin_memcpy(dst + 16 * i, &v, 16);
+    }
+    if (blockIdx.x == 0) for (unsigned long long i = (n16 << 4) + threadIdx.x; i < bytes; i += 256) dst[i] = src[i];
+}
+
 static std::atomic<int> g_pipe_handles{0};   // handles of this process that have submitted pipelined frames and still exist
 void orbx_pipe_handle_released() { g_pipe_handles.fetch_sub(1, std::memory_order_relaxed); }
 
 // one frame into the next pipeline slot: eyes = 2 (stereo: both extractions + ComputeStereoMatches) or 1 (mono: extraction only)
+static double g_pp[8]; static long g_pp_n;     // ORBX_PIPE_PROF: host microseconds per section of pipe_submit / pipe_wait
+static inline double pp_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static const bool g_pp_on = getenv("ORBX_PIPE_PROF") != nullptr;
+struct PpScope { int k; double t0; PpScope(int k_) : k(k_), t0(g_pp_on ? pp_now() : 0) {} ~PpScope() { if (g_pp_on) g_pp[k] += pp_now() - t0; } };
+extern "C" void orbx_debug_pipe_prof_print()
+{
+    if (!g_pp_on || !g_pp_n) return;
+    const char *nm[8] = { "setdevice+lane+geometry", "pinned test + slot", "upload enqueue", "extract launches", "stereo launch", "download enqueue + event", "wait: event sync", "wait: copy out" };
+    for (int i = 0; i < 8; i++) fprintf(stderr, "pipe prof: %-28s %7.2f us per frame\n", nm[i], g_pp[i] / g_pp_n);
+}
+
 static int pipe_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t *img_right, int eyes, int w, int h, size_t stride,
                        float bf, float min_z, int *ticket)
 {
+    g_pp_n++;
+    PpScope *pp = new PpScope(0);
+#define PP_NEXT(K) do { delete pp; pp = new PpScope(K); } while (0)
+    struct PpEnd { PpScope *&p; ~PpEnd() { delete p; p = nullptr; } } pp_end{pp};
     ORBX_HIP(hipSetDevice(e->device));
-    // Two kernel lanes: a single stereo frame is a chain of 13 dependent launches of ~130 us that keeps a few percent of the chip
-    // busy, so consecutive frames alternate between the handle and a shadow handle (own stream, own pyramid / candidate / quadtree
-    // workspaces, created on first use) and their chains overlap.  Slots, tickets and the order of results are unchanged.
-    // (Only while this is the process's one pipelined handle: several camera streams on several handles already overlap each
-    // other, and twice the streams per handle then only adds runtime contention -- four client threads: 11.3 k frames/s
-    // with one lane each, 8.2 k with two.)
+    // Kernel lanes: a single stereo frame is a chain of dependent launches (~70 us) that keeps a few percent of the chip busy, so
+    // consecutive frames go round the handle and its shadow handles (own stream, own pyramid / candidate / quadtree workspaces,
+    // created on first use) and their chains overlap.  Slots, tickets and the order of results are unchanged.
+    // (With the copy-engine transport of round 2 lanes only paid for a lone handle -- four client threads: 11.3 k frames/s with one lane
+    // each, 8.2 k with two --; with the kernel transport they pay for every handle: two camera streams 14.7 k -> 17.3 k, four 20 k either way.)
     if (!e->pipe_counted) { e->pipe_counted = true; g_pipe_handles.fetch_add(1, std::memory_order_relaxed); }
     orbx_extractor *x = e;
-    if ((e->pipe_next & 1u) && g_pipe_handles.load(std::memory_order_relaxed) == 1) {
-        if (!e->lane2) {
-            const int lrc = orbx_extractor_create(&e->lane2, e->nfeatures, (float)e->scale_factor, e->nlevels, e->ini_th, e->min_th, e->device, e->max_w, e->max_h, 2);
+    const int nl = e->pipe_lanes, li = (int)(e->pipe_next % (unsigned)nl);
+    if (li) {
+        orbx_extractor *&sh = e->lanes[li - 1];
+        if (!sh) {
+            const int lrc = orbx_extractor_create(&sh, e->nfeatures, (float)e->scale_factor, e->nlevels, e->ini_th, e->min_th, e->device, e->max_w, e->max_h, 2);
             if (lrc) return lrc;
         }
-        x = e->lane2;
+        x = sh;
         if (x->cv_profile != e->cv_profile) orbx_extractor_set_cv_profile(x, e->cv_profile);
         x->pyr_group_max_images = e->pyr_group_max_images;
     }
     int rc = orbx_prepare_geometry(x, w, h);   // waits for everything in flight only when the image size changes
     if (rc) return rc;
+    PP_NEXT(1);
     PipeSlot &s = e->pipe[e->pipe_next % ORBX_PIPE_DEPTH];
     if (s.busy) { orbx_set_error("all %d pipeline slots are in flight: wait for the oldest ticket first", ORBX_PIPE_DEPTH); return ORBX_E_INVALID; }
     const int need = x->geom.kp_total;
-    const bool in_place = stride == (size_t)w && is_pinned_host(img_left) && (eyes == 1 || is_pinned_host(img_right));
+    const uint8_t *pin[2] = { stride == (size_t)w ? pinned_device_ptr(img_left) : nullptr, stride == (size_t)w && eyes == 2 ? pinned_device_ptr(img_right) : nullptr };
+    const bool in_place = pin[0] && (eyes == 1 || pin[1]);
     const size_t pitch = in_place ? (size_t)w : align_up(w, 64), img_bytes = pitch * h;
     if (!e->copy_in) {
         ORBX_HIP(hipStreamCreateWithFlags(&e->copy_in, hipStreamNonBlocking));
@@ -2750,40 +2803,60 @@ static int pipe_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t
     // upload: the slot's device input was last read by the kernels of the frame that used it ORBX_PIPE_DEPTH submissions ago,
     // which its _wait has already seen finish (ev_d2h follows ev_done), so the copy stream may overwrite it right away
     const uint8_t *eye_ptr[2] = { img_left, img_right };
-    if (in_place) {
-        for (int i = 0; i < eyes; i++) ORBX_HIP(hipMemcpyAsync(s.d_in + img_bytes * i, eye_ptr[i], img_bytes, hipMemcpyHostToDevice, e->copy_in));
+    PP_NEXT(2);
+    // (inline form: upload, kernels and download of a frame all on its lane's stream -- no events, no stream hops; the lanes overlap each other)
+    hipStream_t s_in = e->pipe_inline ? x->stream : e->copy_in, s_out = e->pipe_inline ? x->stream : e->copy_out;
+    const bool kcopy = e->pipe_inline && e->pipe_kcopy;
+    if (in_place && kcopy) {
+        hipLaunchKernelGGL(k_copy_bytes, dim3(128, eyes), dim3(256), 0, x->stream, pin[0], pin[1], s.d_in, s.d_in + img_bytes, (unsigned long long)img_bytes);
+    } else if (in_place) {
+        for (int i = 0; i < eyes; i++) ORBX_HIP(hipMemcpyAsync(s.d_in + img_bytes * i, eye_ptr[i], img_bytes, hipMemcpyHostToDevice, s_in));
     } else {
         for (int i = 0; i < eyes; i++) {
             uint8_t *dst = s.h_in + img_bytes * i;
             if (stride == pitch) memcpy(dst, eye_ptr[i], img_bytes);
             else for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * pitch, eye_ptr[i] + (size_t)y * stride, (size_t)w);
         }
-        ORBX_HIP(hipMemcpyAsync(s.d_in, s.h_in, img_bytes * eyes, hipMemcpyHostToDevice, e->copy_in));
+        if (kcopy) hipLaunchKernelGGL(k_copy_bytes, dim3(128, eyes), dim3(256), 0, x->stream, (const uint8_t *)s.h_in_dev, (const uint8_t *)s.h_in_dev + img_bytes, s.d_in, s.d_in + img_bytes,
+                                      (unsigned long long)img_bytes);
+        else ORBX_HIP(hipMemcpyAsync(s.d_in, s.h_in, img_bytes * eyes, hipMemcpyHostToDevice, s_in));
     }
-    ORBX_HIP(hipEventRecord(s.ev_h2d, e->copy_in));
-    ORBX_HIP(hipStreamWaitEvent(x->stream, s.ev_h2d, 0));
+    if (!e->pipe_inline) {
+        ORBX_HIP(hipEventRecord(s.ev_h2d, e->copy_in));
+        ORBX_HIP(hipStreamWaitEvent(x->stream, s.ev_h2d, 0));
+    }
     x->prof_chain = false;
-    rc = orbx_extract_batch_device(x, s.d_in, img_bytes, pitch, eyes, w, h, s.d_kps, s.d_desc, need, s.d_n, nullptr);
-    if (rc) return rc;
     orbx_keypoint *dk = (orbx_keypoint *)s.d_kps;
     uint8_t *dd = (uint8_t *)s.d_desc;
     int *dn = (int *)s.d_n;
+    // the kernel error flag of this frame travels with its counts (k_desc drops it into the slot's block).  It is sticky on the device
+    // (a node-table overflow is a configuration error, not a per-frame event): pipe_wait clears it when it reports it
+    x->flag_out = dn + 2;
+    PP_NEXT(3);
+    rc = orbx_extract_batch_device(x, s.d_in, img_bytes, pitch, eyes, w, h, s.d_kps, s.d_desc, need, s.d_n, nullptr);
+    x->flag_out = nullptr;
+    if (rc) return rc;
+    PP_NEXT(4);
     if (eyes == 2) {
         rc = orbx_stereo_match_batch_device(x, 0, x, 1, 1, dk, dd, dn, dk + need, dd + (size_t)32 * need, dn + 1, need, bf, min_z, s.d_ur, s.d_z, nullptr);
         if (rc) return rc;
     }
-    // the kernel error flag of this frame travels with its counts.  It is sticky on the device (a node-table overflow is a
-    // configuration error, not a per-frame event): pipe_wait clears it when it reports it
-    int *d_flag = x->d_lvl_cnt + (size_t)x->max_batch * ORBX_MAX_LEVELS;
-    ORBX_HIP(hipMemcpyAsync(dn + 2, d_flag, sizeof(int), hipMemcpyDeviceToDevice, x->stream));
-    ORBX_HIP(hipEventRecord(s.ev_done, x->stream));
-    // download on the second copy stream: one copy of the slot's block (counts, both eyes' keypoints and descriptors, uRight, depth)
+    PP_NEXT(5);
+    // download: one copy of the slot's block (counts + flag, both eyes' keypoints and descriptors, uRight, depth)
     const size_t o_kps = 64, o_desc = o_kps + align_up(sizeof(orbx_keypoint) * 2 * (size_t)need, 64), o_ur = o_desc + (size_t)64 * need,
                  o_z = o_ur + align_up(4 * (size_t)need, 64);
-    ORBX_HIP(hipStreamWaitEvent(e->copy_out, s.ev_done, 0));
-    ORBX_HIP(hipMemcpyAsync(s.h_out, s.d_out, eyes == 2 ? o_z + 4 * (size_t)need : o_desc + (size_t)32 * eyes * need, hipMemcpyDeviceToHost, e->copy_out));
+    if (!e->pipe_inline) {
+        ORBX_HIP(hipEventRecord(s.ev_done, x->stream));
+        ORBX_HIP(hipStreamWaitEvent(e->copy_out, s.ev_done, 0));
+    }
+    {
+        const size_t out_bytes = eyes == 2 ? o_z + 4 * (size_t)need : o_desc + (size_t)32 * eyes * need;
+        if (kcopy) hipLaunchKernelGGL(k_copy_bytes, dim3(64, 1), dim3(256), 0, x->stream, (const uint8_t *)s.d_out, (const uint8_t *)nullptr, s.h_out_dev, (uint8_t *)nullptr,
+                                      (unsigned long long)out_bytes);
+        else ORBX_HIP(hipMemcpyAsync(s.h_out, s.d_out, out_bytes, hipMemcpyDeviceToHost, s_out));
+    }
     s.lane = x;
-    ORBX_HIP(hipEventRecord(s.ev_d2h, e->copy_out));
+    ORBX_HIP(hipEventRecord(s.ev_d2h, s_out));
     // tickets are the low 31 bits of an unsigned submit counter: never negative, and (the depth divides 2^31) still congruent to the slot
     s.busy = true; s.cap = need; s.ticket = (int)(e->pipe_next & 0x7FFFFFFFu); s.eyes = eyes;
     *ticket = s.ticket;
@@ -2798,7 +2871,8 @@ static int pipe_wait(orbx_extractor *e, int ticket, int eyes, orbx_keypoint *kps
     ORBX_HIP(hipSetDevice(e->device));
     const int need = s.cap;
     if (cap < need) { orbx_set_error("keypoint capacity %d < orbx_max_keypoints() = %d (the ticket stays valid)", cap, need); return ORBX_E_CAPACITY; }
-    ORBX_HIP(hipEventSynchronize(s.ev_d2h));
+    { PpScope w6(6); ORBX_HIP(hipEventSynchronize(s.ev_d2h)); }
+    PpScope w7(7);
     s.busy = false;
     const size_t o_kps = 64, o_desc = o_kps + align_up(sizeof(orbx_keypoint) * 2 * (size_t)need, 64), o_ur = o_desc + (size_t)64 * need,
                  o_z = o_ur + align_up(4 * (size_t)need, 64);

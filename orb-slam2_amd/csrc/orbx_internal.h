@@ -72,6 +72,7 @@ struct ProfEvent { hipEvent_t a, b; int stage; bool owns_a; };
 // One frame in flight of the pipelined host-pointer stereo path (orbx_extract_stereo_submit / _wait)
 struct PipeSlot {
     uint8_t *h_in, *d_in; size_t in_cap;     // both eyes, pinned host staging and device level 0
+    uint8_t *h_in_dev, *h_out_dev;           // the addresses a kernel reads / writes the two pinned buffers at
     uint8_t *h_out; size_t h_out_cap;        // pinned: [n0 n1 flag | keypoints x2 | descriptors x2 | uRight | depth]
     uint8_t *d_out;                          // one device block in the layout of h_out (a single download per frame)
     void *d_kps, *d_desc, *d_n; float *d_ur, *d_z; int out_cap;   // views into d_out
@@ -123,8 +124,13 @@ struct orbx_extractor {
     // pipelined stereo frames: copies ride their own streams so that frame i+1 uploads and frame i-1 downloads while frame i computes
     PipeSlot pipe[ORBX_PIPE_DEPTH]; hipStream_t copy_in, copy_out; unsigned pipe_next;
     bool pipe_counted;               // this handle is counted in the process-wide number of pipelined handles
-    orbx_extractor *lane2;           // second kernel lane of the pipelined forms: odd submissions run on its stream and workspaces, so the
-                                     // launch chains of neighbouring frames overlap (a frame alone fills a few percent of the chip)
+    orbx_extractor *lanes[ORBX_PIPE_DEPTH - 1];   // further kernel lanes of the pipelined forms (shadow handles with their own stream and
+                                     // workspaces): submission i runs on lane i % pipe_lanes, so the launch chains of neighbouring frames
+                                     // overlap (a frame alone fills a few percent of the chip)
+    int pipe_lanes;                  // lanes in use (1 .. ORBX_PIPE_DEPTH; ORBX_PIPE_LANES)
+    bool pipe_inline;                // a frame's upload and download ride its lane's stream (no copy streams, no events between them)
+    bool pipe_kcopy;                 // ... and are done by a copy kernel reading / writing the pinned buffers over PCIe (inline form only)
+    int *flag_out;                   // where the next extraction's k_desc drops the kernel error flag (pipelined frames: into the slot's block)
     // grouped pyramid of small launches (k_pyr_group): group i builds levels first .. first + n - 1 in one launch
     struct PyrGroup { int first, n, tiles_x, tiles_y, tab_cx, tab_cy, lds_b, lds_bytes; } pyr_groups[ORBX_MAX_LEVELS];
     int n_pyr_groups;                // 0: this geometry has no grouped form (per-level launches at every batch size)

@@ -602,10 +602,15 @@ def test_stereo_border_windows(pkg, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pinned", [False, True])
-def test_extract_stereo_pipelined(pkg, oracle, pinned):
+@pytest.mark.parametrize("pinned,transport", [(False, {}), (True, {}), (True, {"ORBX_PIPE_KCOPY": "0"}), (False, {"ORBX_PIPE_KCOPY": "0"}),
+                                              (True, {"ORBX_PIPE_INLINE": "0", "ORBX_PIPE_LANES": "2"}), (True, {"ORBX_PIPE_LANES": "1"}),
+                                              (False, {"ORBX_PIPE_LANES": "3"})])
+def test_extract_stereo_pipelined(pkg, oracle, monkeypatch, pinned, transport):
     """orbx_extract_stereo_submit / _wait: frames in flight up to the pipeline depth, results per ticket equal the oracle's
-    (and the synchronous one-call form); resubmitting a slot before its wait is refused"""
+    (and the synchronous one-call form); resubmitting a slot before its wait is refused.  Every transport of the frames -- copy kernel on
+    the frame's lane stream (default), copy engines on the lane stream, copy engines on two copy streams -- and 1 to 4 kernel lanes"""
+    for k, v in transport.items():
+        monkeypatch.setenv(k, v)
     w, h, nf = 1241, 376, 1000
     bf, b = 386.1448, 386.1448 / 718.856
     depth = pkg.orbx.pipeline_depth()
