@@ -778,8 +778,12 @@ __device__ __forceinline__ void tree_body(const Geom *__restrict__ g, const int 
                                               uint32_t *__restrict__ lvl_kp, int lds_pts_cap, int *__restrict__ err_flag,
                                               unsigned char *__restrict__ g_tab, long long g_tab_stride, const uint32_t *__restrict__ cand_prim, int reg_pts);
 
+#ifndef ORBX_TREE_WPE
+#define ORBX_TREE_WPE 7     // waves per SIMD the 256-thread form is compiled for (= workgroups per CU): 72 VGPRs
+#endif
+// (the 1024-thread form has four waves per SIMD by construction: with the 256-thread form's register cap it spilled)
 template <int NT, bool TAB_LDS>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_tree(const Geom *__restrict__ g, const int *__restrict__ cell_cnt,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 1024 ? 4 : ORBX_TREE_WPE, NT == 1024 ? 4 : ORBX_TREE_WPE))) void k_tree(const Geom *__restrict__ g, const int *__restrict__ cell_cnt,
                                               const uint32_t *__restrict__ cand, uint32_t *__restrict__ g_pts,
                                               uint16_t *__restrict__ g_nid, int *__restrict__ lvl_cnt,
                                               uint32_t *__restrict__ lvl_kp, int lds_pts_cap, int *__restrict__ err_flag,
@@ -868,7 +872,11 @@ __device__ __forceinline__ void tree_body(const Geom *__restrict__ g, const int 
     // labels in registers -- no LDS for them at all (they were half of the workgroup's LDS, and LDS is what limits the
     // (level, image) workgroups per CU: 4 -> 8), and no LDS round trip per point and sweep.  Bigger levels fall back to arrays
     // (LDS up to lds_pts_cap, else the HBM scratch).
-    const bool in_regs = reg_pts && n <= REG_PTS;
+    // (register form with an overflow: a level with up to lds_pts_cap more candidates than the registers hold keeps the excess in a small
+    // LDS array -- every textured 1241 x 376 level 0 has 3100-4000 candidates, and a level beyond the capacity walks ALL its points in the
+    // HBM scratch)
+    const bool in_regs = reg_pts && n <= REG_PTS + lds_pts_cap;
+    const int n_over = in_regs && n > REG_PTS ? n - REG_PTS : 0;
     // Which points a thread keeps is free (a point's list index i travels with it); neighbouring LANES take points NT / 64 apart, not
     // neighbours: the list is cell-row-major, neighbours fall into the same quadtree node, and 64 lanes adding to one node's LDS
     // counter serialise (the relabel + classify passes of the first sweeps, 16-64 counters for ~3000 points, were 11 k of 72 k cycles)
@@ -899,9 +907,15 @@ __device__ __forceinline__ void tree_body(const Geom *__restrict__ g, const int 
                 uint4 q0, q1, q2, q3;
                 if (pre) { q0 = pq0; q1 = pq1; q2 = pq2; q3 = pq3; } else { q0 = pr[0]; q1 = pr[1]; q2 = pr[2]; q3 = pr[3]; }
                 const uint32_t v[16] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
+                if (in_regs && end > REG_PTS) {     // (part of) the cell lies beyond the register capacity: those points go to the overflow array
 #pragma unroll
-                for (int e = 0; e < 16; e++) if (e < cn) pts[beg + e] = v[e];
-                for (int e = 16; e < cn; e++) pts[beg + e] = s[e];
+                    for (int e = 0; e < 16; e++) if (e < cn) { const int i = beg + e; if (i < REG_PTS) pts[i] = v[e]; else lpts[i - REG_PTS] = v[e]; }
+                    for (int e = 16; e < cn; e++) { const int i = beg + e; if (i < REG_PTS) pts[i] = s[e]; else lpts[i - REG_PTS] = s[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) if (e < cn) pts[beg + e] = v[e];
+                    for (int e = 16; e < cn; e++) pts[beg + e] = s[e];
+                }
             }
         }
     }
@@ -912,11 +926,16 @@ __device__ __forceinline__ void tree_body(const Geom *__restrict__ g, const int 
         __syncthreads();        // the staging area becomes the node tables
     }
     // one pass over the points: BODY sees the index i, the packed point p and its label nd (read / write)
+    // (the empty asm hides the point's value from loop-invariant code motion: LLVM otherwise extracts x and y of all the thread's points
+    // once, keeps those 2 x RP values alive across the sweep loop and spills -- 40 spill stores / 64 reloads in the 256-thread form)
 #define FOR_POINTS(...) do { \
         if (in_regs) { \
             _Pragma("unroll") for (int k_ = 0; k_ < RP; k_++) { \
                 const int i = pbase + NT * k_; \
-                if (i < n) { const uint32_t p = rp[k_]; (void)p; unsigned nd = rn[k_]; __VA_ARGS__; rn[k_] = nd; } \
+                if (i < n) { uint32_t p = rp[k_]; asm volatile("" : "+v"(p)); unsigned nd = rn[k_]; __VA_ARGS__; rn[k_] = nd; } \
+            } \
+            for (int j_ = tid; j_ < n_over; j_ += NT) { \
+                const int i = REG_PTS + j_; (void)i; const uint32_t p = lpts[j_]; (void)p; unsigned nd = lnid[j_]; __VA_ARGS__; lnid[j_] = (uint16_t)nd; \
             } \
         } else { \
             for (int i = tid; i < n; i += NT) { const uint32_t p = pts[i]; (void)p; unsigned nd = nid[i]; __VA_ARGS__; nid[i] = (uint16_t)nd; } \
@@ -930,8 +949,10 @@ __device__ __forceinline__ void tree_body(const Geom *__restrict__ g, const int 
     // atomics serialise lane by lane, and this pass and the first classification were 27 % of a level-0 tree (36 k cycles).  A thread
     // owns at most 15 points per pass, so it counts them in 4-bit fields of one 64-bit register; the fields are summed over the wave
     // on the DPP path and lane 0 adds each total once: T atomics per wave instead of one per point.
-    const bool few_pts_per_thread = in_regs ? RP <= 15 : (n + NT - 1) / NT <= 15;
-    const bool seven_pts_per_thread = (n + NT - 1) / NT <= 7;   // (the 1024-thread form: a thread holds at most 4 points)
+    // points a thread sees per pass, at most (the 4-bit count fields below must hold them)
+    const int ppt = in_regs ? (min(n, REG_PTS) + NT - 1) / NT + (n_over + NT - 1) / NT : (n + NT - 1) / NT;
+    const bool few_pts_per_thread = ppt <= 15;
+    const bool seven_pts_per_thread = ppt <= 7;   // (the 1024-thread form: a thread holds at most 4 + 1 points)
     auto add_packed = [&](unsigned long long acc, int T, int *dst) {
         if (seven_pts_per_thread) {
             // all sixteen fields summed over the wave TOGETHER, widening as the partial sums grow: a field is at most 7, so two lanes'
@@ -1103,7 +1124,7 @@ __device__ __forceinline__ void tree_body(const Geom *__restrict__ g, const int 
         // node k stays with thread k from its child counts to its children's table entries, so the split flags, the packed scan input
         // and the scan result never go through LDS, and the sweep needs three workgroup barriers instead of six (a level-0 tree of a
         // single frame is a chain of ~50 barrier-to-barrier steps of ~0.4 us each: that chain, not the work, is its 35 us).
-        const bool one_per_thread = !phase2 && m <= NT;
+        const bool one_per_thread = NT == 1024 && !phase2 && m <= NT;   // (neutral at 256 threads, and its live values push that form into register spills)
         int my_nc = 0, my_run = 0;
         if (one_per_thread) {
             const int par = sweep & 1;
@@ -1738,11 +1759,12 @@ static int lds_pts_cap(const Geom &G)
 // ORBX_TREE_REG_PTS candidates (the same P_0/160 rule) and node tables that fit the LDS; bigger levels of such an image go to the
 // HBM scratch.  The workgroup's LDS is then the node tables (which double as the gather's staging area) + the cell prefix array.
 static bool tree_reg_mode(const Geom &G) { return tree_tab_in_lds(G) && lds_pts_cap(G) <= ORBX_TREE_REG_PTS; }
-static int tree_launch_pts_cap(const Geom &G) { return tree_reg_mode(G) ? 0 : lds_pts_cap(G); }
+// (register form: the capacity of the overflow array -- points beyond the register capacity of a level; 6 bytes each)
+static int tree_launch_pts_cap(const Geom &G) { return tree_reg_mode(G) ? ORBX_TREE_OVER_PTS : lds_pts_cap(G); }
 static size_t tree_launch_lds(const Geom &G)
 {
     if (!tree_reg_mode(G)) return tree_lds_bytes(G, lds_pts_cap(G));
-    return std::max(tree_tab_bytes(G), (size_t)ORBX_TREE_REG_PTS_BIG * 4) + tree_fixed_lds(G);   // (the 1024-thread form stages 4096 points)
+    return std::max(tree_tab_bytes(G), (size_t)ORBX_TREE_REG_PTS_BIG * 4) + tree_fixed_lds(G) + (size_t)ORBX_TREE_OVER_PTS * 6;   // (the 1024-thread form stages 4096 points)
 }
 
 

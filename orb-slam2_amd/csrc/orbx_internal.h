@@ -18,6 +18,9 @@
 #define ORBX_TREE_REG_PTS 3072 // k_tree: a level with at most this many candidates keeps them in registers (12 per thread of 256)
 #endif
 #define ORBX_TREE_REG_PTS_BIG 4096 // the same for the 1024-thread form (4 per thread)
+#ifndef ORBX_TREE_OVER_PTS
+#define ORBX_TREE_OVER_PTS 1024 // register form: points of a level beyond the register capacity that an LDS overflow array takes
+#endif
 #define ORBX_FAST_LIST_CAP 512 // k_fast: pretest candidates listed per round (u16 each); denser cells take several rounds
 
 // Geometry of one pyramid level for one image size (host computes, device reads).
