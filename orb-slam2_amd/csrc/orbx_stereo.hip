@@ -455,7 +455,7 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
                            (const orbx_keypoint *)d_kR, (const int *)d_nR, cap, tabs, (int *)d_row_off, (uint4 *)d_entries, ent_cap);
     const char *kpw_env = getenv("ORBX_STEREO_KPW");                     // tests: both forms on the same input
     const int kpw_forced = kpw_env && (*kpw_env == '1' || *kpw_env == '4') ? *kpw_env - '0' : 0;
-    const int kpw = kpw_forced ? kpw_forced : (long long)batch * cap <= 16384 ? 1 : 4;    // few pairs: one keypoint per wave (see k_stereo)
+    const int kpw = kpw_forced ? kpw_forced : (long long)batch * cap <= 2560 ? 1 : 4;    // a frame or two: one keypoint per wave (see k_stereo; 4 frames 111 vs 115 us, 8 frames 139 vs 154 with four)
     const bool fold = kpw == 1;
     hipLaunchKernelGGL((fold ? k_stereo<true> : k_stereo<false>), dim3((cap + 4 * kpw - 1) / (4 * kpw), batch), dim3(256), 0, s, L->d_geom, pl, pr, img_l0, img_r0,
                        (const orbx_keypoint *)d_kL, (const uint32_t *)d_dL, (const int *)d_nL,
