@@ -76,7 +76,8 @@ int orbx_gaussian_taps(int profile, int taps[7]);
 
 /* Tuning, no effect on results: extractions of at most `max_images` images per launch build the pyramid (ComputePyramid,
  * src/ORBextractor.cc:1347-1370) with two launches that each produce several levels (a single frame's time is its chain of dependent
- * launches); larger batches keep one launch per level, which moves fewer bytes.  Default 8; 0 = always one launch per level. */
+ * launches); launches of up to 24 images still take the small levels (3 and up) in one launch; larger batches keep one launch per
+ * level, which moves fewer bytes.  Default 8; 0 = always one launch per level. */
 int orbx_extractor_set_pyramid_group_limit(orbx_extractor *e, int max_images);
 
 /* getters: GetLevels / GetScaleFactor / GetScaleFactors / GetInverseScaleFactors /

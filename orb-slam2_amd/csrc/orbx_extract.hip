@@ -2153,7 +2153,8 @@ extern "C" int orbx_extractor_set_pyramid_group_limit(orbx_extractor *e, int max
 {
     if (!e || max_images < 0) { orbx_set_error("orbx_extractor_set_pyramid_group_limit: invalid argument"); return ORBX_E_INVALID; }
     e->pyr_group_max_images = max_images;       // a launch constant of later extractions; results do not depend on it
-    for (orbx_extractor *x : e->lanes) if (x) x->pyr_group_max_images = max_images;
+    if (max_images == 0) e->pyr_group_mid_images = 0;       // 0 = one launch per level, always
+    for (orbx_extractor *x : e->lanes) if (x) { x->pyr_group_max_images = max_images; x->pyr_group_mid_images = e->pyr_group_mid_images; }
     return ORBX_OK;
 }
 
@@ -2181,6 +2182,8 @@ extern "C" int orbx_extractor_create(orbx_extractor **out, int nfeatures, float 
     {   // launches of up to this many images build the pyramid with k_pyr_group (2 launches instead of 7); more: k_resize per level
         const char *env = getenv("ORBX_PYR_GROUP_MAX_IMAGES");
         e->pyr_group_max_images = env && *env ? atoi(env) : 8;
+        const char *mid = getenv("ORBX_PYR_GROUP_MID_IMAGES");
+        e->pyr_group_mid_images = mid && *mid ? atoi(mid) : 24;     // (8 frames: 57.2 -> 59.8 k frames/s; 16 frames: the same; 32: slower)
         const char *pl = getenv("ORBX_PIPE_LANES"), *pi = getenv("ORBX_PIPE_INLINE");
         // defaults (examples/stereo_stream on one camera stream): four lanes, transport by copy kernel on the lane's stream: 19 k frames/s;
         // copy engines on two copy streams: 15 k whatever the lanes; ORBX_PIPE_INLINE=0 / ORBX_PIPE_KCOPY=0 select the older forms
@@ -2328,23 +2331,11 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
     pr.pyr = e->d_pyr; pr.pyr_stride = G.pyr_bytes;
     e->last_img0 = pr.img0; e->last_img_stride = img_stride; e->last_pitch = pitch; e->last_batch = batch;
 
-    const bool grouped = e->n_pyr_groups > 0 && batch <= e->pyr_group_max_images;
-    for (int gi = 0; grouped && gi < e->n_pyr_groups; gi++) {
-        const orbx_extractor::PyrGroup &P = e->pyr_groups[gi];
-        const LevelGeom &S = G.lv[P.first - 1];
-        PyrGroupArgs ga;
-        memset(&ga, 0, sizeof ga);
-        ga.n = P.n; ga.s_level0 = P.first == 1; ga.s_w = S.w; ga.s_h = S.h; ga.s_pitch = S.pitch; ga.s_off = S.pyr_off;
-        ga.tab_cx = P.tab_cx; ga.tab_cy = P.tab_cy; ga.lds_b = P.lds_b;
-        for (int k = 0; k < P.n; k++) {
-            const LevelGeom &L = G.lv[P.first + k];
-            ga.lv[k].w = L.w; ga.lv[k].h = L.h; ga.lv[k].pitch = L.pitch; ga.lv[k].tab_x = L.tab_x; ga.lv[k].tab_y = L.tab_y; ga.lv[k].pyr_off = L.pyr_off;
-        }
-        orbx_prof_begin(e, ORBX_STAGE_RESIZE, s);
-        hipLaunchKernelGGL(k_pyr_group, dim3(P.tiles_x, P.tiles_y, batch), dim3(PG_NT), (size_t)P.lds_bytes, s, ga, pr, e->d_pyr, e->d_tabs);
-        orbx_prof_end(e, s);
-    }
-    for (int l = 1; l < G.nlevels && !grouped; l++) {
+    // Pyramid: launches of a frame or two build it in two grouped launches; mid-sized launches keep one launch per level for the big levels
+    // (1, 2) and take the small ones (3 .. 7, latency-bound even for dozens of images) in one grouped launch; batches: one launch per level
+    const int regime = e->n_pyr_groups > 0 && batch <= e->pyr_group_max_images ? 2
+                     : e->n_pyr_groups > 1 && batch <= e->pyr_group_mid_images ? 1 : 0;
+    auto launch_level = [&](int l) {
         const LevelGeom &L = G.lv[l];
         orbx_prof_begin(e, ORBX_STAGE_RESIZE, s);
         if (L.resize_lds == 1)
@@ -2360,7 +2351,28 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
             hipLaunchKernelGGL(k_resize_direct, dim3((L.pitch / 4 + 63) / 64, (L.h + 3) / 4, batch), dim3(256), 0, s,
                                e->d_geom, l, pr, e->d_pyr, e->d_tabs);
         orbx_prof_end(e, s);
-    }
+    };
+    auto launch_group = [&](int gi) {
+        const orbx_extractor::PyrGroup &P = e->pyr_groups[gi];
+        const LevelGeom &S = G.lv[P.first - 1];
+        PyrGroupArgs ga;
+        memset(&ga, 0, sizeof ga);
+        ga.n = P.n; ga.s_level0 = P.first == 1; ga.s_w = S.w; ga.s_h = S.h; ga.s_pitch = S.pitch; ga.s_off = S.pyr_off;
+        ga.tab_cx = P.tab_cx; ga.tab_cy = P.tab_cy; ga.lds_b = P.lds_b;
+        for (int k = 0; k < P.n; k++) {
+            const LevelGeom &L = G.lv[P.first + k];
+            ga.lv[k].w = L.w; ga.lv[k].h = L.h; ga.lv[k].pitch = L.pitch; ga.lv[k].tab_x = L.tab_x; ga.lv[k].tab_y = L.tab_y; ga.lv[k].pyr_off = L.pyr_off;
+        }
+        orbx_prof_begin(e, ORBX_STAGE_RESIZE, s);
+        hipLaunchKernelGGL(k_pyr_group, dim3(P.tiles_x, P.tiles_y, batch), dim3(PG_NT), (size_t)P.lds_bytes, s, ga, pr, e->d_pyr, e->d_tabs);
+        orbx_prof_end(e, s);
+    };
+    if (regime == 0) for (int l = 1; l < G.nlevels; l++) launch_level(l);
+    else
+        for (int gi = 0; gi < e->n_pyr_groups; gi++) {
+            if (regime == 2 || gi >= 1) launch_group(gi);
+            else for (int l = e->pyr_groups[gi].first; l < e->pyr_groups[gi].first + e->pyr_groups[gi].n; l++) launch_level(l);
+        }
     orbx_prof_begin(e, ORBX_STAGE_FAST, s);
     {
         FastArgs fa;
@@ -2806,7 +2818,7 @@ static int pipe_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t
         }
         x = sh;
         if (x->cv_profile != e->cv_profile) orbx_extractor_set_cv_profile(x, e->cv_profile);
-        x->pyr_group_max_images = e->pyr_group_max_images;
+        x->pyr_group_max_images = e->pyr_group_max_images; x->pyr_group_mid_images = e->pyr_group_mid_images;
     }
     int rc = orbx_prepare_geometry(x, w, h);   // waits for everything in flight only when the image size changes
     if (rc) return rc;

@@ -138,6 +138,7 @@ struct orbx_extractor {
     struct PyrGroup { int first, n, tiles_x, tiles_y, tab_cx, tab_cy, lds_b, lds_bytes; } pyr_groups[ORBX_MAX_LEVELS];
     int n_pyr_groups;                // 0: this geometry has no grouped form (per-level launches at every batch size)
     int pyr_group_max_images;        // launches of at most this many images take the grouped form
+    int pyr_group_mid_images;        // ... and up to this many: levels of the first group by one launch each, the later groups grouped
     int fast_waves;                  // waves per FAST cell: 0 = by launch size (several for a frame or two, one for batches); 1-4 forces (ORBX_FAST_WAVES)
     // stereo row table written by the most recent extraction as a by-product of k_desc (desc_rowtab): valid for the keypoint buffer
     // rt_kps (capacity rt_cap per image, rt_batch images); d_rt_off == nullptr: this geometry has none (more rows than k_desc's LDS holds)

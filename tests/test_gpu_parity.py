@@ -87,6 +87,12 @@ def test_pyramid_launch_forms(pkg, oracle, monkeypatch, groups):
         ex.set_pyramid_group_limit(64)
         k1, d1 = _check_stages(ex, orc, img, f"{w}x{h} sf {sf} groups {groups}")
         assert k0.tobytes() == k1.tobytes() and d0.tobytes() == d1.tobytes()
+    # mid-sized launches: the first group's levels by one launch each, the later groups grouped (limit 0 < 1 image <= the mid limit)
+    monkeypatch.setenv("ORBX_PYR_GROUP_MID_IMAGES", "64")
+    monkeypatch.setenv("ORBX_PYR_GROUP_MAX_IMAGES", "0")
+    ex = pkg.ORBextractor(nf, sf, nl, 20, 7, device=0, max_size=(w, h))
+    k2, d2 = _check_stages(ex, orc, img, f"{w}x{h} sf {sf} groups {groups}, mid regime")
+    assert k0.tobytes() == k2.tobytes() and d0.tobytes() == d2.tobytes()
     with pytest.raises(pkg.OrbxError):
         ex.set_pyramid_group_limit(-1)
 
