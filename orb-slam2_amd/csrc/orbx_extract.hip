@@ -2398,9 +2398,10 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
     int *err_flag = e->d_lvl_cnt + (size_t)e->max_batch * ORBX_MAX_LEVELS;
     orbx_prof_begin(e, ORBX_STAGE_TREE, s);
     {
-        // 256 threads for batches (many (level, image) workgroups co-resident per CU); fewer workgroups than CUs: 1024 threads
-        // each shorten the per-workgroup chain (a single stereo frame: 51 -> ~30 us)
-        const bool big = batch * G.nlevels < 256, lds = tree_tab_in_lds(G);
+        // 256 threads for batches (many (level, image) workgroups co-resident per CU); launches of few workgroups: 1024 threads
+        // each shorten the per-workgroup chain (a single stereo frame: 51 -> 19 us)
+        // (up to 512 workgroups -- 64 images of 8 levels: 16 frames 78 -> 85.5 k frames/s, 32 frames 106.5 -> 109 k; 1024 workgroups: slower)
+        const bool big = batch * G.nlevels <= 512, lds = tree_tab_in_lds(G);
         void (*kern)(const Geom *, const int *, const uint32_t *, uint32_t *, uint16_t *, int *, uint32_t *, int, int *, unsigned char *, long long,
                      const uint32_t *, int) =
             big ? (lds ? k_tree<1024, true> : k_tree<1024, false>) : (lds ? k_tree<256, true> : k_tree<256, false>);
