@@ -2036,7 +2036,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
         orbx_set_error("internal: %d FAST cells per level do not fit the quadtree kernel's LDS", G.max_cells_level);
         return ORBX_E_INVALID;
     }
-    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(orbx_use_device(e->device));
     {   // earlier launches (possibly on a caller's non-blocking stream) still read d_geom / d_tabs / d_cells and the workspaces
         const int qrc = orbx_quiesce(e);
         if (qrc) return qrc;
@@ -2316,7 +2316,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
         orbx_set_error("orbx_extract_batch_device: invalid argument");
         return ORBX_E_INVALID;
     }
-    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(orbx_use_device(e->device));
     int rc = orbx_prepare_geometry(e, w, h);
     if (rc) return rc;
     const Geom &G = e->geom;
@@ -2440,7 +2440,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
 extern "C" int orbx_sync(orbx_extractor *e, void *stream)
 {
     if (!e) { orbx_set_error("null extractor"); return ORBX_E_INVALID; }
-    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(orbx_use_device(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
     // the kernel error flag rides the same stream into pinned memory: one synchronisation, no blocking pageable copy
     int *d_flag = e->d_lvl_cnt + (size_t)e->max_batch * ORBX_MAX_LEVELS;
@@ -2497,7 +2497,7 @@ extern "C" int orbx_extract_batch(orbx_extractor *e, const uint8_t *const *imgs,
     }
     if (w == 0 || h == 0) { for (int i = 0; i < batch; i++) n_out[i] = 0; return ORBX_OK; } // reference :1264
     if (stride < (size_t)w) { orbx_set_error("stride < width"); return ORBX_E_INVALID; }
-    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(orbx_use_device(e->device));
     int rc = orbx_prepare_geometry(e, w, h);
     if (rc) return rc;
     const int need = e->geom.kp_total;
@@ -2564,7 +2564,7 @@ extern "C" int orbx_extract_color(orbx_extractor *e, const uint8_t *img, int w, 
     }
     if (w == 0 || h == 0) { *n_out = 0; return ORBX_OK; }
     if (!img || stride < (size_t)w * channels) { orbx_set_error("orbx_extract_color: bad image / stride"); return ORBX_E_INVALID; }
-    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(orbx_use_device(e->device));
     int rc = orbx_prepare_geometry(e, w, h);
     if (rc) return rc;
     const int need = e->geom.kp_total;
@@ -2611,7 +2611,7 @@ extern "C" int orbx_extract_rectified(orbx_extractor *e, const orbx_rectifier *r
         orbx_set_error("orbx_extract_rectified: invalid argument");
         return ORBX_E_INVALID;
     }
-    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(orbx_use_device(e->device));
     int rc = orbx_prepare_geometry(e, rw, rh);
     if (rc) return rc;
     const int need = e->geom.kp_total;
@@ -2660,7 +2660,7 @@ extern "C" int orbx_extract_stereo(orbx_extractor *e, const uint8_t *img_left, c
         return ORBX_E_INVALID;
     }
     if (e->max_batch < 2) { orbx_set_error("orbx_extract_stereo needs an extractor created with max_batch >= 2"); return ORBX_E_INVALID; }
-    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(orbx_use_device(e->device));
     int rc = orbx_prepare_geometry(e, w, h);
     if (rc) return rc;
     const int need = e->geom.kp_total;
@@ -2802,7 +2802,7 @@ static int pipe_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t
     PpScope *pp = new PpScope(0);
 #define PP_NEXT(K) do { delete pp; pp = new PpScope(K); } while (0)
     struct PpEnd { PpScope *&p; ~PpEnd() { delete p; p = nullptr; } } pp_end{pp};
-    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(orbx_use_device(e->device));
     // Kernel lanes: a single stereo frame is a chain of dependent launches (~70 us) that keeps a few percent of the chip busy, so
     // consecutive frames go round the handle and its shadow handles (own stream, own pyramid / candidate / quadtree workspaces,
     // created on first use) and their chains overlap.  Slots, tickets and the order of results are unchanged.
@@ -2903,7 +2903,7 @@ static int pipe_wait(orbx_extractor *e, int ticket, int eyes, orbx_keypoint *kps
 {
     PipeSlot &s = e->pipe[ticket % ORBX_PIPE_DEPTH];
     if (!s.busy || s.ticket != ticket || s.eyes != eyes) { orbx_set_error("ticket %d is not in flight (or was submitted through the other form)", ticket); return ORBX_E_INVALID; }
-    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(orbx_use_device(e->device));
     const int need = s.cap;
     if (cap < need) { orbx_set_error("keypoint capacity %d < orbx_max_keypoints() = %d (the ticket stays valid)", cap, need); return ORBX_E_CAPACITY; }
     { PpScope w6(6); ORBX_HIP(hipEventSynchronize(s.ev_d2h)); }
@@ -2979,7 +2979,7 @@ extern "C" int orbx_pyramid_level(orbx_extractor *e, int image_index, int level,
     if (h) *h = L.h;
     if (!dst) return ORBX_OK;
     if (dst_stride < (size_t)L.w) { orbx_set_error("dst_stride < level width"); return ORBX_E_INVALID; }
-    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(orbx_use_device(e->device));
     ORBX_HIP(hipStreamSynchronize(e->stream));
     const uint8_t *src; size_t pitch;
     if (level == 0) { src = e->last_img0 + e->last_img_stride * image_index; pitch = e->last_pitch; }
@@ -2991,7 +2991,7 @@ extern "C" int orbx_pyramid_level(orbx_extractor *e, int image_index, int level,
 extern "C" int orbx_debug_level_counts(orbx_extractor *e, int image_index, int32_t *counts)
 {
     if (!e || !counts || image_index < 0 || image_index >= e->last_batch) { orbx_set_error("bad argument"); return ORBX_E_INVALID; }
-    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(orbx_use_device(e->device));
     ORBX_HIP(hipStreamSynchronize(e->stream));
     ORBX_HIP(hipMemcpy(counts, e->d_lvl_cnt + (size_t)image_index * ORBX_MAX_LEVELS, sizeof(int) * e->nlevels, hipMemcpyDeviceToHost));
     return ORBX_OK;
@@ -3003,7 +3003,7 @@ extern "C" int orbx_debug_candidates(orbx_extractor *e, int image_index, int lev
         orbx_set_error("bad argument");
         return ORBX_E_INVALID;
     }
-    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(orbx_use_device(e->device));
     ORBX_HIP(hipStreamSynchronize(e->stream));
     const Geom &G = e->geom;
     const LevelGeom &L = G.lv[level];

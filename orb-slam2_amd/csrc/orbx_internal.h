@@ -190,6 +190,15 @@ int orbx_bow_forced_form();
 #define ORBX_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
     orbx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return ORBX_E_HIP; } } while (0)
 
+// hipSetDevice only when the calling thread is on another device (a read of the thread's current device is cheaper than the set, and the
+// hot host paths -- a pipelined submit makes three API entries per frame -- call it every time)
+static inline hipError_t orbx_use_device(int device)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == device) return hipSuccess;
+    return hipSetDevice(device);
+}
+
 // host-side exact arithmetic helpers shared by the .hip files
 static inline int orbx_cv_round(float v) { return (int)lrintf(v); }
 

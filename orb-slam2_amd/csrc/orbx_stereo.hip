@@ -392,7 +392,7 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
         return ORBX_E_INVALID;
     }
     if (cap >= 65536) { orbx_set_error("cap must be < 65536"); return ORBX_E_INVALID; }
-    ORBX_HIP(hipSetDevice(L->device));
+    ORBX_HIP(orbx_use_device(L->device));
     hipStream_t s = stream ? (hipStream_t)stream : L->stream;
     const size_t need = (size_t)batch * cap * sizeof(int);
     if (need > L->st_cap || !L->d_st_dist) {
@@ -483,7 +483,7 @@ extern "C" int orbx_stereo_match(orbx_extractor *L, orbx_extractor *R,
     for (int i = 0; i < nR; i++)
         if (kR[i].octave < 0 || kR[i].octave >= L->nlevels) { orbx_set_error("right keypoint %d: octave %d out of range", i, kR[i].octave); return ORBX_E_INVALID; }
     if (!L->last_img0 || !R->last_img0) { orbx_set_error("run orbx_extract on both eyes first"); return ORBX_E_INVALID; }
-    ORBX_HIP(hipSetDevice(L->device));
+    ORBX_HIP(orbx_use_device(L->device));
     ORBX_HIP(hipStreamSynchronize(R->stream)); // the right pyramid was produced on R's stream
     const int cap = nL > nR ? nL : (nR > 0 ? nR : 1);
     void *bkL, *bdL, *bkR, *bdR, *bn, *bu, *bz;
