@@ -359,6 +359,45 @@ def test_stereo_launch_forms(pkg, oracle, monkeypatch, kpw, rowtab):
         assert r[4].tobytes() == our.tobytes() and r[5].tobytes() == odp.tobytes()
 
 
+def test_stereo_row_table_sources_device(pkg, oracle):
+    """orbx_stereo_match_batch_device takes the row table the right image's extraction left behind only when it is handed that very
+    keypoint buffer; a copy at another address -- also one the caller has edited -- gets a table built from what it holds"""
+    import torch
+    w, h, nf = 1241, 376, 1000
+    bf, b = 386.1448, 386.1448 / 718.856
+    left, right, _ = synth.stereo_pair(91, w, h)
+    pitch = (w + 63) // 64 * 64
+    host = np.zeros((2, h, pitch), np.uint8); host[0, :, :w] = left; host[1, :, :w] = right
+    imgs = torch.from_numpy(host).cuda()
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7, device=0, max_size=(w, h), max_batch=2)
+    cap = ex.max_keypoints(w, h)
+    kps = torch.zeros((2, cap, 7), device="cuda"); desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ur = torch.zeros(cap, device="cuda"); dp = torch.zeros(cap, device="cuda")
+    ex.extract_batch_device(imgs.data_ptr(), h * pitch, pitch, 2, w, h, kps.data_ptr(), desc.data_ptr(), cap, n.data_ptr(), None)
+    oL, oR = oracle.Oracle(nf, 1.2, 8, 20, 7), oracle.Oracle(nf, 1.2, 8, 20, 7)
+    okL, odL = oL.extract(left); okR, odR = oR.extract(right)
+
+    def run(kr_ptr):
+        pkg.orbx.stereo_match_batch_device(ex, 0, ex, 1, 1, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), kr_ptr, desc[1:].data_ptr(), n[1:].data_ptr(),
+                                           cap, bf, b, ur.data_ptr(), dp.data_ptr(), None)
+        ex.sync()
+        nl = int(n[0].item())
+        return ur.cpu().numpy()[:nl].copy(), dp.cpu().numpy()[:nl].copy()
+    our, odp = oracle.stereo_match(oL, oR, okL, odL, okR, odR, bf, b)
+    g_ur, g_dp = run(kps[1:].data_ptr())                        # the extraction's own buffer: by-product table
+    assert g_ur.tobytes() == our.tobytes() and g_dp.tobytes() == odp.tobytes() and (our >= 0).sum() > 50
+    clone = kps[1:].clone()                                      # the same keypoints at another address: k_stereo_prep
+    g_ur, g_dp = run(clone.data_ptr())
+    assert g_ur.tobytes() == our.tobytes() and g_dp.tobytes() == odp.tobytes()
+    ed = okR.copy()                                              # an edited copy: a third of the right keypoints moved 40 rows down
+    ed["y"][::3] += 40.0
+    clone2 = torch.from_numpy(np.pad(ed.view(np.uint8).reshape(len(ed), 28), ((0, cap - len(ed)), (0, 0))).copy()).cuda()
+    eur, edp = oracle.stereo_match(oL, oR, okL, odL, ed, odR, bf, b)
+    g_ur, g_dp = run(clone2.data_ptr())
+    assert g_ur.tobytes() == eur.tobytes() and g_dp.tobytes() == edp.tobytes() and eur.tobytes() != our.tobytes()
+
+
 def test_stereo_rejects_bad_octave(pkg):
     w, h = 640, 480
     exL, exR = _extractor(pkg, 300, w, h), _extractor(pkg, 300, w, h)
