@@ -604,10 +604,10 @@ def run_workload(ctx, args):
             sweep = {}
             for bs in (1, 8, 64, 256):
                 r = StereoRig(pkg, torch, dev, local, W, H, NFEAT, bs, pairs)
-                for _ in range(3):
+                for _ in range(6):
                     r.step()
                 r.stream.synchronize()
-                ks = max(10, min(200, 2048 // bs))
+                ks = max(20, min(200, 2048 // bs))
                 t0 = time.perf_counter()
                 for _ in range(ks):
                     r.step()
