@@ -779,7 +779,8 @@ __device__ __forceinline__ void tree_body(const Geom *__restrict__ g, const int 
                                               unsigned char *__restrict__ g_tab, long long g_tab_stride, const uint32_t *__restrict__ cand_prim, int reg_pts);
 
 #ifndef ORBX_TREE_WPE
-#define ORBX_TREE_WPE 7     // waves per SIMD the 256-thread form is compiled for (= workgroups per CU): 72 VGPRs
+#define ORBX_TREE_WPE 6     // waves per SIMD the 256-thread form is compiled for (= workgroups per CU): 79 VGPRs, no spills; the LDS (25 KB per
+                            // workgroup with the overflow array) holds six anyway (7: 72 VGPRs + 20 bytes of scratch, 0.094 against 0.091 ms)
 #endif
 // (the 1024-thread form has four waves per SIMD by construction: with the 256-thread form's register cap it spilled)
 template <int NT, bool TAB_LDS>
@@ -2787,7 +2788,12 @@ void orbx_pipe_handle_released() { g_pipe_handles.fetch_sub(1, std::memory_order
 static double g_pp[8]; static long g_pp_n;     // ORBX_PIPE_PROF: host microseconds per section of pipe_submit / pipe_wait
 static inline double pp_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static const bool g_pp_on = getenv("ORBX_PIPE_PROF") != nullptr;
-struct PpScope { int k; double t0; PpScope(int k_) : k(k_), t0(g_pp_on ? pp_now() : 0) {} ~PpScope() { if (g_pp_on) g_pp[k] += pp_now() - t0; } };
+struct PpScope {    // charges the time since construction / the last next() to section k
+    int k; double t0;
+    explicit PpScope(int k_) : k(k_), t0(g_pp_on ? pp_now() : 0) {}
+    void next(int k_) { if (g_pp_on) { const double t = pp_now(); g_pp[k] += t - t0; t0 = t; } k = k_; }
+    ~PpScope() { if (g_pp_on) g_pp[k] += pp_now() - t0; }
+};
 extern "C" void orbx_debug_pipe_prof_print()
 {
     if (!g_pp_on || !g_pp_n) return;
@@ -2799,9 +2805,8 @@ static int pipe_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t
                        float bf, float min_z, int *ticket)
 {
     g_pp_n++;
-    PpScope *pp = new PpScope(0);
-#define PP_NEXT(K) do { delete pp; pp = new PpScope(K); } while (0)
-    struct PpEnd { PpScope *&p; ~PpEnd() { delete p; p = nullptr; } } pp_end{pp};
+    PpScope pp(0);
+#define PP_NEXT(K) pp.next(K)
     ORBX_HIP(orbx_use_device(e->device));
     // Kernel lanes: a single stereo frame is a chain of dependent launches (~70 us) that keeps a few percent of the chip busy, so
     // consecutive frames go round the handle and its shadow handles (own stream, own pyramid / candidate / quadtree workspaces,
@@ -2897,6 +2902,7 @@ static int pipe_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t
     *ticket = s.ticket;
     e->pipe_next++;
     return ORBX_OK;
+#undef PP_NEXT
 }
 
 static int pipe_wait(orbx_extractor *e, int ticket, int eyes, orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out, float *u_right, float *depth)
