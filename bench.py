@@ -29,7 +29,7 @@ Outside the timed region the headline run also (rank 0 / every rank as noted):
   * runs short legs of the other BASELINE configs in the same process (N = 1, rank 0) -> config.other_configs: `tum640`
     (config 1: 640x480 mono @1000, CPU oracle beside the GPU rate), `euroc_bow` (config 3), `fhd4000` (config 4) and
     `euroc_track` (extract + ComputeBoW + SearchByBoW(previous keyframe, frame)), each with its own `verified`
-    block (every frame of its last step against the oracle; BoW: 64 keyframes x 4 frames of the search rows) and a
+    block (every frame of its last step against the oracle; BoW: every keyframe x 4 frames of the search rows) and a
     CPU-oracle figure on one thread (mono: src/Frame.cc:205 runs one extraction);
   * times the three north-star matchers per call next to the CPU oracle -> config.matchers (tools/matcher_bench.py).
 `roofline.traffic` and `roofline.issue` come from committed rocprofv3 counter files (profiles/*_traffic.json, *_sq_counters.json),
@@ -452,7 +452,7 @@ def run_workload(ctx, args):
         verified = rig.verify(expect, len(pairs))
 
     if not stereo and rank == 0 and not args.no_verify:
-        # every frame of the batch against the oracle's extraction of its image; BoW: + the search rows of up to 64 keyframes x 4
+        # every frame of the batch against the oracle's extraction of its image; BoW: + the search rows of every keyframe x 4
         # frames against the oracle's ComputeBoW + SearchByBoW (the keyframes' FeatureVectors re-derived by the oracle too)
         from oracle import oracle_py
         orc = oracle_py.Oracle(NFEAT, 1.2, NLEVELS, 20, 7)
@@ -468,19 +468,21 @@ def run_workload(ctx, args):
             ovoc = oracle_py.Vocabulary(10, 6, par, leaf, nd, wt)
             bow_cpu = {"ovoc": ovoc, "kfs": bow["kfs"]}
             if not bow["host_path"]:
-                nkc, nfc = min(NKF, 64), min(B, 4)
+                nkc, nfc = NKF, min(B, 4)          # EVERY keyframe of the map (config 3: all 500) x the first four frames of the launch
                 dm = bow["d_match"][:nfc, :nkc].cpu().numpy(); dn = bow["d_nm"][:nfc, :nkc].cpu().numpy()
                 badp = []
+                same_fv = []
+                for kq in range(nkc):               # the keyframes' FeatureVectors re-derived by the oracle, once each
+                    kf = bow["kfs"][kq]
+                    tk = ovoc.transform(kf["desc"], 4)
+                    same_fv.append(np.array_equal(tk["fv_node_id"], kf["node_id"]) and np.array_equal(tk["fv_node_off"], kf["node_off"]) and np.array_equal(tk["fv_feat"], kf["feat"]))
                 for f in range(nfc):
                     ok_, od_ = ref[f % len(monos)]
                     t = ovoc.transform(od_, 4)
                     q = dict(desc=od_, node_id=t["fv_node_id"], node_off=t["fv_node_off"], feat=t["fv_feat"], flag=np.zeros(len(od_), np.uint8), angle=ok_["angle"].copy())
                     for kq in range(nkc):
-                        kf = bow["kfs"][kq]
-                        tk = ovoc.transform(kf["desc"], 4)
-                        same_fv = (np.array_equal(tk["fv_node_id"], kf["node_id"]) and np.array_equal(tk["fv_node_off"], kf["node_off"]) and np.array_equal(tk["fv_feat"], kf["feat"]))
-                        exp, en = oracle_py.search_by_bow_kf_f(kf, q, 0.75, True)
-                        if not (same_fv and en == int(dn[f, kq]) and np.array_equal(dm[f, kq, :len(exp)], exp)):
+                        exp, en = oracle_py.search_by_bow_kf_f(bow["kfs"][kq], q, 0.75, True)
+                        if not (same_fv[kq] and en == int(dn[f, kq]) and np.array_equal(dm[f, kq, :len(exp)], exp)):
                             badp.append((f, kq))
                 verified["bow"] = {"pairs_checked": nfc * nkc, "what": f"search rows of keyframes 0..{nkc - 1} x frames 0..{nfc - 1} of the last launch, and those keyframes' FeatureVectors, "
                                                                       "against oracle ComputeBoW + SearchByBoW", "mismatching_pairs": badp[:8]}
