@@ -619,18 +619,18 @@ def run_workload(ctx, args):
             out["config"]["batch_sweep_frames_per_s"] = sweep
             # the same 256 frames as two half-batches on two handles / streams, submitted round-robin: the launch chains of the halves overlap
             # (one half's latency-bound quadtree and stereo kernels run beside the other's FAST) -- a deployment option, not the headline
-            halves = [StereoRig(pkg, torch, dev, local, W, H, NFEAT, B // 2, pairs[i::2] if len(pairs) > 1 else pairs) for i in range(2)] if B >= 2 else []
+            halves = [StereoRig(pkg, torch, dev, local, W, H, NFEAT, B // 2, pairs) for i in range(2)] if B >= 2 else []
             if halves:
-                for _ in range(4):
+                for _ in range(6):
                     for r in halves:
                         r.step()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for _ in range(20):
+                for _ in range(30):
                     for r in halves:
                         r.step()
                 torch.cuda.synchronize()
-                out["config"]["two_half_batches_on_two_streams_frames_per_s"] = round(2 * (B // 2) * 20 / (time.perf_counter() - t0), 1)
+                out["config"]["two_half_batches_on_two_streams_frames_per_s"] = round(2 * (B // 2) * 30 / (time.perf_counter() - t0), 1)
                 del halves
             # B = 1 is the reference's operating point (one stereo frame at a time, Examples/Stereo/stereo_kitti.cc:68-117): its time is the
             # chain of dependent launches of one frame
