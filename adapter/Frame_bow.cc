@@ -43,7 +43,7 @@ void Frame::UndistortKeyPoints()
     std::vector<float> xy(2 * (size_t)(N > 0 ? N : 1));
     for (int i = 0; i < N; i++) { xy[2 * i] = mvKeys[i].pt.x; xy[2 * i + 1] = mvKeys[i].pt.y; }
     // cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) (:490): five fixed-point iterations in double, on the device
-    if (orbx_undistort_keypoints(0, &xy[0], N, mK.at<float>(0, 0), mK.at<float>(1, 1), mK.at<float>(0, 2), mK.at<float>(1, 2),
+    if (orbx_undistort_keypoints(orbx_adapter::Device(), &xy[0], N, mK.at<float>(0, 0), mK.at<float>(1, 1), mK.at<float>(0, 2), mK.at<float>(1, 2),
                                  mDistCoef.ptr<float>(), (int)mDistCoef.total(), &xy[0]) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
     mvKeysUn.resize(N);                                   // :493-500

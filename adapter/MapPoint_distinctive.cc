@@ -45,7 +45,7 @@ void MapPoint::ComputeDistinctiveDescriptors()
         memcpy(&flat[32 * i], vDescriptors[i].data, 32);
     const int32_t off[2] = { 0, (int32_t)vDescriptors.size() };
     int32_t best = -1;
-    if (orbx_distinctive_descriptors(0, &flat[0], off, 1, &best) != ORBX_OK)
+    if (orbx_distinctive_descriptors(orbx_adapter::Device(), &flat[0], off, 1, &best) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
     {
         unique_lock<mutex> lock(mMutexFeatures);
@@ -73,7 +73,7 @@ void DistinctiveDescriptors(const std::vector<ORB_SLAM2::MapPoint *> &points)
     if (points.empty())
         return;
     std::vector<int32_t> best(points.size(), -1);
-    if (orbx_distinctive_descriptors(0, flat.empty() ? NULL : &flat[0], &off[0], (int)points.size(), &best[0]) != ORBX_OK)
+    if (orbx_distinctive_descriptors(orbx_adapter::Device(), flat.empty() ? NULL : &flat[0], &off[0], (int)points.size(), &best[0]) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
     for (size_t p = 0; p < points.size(); p++)
         if (best[p] >= 0) {

@@ -2,6 +2,7 @@
 // Call sites stay untouched: Frame::ExtractORB (src/Frame.cc:285-292), the getters read by the Frame constructors
 // (src/Frame.cc:73-79,136-142,195-201), construction in src/Tracking.cc:124-130.
 #include "ORBextractor.h"
+#include "orbx_device.h"
 
 #include <stdexcept>
 #include <string.h>
@@ -16,7 +17,7 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST), mH(NULL)
 {
     // max_batch 2: one handle serves both eyes of a stereo frame through ExtractStereo()
-    if (orbx_extractor_create(&mH, nfeatures, _scaleFactor, nlevels, iniThFAST, minThFAST, /*device*/ 0, /*max_w*/ 4096, /*max_h*/ 4096,
+    if (orbx_extractor_create(&mH, nfeatures, _scaleFactor, nlevels, iniThFAST, minThFAST, orbx_adapter::Device(), /*max_w*/ 4096, /*max_h*/ 4096,
                               /*max_batch*/ 2) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
     mvScaleFactor.resize(nlevels);

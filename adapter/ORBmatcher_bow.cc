@@ -45,7 +45,7 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint *> &vpMapPo
     f.bind(orbx_adapter::dense_descriptors(F.mDescriptors, F.N), F.N);
     vector<int32_t> match(F.N > 0 ? F.N : 1);
     int nmatches = 0;
-    if (orbx_search_by_bow_kf_f(0, &kf.fs, &f.fs, mfNNratio, mbCheckOrientation ? 1 : 0, &match[0], &nmatches) != ORBX_OK)
+    if (orbx_search_by_bow_kf_f(orbx_adapter::Device(), &kf.fs, &f.fs, mfNNratio, mbCheckOrientation ? 1 : 0, &match[0], &nmatches) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
     vpMapPointMatches = vector<MapPoint *>(F.N, static_cast<MapPoint *>(NULL));   // :175
     for (int i = 0; i < F.N; i++)
@@ -69,7 +69,7 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &
     k2.bind(orbx_adapter::dense_descriptors(pKF2->mDescriptors, pKF2->N), pKF2->N);
     vector<int32_t> match12(pKF1->N > 0 ? pKF1->N : 1);
     int nmatches = 0;
-    if (orbx_search_by_bow_kf_kf(0, &k1.fs, &k2.fs, mfNNratio, mbCheckOrientation ? 1 : 0, &match12[0], &nmatches) != ORBX_OK)
+    if (orbx_search_by_bow_kf_kf(orbx_adapter::Device(), &k1.fs, &k2.fs, mfNNratio, mbCheckOrientation ? 1 : 0, &match12[0], &nmatches) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
     vpMatches12 = vector<MapPoint *>(vpMapPoints1.size(), static_cast<MapPoint *>(NULL));   // :580
     for (int i = 0; i < pKF1->N; i++)
@@ -116,7 +116,7 @@ int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F
     const int cap = pKF1->N > 0 ? pKF1->N : 1;
     vector<int32_t> pairs(2 * (size_t)cap);
     int npairs = 0;
-    if (orbx_search_for_triangulation(0, &k1.fs, &k2.fs, f12, ex, ey, &pKF2->mvScaleFactors[0], &pKF2->mvLevelSigma2[0],
+    if (orbx_search_for_triangulation(orbx_adapter::Device(), &k1.fs, &k2.fs, f12, ex, ey, &pKF2->mvScaleFactors[0], &pKF2->mvLevelSigma2[0],
                                       (int)pKF2->mvScaleFactors.size(), bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0, &pairs[0], cap,
                                       &npairs) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());

@@ -126,7 +126,7 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set
     vector<int32_t> match((size_t)(CurrentFrame.N > 0 ? CurrentFrame.N : 1));
     int nmatches = 0;
     ORBX_CAPTURE(cur.ff, &pts.pp);
-    if (orbx_search_by_projection_keyframe(0, &cur.ff, &pts.pp, &CurrentFrame.mvScaleFactors[0], (int)CurrentFrame.mvScaleFactors.size(), th, ORBdist,
+    if (orbx_search_by_projection_keyframe(orbx_adapter::Device(), &cur.ff, &pts.pp, &CurrentFrame.mvScaleFactors[0], (int)CurrentFrame.mvScaleFactors.size(), th, ORBdist,
                                            mbCheckOrientation ? 3 : 0, &match[0], &nmatches) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
     for (int f = 0; f < CurrentFrame.N; f++) {
@@ -176,7 +176,7 @@ int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapP
     vector<int32_t> match((size_t)(pKF->N > 0 ? pKF->N : 1));
     int nmatches = 0;
     ORBX_CAPTURE(kf.ff, &pts.pp);
-    if (orbx_search_by_projection_sim3(0, &kf.ff, &pts.pp, &pKF->mvScaleFactors[0], (int)pKF->mvScaleFactors.size(), (float)th, &match[0], &nmatches) != ORBX_OK)
+    if (orbx_search_by_projection_sim3(orbx_adapter::Device(), &kf.ff, &pts.pp, &pKF->mvScaleFactors[0], (int)pKF->mvScaleFactors.size(), (float)th, &match[0], &nmatches) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
     for (int idx = 0; idx < pKF->N; idx++)
         if (match[idx] >= 0)
@@ -212,7 +212,7 @@ int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const
     vector<int32_t> best(np, -1);
     int nfound = 0;
     ORBX_CAPTURE(kf.ff, &pts.pp);
-    if (orbx_window_best(0, &kf.ff, &pts.pp, &pKF->mvScaleFactors[0], &pKF->mvInvLevelSigma2[0], (int)pKF->mvScaleFactors.size(), th, 1, TH_LOW,
+    if (orbx_window_best(orbx_adapter::Device(), &kf.ff, &pts.pp, &pKF->mvScaleFactors[0], &pKF->mvInvLevelSigma2[0], (int)pKF->mvScaleFactors.size(), th, 1, TH_LOW,
                          &best[0], NULL, &nfound) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
     // the map surgery of :1011-1033, in the reference's order.  A point's best keypoint does not depend on the map state, but whether
@@ -265,7 +265,7 @@ int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoi
     vector<int32_t> best(np, -1);
     int nfound = 0;
     ORBX_CAPTURE(kf.ff, &pts.pp);
-    if (orbx_window_best(0, &kf.ff, &pts.pp, &pKF->mvScaleFactors[0], NULL, (int)pKF->mvScaleFactors.size(), th, 0, TH_LOW, &best[0], NULL, &nfound) != ORBX_OK)
+    if (orbx_window_best(orbx_adapter::Device(), &kf.ff, &pts.pp, &pKF->mvScaleFactors[0], NULL, (int)pKF->mvScaleFactors.size(), th, 0, TH_LOW, &best[0], NULL, &nfound) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
     int nFused = 0;
     for (size_t i = 0; i < vpPoints.size(); i++) {                   // :1140-1157
@@ -348,7 +348,7 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> 
     int nFound = 0;
     ORBX_CAPTURE(kf2.ff, &p12.pp);
     ORBX_CAPTURE2(kf1.ff, &p21.pp);
-    if (orbx_search_by_sim3(0, &kf1.ff, &kf2.ff, &p12.pp, &p21.pp, &pKF1->mvScaleFactors[0], &pKF2->mvScaleFactors[0], (int)pKF1->mvScaleFactors.size(), th,
+    if (orbx_search_by_sim3(orbx_adapter::Device(), &kf1.ff, &kf2.ff, &p12.pp, &p21.pp, &pKF1->mvScaleFactors[0], &pKF2->mvScaleFactors[0], (int)pKF1->mvScaleFactors.size(), th,
                             &m12[0], &nFound) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
     for (int i1 = 0; i1 < N1; i1++)

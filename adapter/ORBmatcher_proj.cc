@@ -71,7 +71,7 @@ int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint *> &vpMapPoin
     vector<int32_t> match((size_t)(F.N > 0 ? F.N : 1));
     int nmatches = 0;
     ORBX_CAPTURE(cur.ff, &pts.pp);
-    if (orbx_search_by_projection_map_points(0, &cur.ff, &pts.pp, &F.mvScaleFactors[0], (int)F.mvScaleFactors.size(), th, mfNNratio, &match[0],
+    if (orbx_search_by_projection_map_points(orbx_adapter::Device(), &cur.ff, &pts.pp, &F.mvScaleFactors[0], (int)F.mvScaleFactors.size(), th, mfNNratio, &match[0],
                                              &nmatches) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
     for (int f = 0; f < F.N; f++)
@@ -116,7 +116,7 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
     vector<int32_t> match((size_t)(CurrentFrame.N > 0 ? CurrentFrame.N : 1));
     int nmatches = 0;
     ORBX_CAPTURE(cur.ff, &pts.pp);
-    if (orbx_search_by_projection_last_frame(0, &cur.ff, &pts.pp, &CurrentFrame.mvScaleFactors[0], (int)CurrentFrame.mvScaleFactors.size(), th,
+    if (orbx_search_by_projection_last_frame(orbx_adapter::Device(), &cur.ff, &pts.pp, &CurrentFrame.mvScaleFactors[0], (int)CurrentFrame.mvScaleFactors.size(), th,
                                              bForward ? 1 : bBackward ? 2 : 0, CurrentFrame.mbf, mbCheckOrientation ? 3 : 0, &match[0],
                                              &nmatches) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
@@ -140,7 +140,7 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f
     vector<int32_t> m12(n1 ? n1 : 1);
     int nmatches = 0;
     ORBX_CAPTURE(f2.ff, NULL);
-    if (orbx_search_for_initialization(0, &f1.ff, &f2.ff, &prev[0], windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, &m12[0], &nmatches) != ORBX_OK)
+    if (orbx_search_for_initialization(orbx_adapter::Device(), &f1.ff, &f2.ff, &prev[0], windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, &m12[0], &nmatches) != ORBX_OK)
         throw std::runtime_error(orbx_last_error());
     vnMatches12 = vector<int>(n1, -1);                  // :433
     for (size_t i1 = 0; i1 < n1; i1++) {

@@ -13,6 +13,8 @@
 
 #include <orbx.h>
 
+#include "orbx_device.h"
+
 #include <Thirdparty/DBoW2/DBoW2/FeatureVector.h>
 
 namespace orbx_adapter
@@ -113,7 +115,7 @@ inline orbx_vocab *&vocabulary()
     static orbx_vocab *v = NULL;
     return v;
 }
-inline int LoadVocabulary(const char *path, int device = 0) { return orbx_vocab_load_text(device, path, &vocabulary()); }
+inline int LoadVocabulary(const char *path, int device = -1) { return orbx_vocab_load_text(device < 0 ? Device() : device, path, &vocabulary()); }
 
 #ifdef ORBX_ADAPTER_CAPTURE
 // test hook (tests/adapter_driver.cc): the projection adaptors leave a copy of what they handed to the ABI, so that the test can give

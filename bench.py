@@ -221,7 +221,8 @@ class StereoRig:
                                      self.desc.data_ptr(), cap, self.nout.data_ptr(), self.sp)
         self.pkg.orbx.stereo_match_batch_device(self.ex, 0, self.ex, B, B, self.kps.data_ptr(), self.desc.data_ptr(), self.nout.data_ptr(),
                                                 self.kps[B:].data_ptr(), self.desc[B:].data_ptr(), self.nout[B:].data_ptr(), cap,
-                                                BF, MIN_Z, self.ur.data_ptr(), self.dp.data_ptr(), self.sp)
+                                                BF, MIN_Z, self.ur.data_ptr(), self.dp.data_ptr(), self.sp,
+                                                row_table=self.pkg.orbx.ROWTAB_OF_EXTRACTION)   # kps[B:] is what the launch above wrote, untouched
 
     def verify(self, expect, npairs):
         """every frame of the batch (frame i holds pair i % npairs) against the oracle's outputs for that pair, byte for byte"""
@@ -241,6 +242,40 @@ class StereoRig:
                 bad.append(i)
         return {"frames": B, "distinct_pairs": npairs, "checked": "keypoints (28 B each), descriptors, uRight, depth of every frame of the last step",
                 "against": "oracle/liborb_oracle.so", "bit_exact": not bad, "mismatching_frames": bad[:8]}
+
+
+class MonoRig:
+    """device-resident batch of B monocular frames on one handle (BASELINE config 1 shape as a leg of every N-GPU line)"""
+
+    def __init__(self, pkg, torch, dev, local, w, h, nfeat, B, images):
+        self.B, self.w, self.h = B, w, h
+        self.pitch = (w + 63) // 64 * 64
+        host = np.zeros((B, h, self.pitch), np.uint8)
+        for i in range(B):
+            host[i, :, :w] = images[i % len(images)]
+        self.imgs = torch.from_numpy(host).to(dev)
+        self.ex = pkg.ORBextractor(nfeat, 1.2, NLEVELS, 20, 7, device=local, max_size=(w, h), max_batch=B)
+        self.cap = cap = self.ex.max_keypoints(w, h)
+        self.kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+        self.desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        self.nout = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.sp = self.stream.cuda_stream
+
+    def step(self):
+        self.ex.extract_batch_device(self.imgs.data_ptr(), self.h * self.pitch, self.pitch, self.B, self.w, self.h, self.kps.data_ptr(),
+                                     self.desc.data_ptr(), self.cap, self.nout.data_ptr(), self.sp)
+
+    def verify(self, images):
+        """every frame of the batch against the oracle's extraction of its image, byte for byte"""
+        from oracle import oracle_py
+        self.stream.synchronize()
+        orc = oracle_py.Oracle(self.ex.nfeatures, 1.2, NLEVELS, 20, 7)
+        ref = [orc.extract(m) for m in images]
+        n = self.nout.cpu().numpy(); k = self.kps.cpu().numpy().view(np.uint8).reshape(self.B, self.cap, 28); d = self.desc.cpu().numpy()
+        bad = [i for i in range(self.B) if not (int(n[i]) == len(ref[i % len(images)][0]) and k[i, :n[i]].tobytes() == ref[i % len(images)][0].tobytes() and
+                                                d[i, :n[i]].tobytes() == ref[i % len(images)][1].tobytes())]
+        return {"frames": self.B, "distinct_images": len(images), "against": "oracle/liborb_oracle.so", "bit_exact": not bad, "mismatching_frames": bad[:8]}
 
 
 def host_fed_batched(pkg, torch, dev, local, pairs, B, steps):
@@ -434,7 +469,8 @@ def run_workload(ctx, args):
     stage_all_ms = {k: v[0] / n_prof for k, v in prof_all.items()}
     dom_stage = max(stage_all_ms, key=stage_all_ms.get)
     ex.profile_stages(1 << pkg.orbx.STAGES.index(dom_stage))
-    elapsed = st.timed_steps(step, args.steps, local_sync, world, device=dist_dev)   # barrier + sync both sides, MAX over ranks
+    tdet = {}
+    elapsed = st.timed_steps(step, args.steps, local_sync, world, device=dist_dev, detail=tdet)   # barrier + sync both sides, MAX over ranks
     ex.profile_enable(False)
     prof = ex.profile_read(reset=True)
     ex.profile_stages(0xFFFFFFFF)
@@ -571,6 +607,12 @@ def run_workload(ctx, args):
                       "keypoints_per_image": round(nkp_avg, 1), "stereo_matches_per_frame": round(matched, 1),
                       "parallelism": f"{world} independent camera-stream batches, one per GPU"},
            "roofline": roofline}
+    if args.workload == "stereo1000" or world > 1:
+        # what makes an N-rank line self-evidencing: how many ranks met (SUM of ones), which card each held, each rank's own rate
+        out["config"]["ranks_seen"] = st.ranks_seen(world, dist_dev)
+        out["config"]["rank_devices"] = st.gather_strings(pkg.orbx.device_identity(local), world, dist_dev)
+        out["config"]["per_rank_frames_per_s"] = [round(B * args.steps / t, 1) for t in tdet["per_rank"]]
+        out["config"]["backend"] = ctx.get("backend", "none")
     if verified is not None:
         out["verified"] = verified
     if bow is not None and bow["queries"]:
@@ -601,6 +643,27 @@ def run_workload(ctx, args):
                                                    "keypoints_per_image": round(float(rig2.nout.float().mean().item()), 1),
                                                    "what": "BASELINE configs 2 / 5: 1241x376 @2000 feats per eye, extract L+R + stereo match, whole-job aggregate over n_gpus"}
         del rig2
+        torch.cuda.empty_cache()
+        # BASELINE config 1 shape (north_star: "synthetic 640x480 / 1241x376 ... at 1, 2, 4 and 8 GPUs") on every rank, its own barrier-aligned window
+        monos = [synth.image(seed0 + 50 + i, 640, 480) for i in range(4)]
+        rig3 = MonoRig(pkg, torch, dev, local, 640, 480, 1000, B, monos)
+        for _ in range(2):
+            rig3.step()
+
+        def sync3():
+            rig3.stream.synchronize(); torch.cuda.synchronize()
+        k3 = max(5, args.steps // 3)
+        d3 = {}
+        el3 = st.timed_steps(rig3.step, k3, sync3, world, device=dist_dev, detail=d3)
+        out["config"]["tum640_frames_per_s"] = {"value": round(st.aggregate_rate(B, k3, world, el3), 1), "frames_per_step_per_gpu": B, "steps": k3,
+                                                "keypoints_per_image": round(float(rig3.nout.float().mean().item()), 1),
+                                                "per_rank_frames_per_s": [round(B * k3 / t, 1) for t in d3["per_rank"]],
+                                                "what": "BASELINE config 1 shape: 640x480 mono @1000 feats, extract only, whole-job aggregate over n_gpus"}
+        if rank == 0 and not args.no_verify:
+            out["config"]["tum640_frames_per_s"]["verified"] = rig3.verify(monos)
+            if not out["config"]["tum640_frames_per_s"]["verified"]["bit_exact"]:
+                out["verified"] = dict(out.get("verified") or {}, bit_exact=False, tum640_leg_mismatch=True)
+        del rig3
         torch.cuda.empty_cache()
         if rank == 0 and world == 1:
             sweep = {}
@@ -656,6 +719,34 @@ def run_workload(ctx, args):
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: this process becomes the PARENT of `python -m torch.distributed.run
+    --nproc-per-node N bench.py <same arguments>` (one rank per GPU), relays the ranks' output -- rank 0's one JSON line on stdout --
+    and returns the launcher's exit code.  The parent never imports torch, never loads liborbx.so and never execs: nothing here
+    touches the GPU, the ranks are ordinary child processes (one process per GPU)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    for line in proc.stdout:                                  # stderr is inherited; stdout is relayed as it comes
+        if line.startswith("{"):
+            lines += 1
+        sys.stdout.write(line); sys.stdout.flush()
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py: expected ONE JSON line from rank 0, saw {lines}", file=sys.stderr)
+        return 4
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -673,6 +764,8 @@ def main():
     args = ap.parse_args()
     if args.cpu_frames < 0:
         args.cpu_frames = 240 if WORKLOADS[args.workload][3] == "stereo" else 6
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))     # no launcher on the command line: start the ranks ourselves, before anything touches the GPU
 
     import torch
     import torch.distributed as dist
@@ -691,7 +784,7 @@ def main():
     assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
     pkg.lib()  # fails loudly if liborbx.so is missing: there is no fallback path
     ctx = {"torch": torch, "pkg": pkg, "st": st, "dev": dev, "local": local, "rank": rank, "world": world,
-           "dist_dev": dev if backend == "nccl" else None}
+           "dist_dev": dev if backend == "nccl" else None, "backend": backend if world > 1 else "none"}
     out = run_workload(ctx, args)
     bad = out.get("verified") is not None and not out["verified"]["bit_exact"]
 

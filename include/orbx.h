@@ -54,6 +54,9 @@ typedef struct orbx_extractor orbx_extractor; /* opaque; owns device pyramid + w
 
 const char *orbx_last_error(void);
 int orbx_device_count(void);
+/* "<pci bus id> <uuid hex> <gcn arch>" of one visible device: an N-process launch (one process per GPU) reports it
+ * per rank so that the line shows every rank held its own card.  No reference counterpart (the reference is single-process CPU). */
+int orbx_device_identity(int device, char *buf, int cap);
 
 /* ---- ORBextractor (include/ORBextractor.h:58-139, src/ORBextractor.cc:429-534) ---------- */
 
@@ -64,13 +67,20 @@ int orbx_extractor_create(orbx_extractor **out, int nfeatures, float scale_facto
                           int ini_th_fast, int min_th_fast, int device, int max_w, int max_h, int max_batch);
 void orbx_extractor_destroy(orbx_extractor *e);
 
-/* Which OpenCV generation's cv::GaussianBlur(7x7, sigma 2) the descriptors are computed on (src/ORBextractor.cc:1311).  The
- * reference builds against "OpenCV 2.4.3 or later, tested with 2.4.11 and 3.2" (README.md:68), and OpenCV changed the 8-bit
- * Gaussian at 3.4.2 to a fixed-point kernel that sums to exactly 256 -- different blurred pixels, different rBRIEF bits.  The
- * arithmetic around the taps is the same in both, so the profile is the 7-tap table (orbx_gaussian_taps).  Default: 3.2, the
- * version the reference was tested with.  Call right after orbx_extractor_create; it applies to all later extractions. */
-#define ORBX_CV_PROFILE_3_2 0     /* OpenCV <= 3.4.1: taps 18 34 49 55 49 34 18 (sum 257) */
-#define ORBX_CV_PROFILE_3_4_2 1   /* OpenCV >= 3.4.2, 4.x: taps 18 34 48 56 48 34 18 (sum 256) */
+/* Which 7-tap table cv::GaussianBlur(7x7, sigma 2) (src/ORBextractor.cc:1311) is computed with.  OpenCV's 8-bit Gaussian has had two
+ * fixed-point kernels over the releases the reference builds against ("OpenCV 2.4.3 or later, tested with 2.4.11 and 3.2", README.md:68):
+ *   ORBX_CV_TAPS_257: every tap rounded by itself, cvRound(k * 256): 18 34 49 55 49 34 18 (sum 257)  -- default;
+ *   ORBX_CV_TAPS_256: rounding error diffused so that the taps sum to exactly 256: 18 34 48 56 48 34 18.
+ * Different taps give different blurred pixels and so different rBRIEF bits; the arithmetic around the taps (exact integer row pass,
+ * (sum + 2^15) >> 16 column pass) is the same for both.  WHICH OpenCV RELEASE USES WHICH TABLE IS PARITY UNPINNED: the reference holds no
+ * fixture and OpenCV is not installed here.  From memory: 3.2 (the tested version) has the 257 table; the fixed-point path that came with
+ * 3.4.2 may still round tap by tap, the error-diffused table arrived with a later 3.4.x / 4.x release.  A deployment decides by comparing one
+ * blurred image against its own OpenCV.  The *_PROFILE_* names are the older spelling of the same two values.
+ * Call right after orbx_extractor_create; it applies to all later extractions. */
+#define ORBX_CV_TAPS_257 0
+#define ORBX_CV_TAPS_256 1
+#define ORBX_CV_PROFILE_3_2 ORBX_CV_TAPS_257
+#define ORBX_CV_PROFILE_3_4_2 ORBX_CV_TAPS_256
 int orbx_extractor_set_cv_profile(orbx_extractor *e, int profile);
 int orbx_gaussian_taps(int profile, int taps[7]);
 
@@ -188,14 +198,20 @@ int orbx_stereo_match(orbx_extractor *L, orbx_extractor *R,
  * from their most recent extract_batch calls (L and R may be the same handle).  Keypoints /
  * descriptors / counts are the device outputs of orbx_extract_batch_device with capacity `cap`.
  * d_u_right, d_depth: [batch*cap] floats.
- * The row table of src/Frame.cc:584-604 is a by-product of the right images' extraction: when d_kR is the very buffer
- * (address and capacity) that R's most recent orbx_extract_batch_device wrote, that table is used, so the buffer must still
- * hold what the extraction wrote -- a caller that edits the right keypoints in place must pass them from another buffer
- * (any other address gets a table built from the keypoints handed in, as orbx_stereo_match always does). */
+ * `row_table` states where the row table of src/Frame.cc:584-604 comes from -- never guessed from addresses:
+ *   ORBX_ROWTAB_FROM_KEYPOINTS  built from the right keypoints handed in (d_kR, d_nR), whatever they are: always correct;
+ *   ORBX_ROWTAB_OF_EXTRACTION   the by-product table R's most recent orbx_extract_batch_device left behind (one launch less).
+ *                               The caller thereby asserts that d_kR still holds exactly what that extraction wrote; the call is
+ *                               refused with ORBX_E_INVALID when d_kR / cap / the image range are not the ones of that extraction,
+ *                               or when that extraction built no table (images taller than 600 rows). */
+#define ORBX_ROWTAB_FROM_KEYPOINTS 0
+#define ORBX_ROWTAB_OF_EXTRACTION 1
 int orbx_stereo_match_batch_device(orbx_extractor *L, int imgL0, orbx_extractor *R, int imgR0, int batch,
                                    const void *d_kL, const void *d_dL, const void *d_nL,
                                    const void *d_kR, const void *d_dR, const void *d_nR, int cap,
-                                   float bf, float min_z, void *d_u_right, void *d_depth, void *stream);
+                                   float bf, float min_z, void *d_u_right, void *d_depth, int row_table, void *stream);
+/* 1 when R's most recent extraction left a row table behind that ORBX_ROWTAB_OF_EXTRACTION could use for (d_kR, imgR0, batch, cap) */
+int orbx_stereo_row_table_available(const orbx_extractor *R, const void *d_kR, int imgR0, int batch, int cap);
 
 /* ---- ORBmatcher (include/ORBmatcher.h:41-83) ---------------------------------------------- */
 
@@ -282,6 +298,9 @@ typedef struct orbx_kf orbx_kf;
 int orbx_kf_create(int device, const orbx_featset *fs, orbx_kf **out);
 void orbx_kf_destroy(orbx_kf *k);
 int orbx_kf_size(const orbx_kf *k);
+/* The per-call matchers keep a small per-THREAD context per device (a stream, mapped pinned blobs, device scratch).  It is given back
+ * when the thread ends; a long-lived thread that is done matching (or a pool worker between jobs) may give it back now. */
+void orbx_thread_release(void);
 /* SearchByBoW(pKF, F): kf_flag as orbx_search_by_bow_kf_f's kf->flag; match_f[f's n] */
 int orbx_kf_search_by_bow_kf_f(const orbx_kf *kf, const uint8_t *kf_flag, const orbx_kf *f,
                                float nnratio, int check_orientation, int32_t *match_f, int *nmatches);

@@ -155,7 +155,7 @@ class Oracle:
             self.h = None
 
     def set_cv_profile(self, profile):
-        """0 = OpenCV <= 3.4.1 GaussianBlur taps (default), 1 = OpenCV >= 3.4.2 fixed-point taps"""
+        """0 = GaussianBlur taps summing to 257 (cvRound per tap; OpenCV 3.2, default), 1 = taps summing to 256 (error-diffused; later OpenCV releases: which one switched is parity unpinned)"""
         assert self.L.oracle_set_cv_profile(self.h, profile) == 0
 
     def _farr(self, fn, n=None):

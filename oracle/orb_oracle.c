@@ -167,10 +167,11 @@ static int reflect101(int i, int n)
 
 /* cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) for 8U (reference src/ORBextractor.cc:1311).  Two OpenCV
  * generations, same arithmetic (exact integer row pass; (sum+2^15)>>16 column pass), different 8-bit fixed-point taps:
- *   profile 0 (OpenCV <= 3.4.1): float kernel -> cvRound(k*256), not renormalised: 18 34 49 55 49 34 18 (sum 257);
- *   profile 1 (OpenCV >= 3.4.2 / 4.x, getGaussianKernelFixedPoint_ED): rounded from the outside in, the rounding error
+ *   profile 0 (TAPS_257; OpenCV 3.2, the version the reference was tested with): float kernel -> cvRound(k*256), not renormalised:
+ *             18 34 49 55 49 34 18 (sum 257);
+ *   profile 1 (TAPS_256; getGaussianKernelFixedPoint_ED of later 3.4.x / 4.x releases): rounded from the outside in, the rounding error
  *             carried to the next tap, centre = 256 - the rest: 18 34 48 56 48 34 18 (sum 256).
- * Both from memory of OpenCV: parity unpinned. */
+ * Both from memory of OpenCV, and so is the release at which the second replaced the first: parity unpinned. */
 void oracle_gaussian_taps(int profile, int taps[7])
 {
     double scale2x = -0.5 / (2.0 * 2.0);

@@ -23,6 +23,25 @@ extern "C" int orbx_device_count(void)
     return n;
 }
 
+// "<pci bus id> <uuid hex> <name>" of device `device`: what an N-rank launch prints per rank so that a reader can see that every
+// rank held its own card (bench.py config.rank_devices)
+extern "C" int orbx_device_identity(int device, char *buf, int cap)
+{
+    if (!buf || cap < 16) { orbx_set_error("identity buffer too small"); return ORBX_E_INVALID; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { orbx_set_error("device %d out of range (%d visible)", device, n); return ORBX_E_NO_DEVICE; }
+    char bus[32] = "?";
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) strcpy(bus, "?");
+    hipUUID u;
+    char hex[33] = "";
+    if (hipDeviceGetUuid(&u, device) == hipSuccess)
+        for (int i = 0; i < 16; i++) snprintf(hex + 2 * i, 3, "%02x", (unsigned char)u.bytes[i]);
+    hipDeviceProp_t p;
+    const char *name = hipGetDeviceProperties(&p, device) == hipSuccess ? p.gcnArchName : "?";
+    snprintf(buf, cap, "%s %s %s", bus, hex[0] ? hex : "?", name);
+    return ORBX_OK;
+}
+
 // ORBmatcher::DescriptorDistance (reference src/ORBmatcher.cc:1733-1749): popcount(a XOR b), 256 bits
 extern "C" int orbx_hamming(const uint8_t *a, const uint8_t *b)
 {

@@ -4,6 +4,36 @@
 
 #define WAVE 64
 
+// ---- arrays that take part in a RELAXED PUBLISH PROTOCOL (k_stereo's folded median cut, k_match's last-arriver finalisation).
+// Producers on any XCD write their results as relaxed agent-scope atomic stores (gfx942 / gfx950: `global_store ... sc1`, a write-through
+// that leaves no dirty line in the producer's L2), wait for the acknowledgements (`publish_drain`: s_waitcnt vmcnt(0)) and only then bump a
+// relaxed agent-scope arrival counter; the workgroup whose bump completes the count reads the array with relaxed agent-scope atomic loads
+// (sc1: served from the memory side, never from a stale line of its own XCD's L2).  That replaces a release fence per producer
+// (`__threadfence()` = buffer_wbl2: 17-27 us of a 2000-item launch, profiles/r03_match_stamps.txt) and is correct ONLY while EVERY access to
+// such an array inside the launch is an agent-scope atomic: one plain load may hit a stale L2 line, one plain store may sit dirty in an L2 the
+// consumer never sees.  `Published<T>` therefore has no operator[] and hands out no pointer: a plain access of these arrays does not
+// compile.  A launch whose consumer is a LATER launch (kernel boundaries write back and invalidate) may use `plain_across_launches()`.
+// The reasoning is about this memory system, so the build is refused for any other target.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "liborbx relies on gfx950 cache semantics (sc1 write-through stores in the relaxed publish protocols): build with --offload-arch=gfx950 only"
+#endif
+template <typename T>
+class Published {
+    T *p_;
+public:
+    Published() = default;
+    __host__ __device__ explicit Published(T *p) : p_(p) {}
+    __device__ __forceinline__ void put(long long i, T v) const { __hip_atomic_store(p_ + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ T get(long long i) const { return __hip_atomic_load(p_ + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __host__ __device__ __forceinline__ Published at(long long off) const { return Published(p_ + off); }
+    // only for a launch that does not run the protocol (its results are consumed by a later launch)
+    __device__ __forceinline__ T *plain_across_launches() const { return p_; }
+};
+// a producer's stores have been acknowledged by the memory side: what it publishes next (the arrival bump) is ordered behind them
+__device__ __forceinline__ void publish_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// the arrival bump itself; returns the number of producers that had arrived before this one
+__device__ __forceinline__ int publish_arrive(int *counter) { return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // forward declaration of the DPP helper macro used below
 #define ORBX_DPP(v, identity, ctrl, row_mask, bank_mask) \
     __builtin_amdgcn_update_dpp((int)(identity), (int)(v), ctrl, row_mask, bank_mask, false)

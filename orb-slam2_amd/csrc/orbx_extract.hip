@@ -1397,7 +1397,7 @@ struct DescArgs {
 // The row table of Frame::ComputeStereoMatches (vRowIndices, src/Frame.cc:584-604) as a by-product of the extraction: it depends only
 // on the keypoints' rows, octaves and columns, which the quadtree has already fixed, so ONE extra wave per image builds it inside the
 // k_desc launch while the other waves compute descriptors (a launch of its own, k_stereo_prep, was 10 us of a single frame's 124 us
-// chain).  orbx_stereo_match_batch_device uses it when it is handed the very keypoint buffer this extraction wrote; any other caller
+// chain).  orbx_stereo_match_batch_device uses it when its caller says so (ORBX_ROWTAB_OF_EXTRACTION: the keypoint buffer still holds what this extraction wrote); any other caller
 // of the stereo matcher still gets k_stereo_prep.  Layout (see orbx_stereo.hip): CSR by the keypoint's centre row, row_off[rows + 1],
 // one entry (iR | octave << 16, x, minr | maxr << 16, 0) per keypoint.
 struct RowTabArgs { int *row_off; uint4 *entries; int ent_cap, rows, on, pad; };
@@ -2154,7 +2154,7 @@ extern "C" int orbx_extractor_set_pyramid_group_limit(orbx_extractor *e, int max
 {
     if (!e || max_images < 0) { orbx_set_error("orbx_extractor_set_pyramid_group_limit: invalid argument"); return ORBX_E_INVALID; }
     e->pyr_group_max_images = max_images;       // a launch constant of later extractions; results do not depend on it
-    if (max_images == 0) e->pyr_group_mid_images = 0;       // 0 = one launch per level, always
+    e->pyr_group_mid_images = max_images == 0 ? 0 : e->pyr_group_mid_cfg;       // 0 = one launch per level, always; any other limit: the configured mid size again
     for (orbx_extractor *x : e->lanes) if (x) { x->pyr_group_max_images = max_images; x->pyr_group_mid_images = e->pyr_group_mid_images; }
     return ORBX_OK;
 }
@@ -2184,7 +2184,9 @@ extern "C" int orbx_extractor_create(orbx_extractor **out, int nfeatures, float 
         const char *env = getenv("ORBX_PYR_GROUP_MAX_IMAGES");
         e->pyr_group_max_images = env && *env ? atoi(env) : 8;
         const char *mid = getenv("ORBX_PYR_GROUP_MID_IMAGES");
-        e->pyr_group_mid_images = mid && *mid ? atoi(mid) : 24;     // (8 frames: 57.2 -> 59.8 k frames/s; 16 frames: the same; 32: slower)
+        e->pyr_group_mid_images = e->pyr_group_mid_cfg = mid && *mid ? atoi(mid) : 24;     // (8 frames: 57.2 -> 59.8 k frames/s; 16 frames: the same; 32: slower)
+        const char *kpw = getenv("ORBX_STEREO_KPW");      // tests: k_stereo's one / four keypoints per wave on the same input
+        e->stereo_kpw_forced = kpw && (*kpw == '1' || *kpw == '4') ? *kpw - '0' : 0;
         const char *pl = getenv("ORBX_PIPE_LANES"), *pi = getenv("ORBX_PIPE_INLINE");
         // defaults (examples/stereo_stream on one camera stream): four lanes, transport by copy kernel on the lane's stream: 19 k frames/s;
         // copy engines on two copy streams: 15 k whatever the lanes; ORBX_PIPE_INLINE=0 / ORBX_PIPE_KCOPY=0 select the older forms
@@ -2685,8 +2687,10 @@ extern "C" int orbx_extract_stereo(orbx_extractor *e, const uint8_t *img_left, c
     orbx_keypoint *dk = (orbx_keypoint *)e->d_out_kps;
     uint8_t *dd = (uint8_t *)e->d_out_desc;
     int *dn = (int *)e->d_out_n;
+    // the right keypoints are what the launch above wrote into the handle's own buffer: its by-product row table serves when it built one
     rc = orbx_stereo_match_batch_device(e, 0, e, 1, 1, dk, dd, dn, dk + need, dd + (size_t)32 * need, dn + 1, need, bf, min_z,
-                                        e->d_out_ur, e->d_out_depth, nullptr);
+                                        e->d_out_ur, e->d_out_depth,
+                                        orbx_stereo_row_table_available(e, dk + need, 1, 1, need) ? ORBX_ROWTAB_OF_EXTRACTION : ORBX_ROWTAB_FROM_KEYPOINTS, nullptr);
     if (rc) return rc;
     ORBX_HIP(hipMemcpyAsync(e->h_out, dn, sizeof(int) * 2, hipMemcpyDeviceToHost, e->stream));
     ORBX_HIP(hipMemcpyAsync(e->h_out + o_kps, dk, sizeof(orbx_keypoint) * (size_t)need * 2, hipMemcpyDeviceToHost, e->stream));
@@ -2785,26 +2789,28 @@ static std::atomic<int> g_pipe_handles{0};   // handles of this process that hav
 void orbx_pipe_handle_released() { g_pipe_handles.fetch_sub(1, std::memory_order_relaxed); }
 
 // one frame into the next pipeline slot: eyes = 2 (stereo: both extractions + ComputeStereoMatches) or 1 (mono: extraction only)
-static double g_pp[8]; static long g_pp_n;     // ORBX_PIPE_PROF: host microseconds per section of pipe_submit / pipe_wait
+// ORBX_PIPE_PROF: host nanoseconds per section of pipe_submit / pipe_wait, summed over every client thread (relaxed atomics: diagnostic only)
+static std::atomic<long long> g_pp[8]; static std::atomic<long> g_pp_n;
 static inline double pp_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static const bool g_pp_on = getenv("ORBX_PIPE_PROF") != nullptr;
 struct PpScope {    // charges the time since construction / the last next() to section k
     int k; double t0;
     explicit PpScope(int k_) : k(k_), t0(g_pp_on ? pp_now() : 0) {}
-    void next(int k_) { if (g_pp_on) { const double t = pp_now(); g_pp[k] += t - t0; t0 = t; } k = k_; }
-    ~PpScope() { if (g_pp_on) g_pp[k] += pp_now() - t0; }
+    void next(int k_) { if (g_pp_on) { const double t = pp_now(); g_pp[k].fetch_add((long long)((t - t0) * 1e3), std::memory_order_relaxed); t0 = t; } k = k_; }
+    ~PpScope() { if (g_pp_on) g_pp[k].fetch_add((long long)((pp_now() - t0) * 1e3), std::memory_order_relaxed); }
 };
 extern "C" void orbx_debug_pipe_prof_print()
 {
-    if (!g_pp_on || !g_pp_n) return;
+    const long frames = g_pp_n.load();
+    if (!g_pp_on || !frames) return;
     const char *nm[8] = { "setdevice+lane+geometry", "pinned test + slot", "upload enqueue", "extract launches", "stereo launch", "download enqueue + event", "wait: event sync", "wait: copy out" };
-    for (int i = 0; i < 8; i++) fprintf(stderr, "pipe prof: %-28s %7.2f us per frame\n", nm[i], g_pp[i] / g_pp_n);
+    for (int i = 0; i < 8; i++) fprintf(stderr, "pipe prof: %-28s %7.2f us per frame\n", nm[i], g_pp[i].load() * 1e-3 / frames);
 }
 
 static int pipe_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t *img_right, int eyes, int w, int h, size_t stride,
                        float bf, float min_z, int *ticket)
 {
-    g_pp_n++;
+    if (g_pp_on) g_pp_n.fetch_add(1, std::memory_order_relaxed);
     PpScope pp(0);
 #define PP_NEXT(K) pp.next(K)
     ORBX_HIP(orbx_use_device(e->device));
@@ -2878,7 +2884,8 @@ static int pipe_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t
     if (rc) return rc;
     PP_NEXT(4);
     if (eyes == 2) {
-        rc = orbx_stereo_match_batch_device(x, 0, x, 1, 1, dk, dd, dn, dk + need, dd + (size_t)32 * need, dn + 1, need, bf, min_z, s.d_ur, s.d_z, nullptr);
+        rc = orbx_stereo_match_batch_device(x, 0, x, 1, 1, dk, dd, dn, dk + need, dd + (size_t)32 * need, dn + 1, need, bf, min_z, s.d_ur, s.d_z,
+                                            orbx_stereo_row_table_available(x, dk + need, 1, 1, need) ? ORBX_ROWTAB_OF_EXTRACTION : ORBX_ROWTAB_FROM_KEYPOINTS, nullptr);
         if (rc) return rc;
     }
     PP_NEXT(5);

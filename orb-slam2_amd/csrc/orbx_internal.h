@@ -139,6 +139,8 @@ struct orbx_extractor {
     int n_pyr_groups;                // 0: this geometry has no grouped form (per-level launches at every batch size)
     int pyr_group_max_images;        // launches of at most this many images take the grouped form
     int pyr_group_mid_images;        // ... and up to this many: levels of the first group by one launch each, the later groups grouped
+    int pyr_group_mid_cfg;           // the configured value of pyr_group_mid_images (default 24 / ORBX_PYR_GROUP_MID_IMAGES): what a non-zero group limit restores
+    int stereo_kpw_forced;           // ORBX_STEREO_KPW (1 / 4), read once when the handle is created: forces k_stereo's keypoints per wave; 0 = by launch size
     int fast_waves;                  // waves per FAST cell: 0 = by launch size (several for a frame or two, one for batches); 1-4 forces (ORBX_FAST_WAVES)
     // stereo row table written by the most recent extraction as a by-product of k_desc (desc_rowtab): valid for the keypoint buffer
     // rt_kps (capacity rt_cap per image, rt_batch images); d_rt_off == nullptr: this geometry has none (more rows than k_desc's LDS holds)

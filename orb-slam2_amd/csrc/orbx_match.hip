@@ -59,7 +59,7 @@ static_assert(sizeof(MTri) == 48, "MTri layout");
 struct MArgs {
     const MItem *items;
     const MTri *tri;                  // [npairs] (triangulation, calls with several pairs)
-    int32_t *tmp;                     // device scratch rows, -1 outside a call
+    Published<int32_t> tmp;           // device scratch rows, -1 outside a call; relaxed publish protocol (orbx_device.h): no plain access compiles
     unsigned *cnt;                    // [0] pairs finalised; pair p: [32 (p + 1)] items arrived, [32 (p + 1) + 1 + bin] rotation histogram; 0 outside a call
     int32_t *out;                     // result block (mapped pinned memory)
     unsigned *flag; unsigned ticket;  // completion flag (mapped pinned memory)
@@ -126,7 +126,7 @@ __device__ __forceinline__ bool m_live(int cnt, unsigned long long mask, const u
 __device__ __forceinline__ void m_record(const MArgs &g, const MItem &it, int slot, int value, float ang1, float ang2)
 {
     const int bin = m_rot_bin(ang1, ang2);
-    __hip_atomic_store(&g.tmp[it.tmp_off + slot], (bin << 20) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    g.tmp.put(it.tmp_off + slot, (bin << 20) | value);
 }
 
 // The last item of a pair: ComputeThreeMaxima (:1687-1728) on the histogram the items accumulated, clearing of the other bins
@@ -136,18 +136,18 @@ template <int MODE>
 __device__ void m_finalize(const MArgs &g, const MItem &it, int lane, unsigned *s_hist M_STAMP_ARG)
 {
     const int nslots = it.nslots, cap = it.cap;
-    int32_t *tmp = g.tmp + it.tmp_off;
+    const Published<int32_t> tmp = g.tmp.at(it.tmp_off);
     int32_t *out = g.out + it.out_off;
     int v[16];
 #pragma unroll
-    for (int u = 0; u < 16; u++) { const int s = u * 64 + lane; v[u] = s < nslots ? tmp[s] : -1; }
+    for (int u = 0; u < 16; u++) { const int s = u * 64 + lane; v[u] = s < nslots ? tmp.get(s) : -1; }
     int k1 = -1, k2 = -1, k3 = -1;
     if (g.check_ori) {
         s_hist[lane & 31] = 0;
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < 16; u++) if (v[u] != -1) atomicAdd(&s_hist[v[u] >> 20], 1u);
-        for (int base = 16 * 64; base < nslots; base += 64) { const int s = base + lane; const int w = s < nslots ? tmp[s] : -1; if (w != -1) atomicAdd(&s_hist[w >> 20], 1u); }
+        for (int base = 16 * 64; base < nslots; base += 64) { const int s = base + lane; const int w = s < nslots ? tmp.get(s) : -1; if (w != -1) atomicAdd(&s_hist[w >> 20], 1u); }
         __syncthreads();
         // the sequential scan of the reference keeps, with strict comparisons, the three largest bins in the order (count
         // descending, bin ascending) among bins with count > 0: three wave maxima of count << 8 | (255 - bin)
@@ -170,7 +170,7 @@ __device__ void m_finalize(const MArgs &g, const MItem &it, int lane, unsigned *
     for (int base = 0; base < nslots; base += 16 * 64) {
         if (base) {
 #pragma unroll
-            for (int u = 0; u < 16; u++) { const int s = base + u * 64 + lane; v[u] = s < nslots ? tmp[s] : -1; }
+            for (int u = 0; u < 16; u++) { const int s = base + u * 64 + lane; v[u] = s < nslots ? tmp.get(s) : -1; }
         }
 #pragma unroll
         for (int u = 0; u < 16; u++) {
@@ -187,7 +187,7 @@ __device__ void m_finalize(const MArgs &g, const MItem &it, int lane, unsigned *
                 if (s < nslots) out[s] = keep ? (v[u] & 0xFFFFF) : -1;
                 cnt_keep += keep ? 1 : 0;
             }
-            if (v[u] != -1) tmp[s] = -1;
+            if (v[u] != -1) tmp.put(s, -1);
         }
     }
     if (MODE != 2) run = wave_sum(cnt_keep);
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(64) void k_match(MArgs g)
     if (it.nitems > 1) {
         // release: every store of this wave to the scratch row was a write-through agent-scope atomic; once they are acknowledged
         // (vmcnt 0) they are visible device-wide, so the counter may be bumped without an L2 write-back
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        publish_drain();
         unsigned prev = 0;
         if (lane == 0) prev = __hip_atomic_fetch_add(&g.cnt[32 * (it.pair + 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
@@ -510,8 +510,27 @@ struct MatchCtx {
     std::vector<MItem> items;
     std::vector<int> pair_first;                                            // first item of each pair (+ end)
     std::vector<unsigned long long> bits;                                   // participation bits of the call's sides, list order
+    bool poisoned = false;      // a call failed after its launch: d_tmp / d_cnt may not be back at -1 / 0 (the kernels rely on that); restored before the next call
+    void release()              // stream, pinned blobs and device scratch of this thread on this device
+    {
+        if (device < 0) return;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && device < ndev && hipSetDevice(device) == hipSuccess) {   // (a runtime that is already shutting down: leave it alone)
+            if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+            if (h_flag) (void)hipHostFree(h_flag);
+            if (h_blob) (void)hipHostFree(h_blob);
+            if (h_out) (void)hipHostFree(h_out);
+            if (d_tmp) (void)hipFree(d_tmp);
+            if (d_cnt) (void)hipFree(d_cnt);
+        }
+        stream = nullptr; h_flag = d_flag = nullptr; h_blob = d_blob = nullptr; h_out = d_out = nullptr; d_tmp = nullptr; d_cnt = nullptr;
+        blob_cap = out_cap = tmp_cap = cnt_cap = 0; device = -1; poisoned = false;
+    }
+    ~MatchCtx() { release(); }  // a thread that called a matcher gives its resources back when it ends (thread pools, short-lived workers)
 };
 static thread_local MatchCtx g_mctx[16];
+// the calling thread's matcher resources on every device, now (they are also released when the thread ends)
+extern "C" void orbx_thread_release(void) { for (MatchCtx &c : g_mctx) c.release(); }
 static thread_local double g_mtime[4];   // host phases of this thread's most recent call, microseconds: prepare, launch, wait, copy-out
 static inline double m_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 extern "C" int orbx_debug_match_timing(double *out4) { if (!out4) return ORBX_E_INVALID; for (int i = 0; i < 4; i++) out4[i] = g_mtime[i]; return ORBX_OK; }
@@ -522,6 +541,14 @@ static int mctx_get(int device, MatchCtx **out)
     if (c && c->stream) {                 // steady state: this thread has used the device before
         int cur = -1;
         if (hipGetDevice(&cur) != hipSuccess || cur != device) ORBX_HIP(hipSetDevice(device));
+        if (c->poisoned) {                // an earlier call failed after its launch: scratch rows back to -1, counters to 0, before anything reads them
+            ORBX_HIP(hipStreamSynchronize(c->stream));
+            if (c->d_tmp) ORBX_HIP(hipMemset(c->d_tmp, 0xFF, c->tmp_cap * sizeof(int32_t)));
+            if (c->d_cnt) ORBX_HIP(hipMemset(c->d_cnt, 0, c->cnt_cap * sizeof(unsigned)));
+            ORBX_HIP(hipDeviceSynchronize());
+            *c->h_flag = 0; c->ticket = 0;
+            c->poisoned = false;
+        }
         *out = c;
         return ORBX_OK;
     }
@@ -531,11 +558,17 @@ static int mctx_get(int device, MatchCtx **out)
         return ORBX_E_NO_DEVICE;
     }
     ORBX_HIP(hipSetDevice(device));
-    ORBX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    ORBX_HIP(hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocCoherent | hipHostMallocMapped));
-    ORBX_HIP(hipHostGetDevicePointer((void **)&c->d_flag, c->h_flag, 0));
-    *c->h_flag = 0;
-    c->device = device;
+    // the context counts as set up (c->stream != 0 is the steady-state test above) only when every piece exists
+    unsigned *hf = nullptr, *df = nullptr;
+    hipStream_t st = nullptr;
+    ORBX_HIP(hipHostMalloc((void **)&hf, 64, hipHostMallocCoherent | hipHostMallocMapped));
+    if (hipHostGetDevicePointer((void **)&df, hf, 0) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipHostFree(hf);
+        orbx_set_error("matcher context: stream / mapped flag could not be created on device %d", device);
+        return ORBX_E_HIP;
+    }
+    *hf = 0;
+    c->h_flag = hf; c->d_flag = df; c->device = device; c->stream = st;
     *out = c;
     return ORBX_OK;
 }
@@ -835,7 +868,7 @@ static int match_call(int mode, int device, HSide *sides, int nsides, const int 
         memset(&g, 0, sizeof g);
         g.items = reinterpret_cast<const MItem *>(c->d_blob);
         g.tri = reinterpret_cast<const MTri *>(c->d_blob + off_tri);
-        g.tmp = c->d_tmp; g.cnt = c->d_cnt;
+        g.tmp = Published<int32_t>(c->d_tmp); g.cnt = c->d_cnt;
         g.out = c->d_out; g.flag = c->d_flag; g.ticket = ++c->ticket; g.npairs = npairs; g.npairs_live = live;
         g.nnratio = nnratio; g.check_ori = check_ori;
         if (mode == 2) {
@@ -849,6 +882,7 @@ static int match_call(int mode, int device, HSide *sides, int nsides, const int 
             for (int i = 0; i < 16; i++) { g.te[i] = i < nlv ? 100 * sf2[i] : 0.f; g.sg[i] = i < nlv ? sig2[i] : 0.f; }
         }
         t_prep = m_now_us();
+        c->poisoned = true;         // until this call has its results: any error return below leaves scratch rows / counters in an unknown state
         const dim3 grid((unsigned)c->items.size()), block(64);
         if (mode == 0) hipLaunchKernelGGL(k_match<0>, grid, block, 0, c->stream, g);
         else if (mode == 1) hipLaunchKernelGGL(k_match<1>, grid, block, 0, c->stream, g);
@@ -867,6 +901,7 @@ static int match_call(int mode, int device, HSide *sides, int nsides, const int 
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        c->poisoned = false;        // the last finaliser has run: every scratch row is -1 again, every counter 0
         t_wait = m_now_us();
     }
     for (int p = 0; p < npairs; p++) {

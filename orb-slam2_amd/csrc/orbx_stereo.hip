@@ -29,13 +29,12 @@ __device__ __forceinline__ int lvl_px(const uint8_t *img, int pitch, int w, int 
 
 // a keypoint's results as write-through stores (sc1): visible to the pair's last workgroup on another XCD once acknowledged
 template <bool FOLD>
-__device__ __forceinline__ void st_store(float *u_right, float *depth, int *st_dist, long long og, float u, float z, int sad)
+__device__ __forceinline__ void st_store(Published<float> u_right, Published<float> depth, Published<int> st_dist, long long og, float u, float z, int sad)
 {
-    if (FOLD) {
-        __hip_atomic_store(&u_right[og], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&depth[og], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&st_dist[og], sad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else { u_right[og] = u; depth[og] = z; st_dist[og] = sad; }     // the cut is a launch of its own: ordinary stores
+    if (FOLD) { u_right.put(og, u); depth.put(og, z); st_dist.put(og, sad); }       // relaxed publish protocol (orbx_device.h)
+    else {                                                                          // the cut is a launch of its own: ordinary stores
+        u_right.plain_across_launches()[og] = u; depth.plain_across_launches()[og] = z; st_dist.plain_across_launches()[og] = sad;
+    }
 }
 
 // Row table of src/Frame.cc:584-604 (vRowIndices).  The reference lists right keypoint iR in every image row of its band
@@ -97,7 +96,9 @@ __device__ __forceinline__ void hist_select(const int *hist, int k, int *sel, in
     }
 }
 
-__device__ __forceinline__ void stereo_cut(int n_l, long long o, float *__restrict__ u_right, float *__restrict__ depth, int *__restrict__ st_dist)
+// Runs either as the consumer of the relaxed publish protocol (the pair's last workgroup inside k_stereo<FOLD>) or as a launch of its own
+// (k_stereo_cut); both read and write the three arrays through Published<T> only.
+__device__ __forceinline__ void stereo_cut(int n_l, long long o, Published<float> u_right, Published<float> depth, Published<int> st_dist)
 {
     __shared__ __align__(16) int hist[256];
     __shared__ int s_sel, s_rem, s_cnt;
@@ -107,7 +108,7 @@ __device__ __forceinline__ void stereo_cut(int n_l, long long o, float *__restri
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int i = tid + 256 * k;
-        d[k] = i < n_l ? __hip_atomic_load(&st_dist[o + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+        d[k] = i < n_l ? st_dist.get(o + i) : -1;
     }
     hist[tid] = 0;
     if (tid == 0) s_cnt = 0;
@@ -116,7 +117,7 @@ __device__ __forceinline__ void stereo_cut(int n_l, long long o, float *__restri
 #pragma unroll
     for (int k = 0; k < K; k++) if (d[k] >= 0) { atomicAdd(&hist[d[k] >> 8], 1); local++; }
     for (int i = tid + 256 * K; i < n_l; i += 256) {
-        const int v = __hip_atomic_load(&st_dist[o + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int v = st_dist.get(o + i);
         if (v >= 0) { atomicAdd(&hist[v >> 8], 1); local++; }
     }
     if (local) atomicAdd(&s_cnt, local);
@@ -132,7 +133,7 @@ __device__ __forceinline__ void stereo_cut(int n_l, long long o, float *__restri
 #pragma unroll
     for (int k = 0; k < K; k++) if (d[k] >= 0 && (d[k] >> 8) == hi) atomicAdd(&hist[d[k] & 255], 1);
     for (int i = tid + 256 * K; i < n_l; i += 256) {
-        const int v = __hip_atomic_load(&st_dist[o + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int v = st_dist.get(o + i);
         if (v >= 0 && (v >> 8) == hi) atomicAdd(&hist[v & 255], 1);
     }
     __syncthreads();
@@ -142,10 +143,10 @@ __device__ __forceinline__ void stereo_cut(int n_l, long long o, float *__restri
     const float th_dist = 1.5f * 1.4f * median;
 #pragma unroll
     for (int k = 0; k < K; k++)
-        if (d[k] >= 0 && !((float)d[k] < th_dist)) { u_right[o + tid + 256 * k] = -1.0f; depth[o + tid + 256 * k] = -1.0f; }
+        if (d[k] >= 0 && !((float)d[k] < th_dist)) { u_right.put(o + tid + 256 * k, -1.0f); depth.put(o + tid + 256 * k, -1.0f); }
     for (int i = tid + 256 * K; i < n_l; i += 256) {
-        const int v = __hip_atomic_load(&st_dist[o + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v >= 0 && !((float)v < th_dist)) { u_right[o + i] = -1.0f; depth[o + i] = -1.0f; }
+        const int v = st_dist.get(o + i);
+        if (v >= 0 && !((float)v < th_dist)) { u_right.put(o + i, -1.0f); depth.put(o + i, -1.0f); }
     }
 }
 
@@ -157,8 +158,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                 const orbx_keypoint *__restrict__ kL, const uint32_t *__restrict__ dL,
                                                 const int *__restrict__ nL, const orbx_keypoint *__restrict__ kR,
                                                 const uint32_t *__restrict__ dR, const int *__restrict__ nR, int cap,
-                                                float bf, float max_d, StereoTabs tabs, float *__restrict__ u_right,
-                                                float *__restrict__ depth, int *__restrict__ st_dist,
+                                                float bf, float max_d, StereoTabs tabs, Published<float> u_right,
+                                                Published<float> depth, Published<int> st_dist,
                                                 const int *__restrict__ row_off, const uint4 *__restrict__ entries, int ent_cap, int reach,
                                                 int *__restrict__ arrive, int kpw)
 {
@@ -351,11 +352,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // stores; once they are acknowledged the workgroup counts itself in, and the one that completes the count sees them all
     if (!FOLD) return;
     __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    publish_drain();
     __syncthreads();
     if (threadIdx.x == 0) {
         const int nwg = (n_l + 4 * kpw - 1) / (4 * kpw);
-        const int old = __hip_atomic_fetch_add(&arrive[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int old = publish_arrive(&arrive[p]);
         s_last = old == nwg - 1;
         if (old == nwg - 1) __hip_atomic_store(&arrive[p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
     }
@@ -364,8 +365,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     stereo_cut(n_l, (long long)p * cap, u_right, depth, st_dist);
 }
 
-__global__ __launch_bounds__(256) void k_stereo_cut(const int *__restrict__ nL, int cap, float *__restrict__ u_right,
-                                                    float *__restrict__ depth, int *__restrict__ st_dist)
+__global__ __launch_bounds__(256) void k_stereo_cut(const int *__restrict__ nL, int cap, Published<float> u_right,
+                                                    Published<float> depth, Published<int> st_dist)
 {
     stereo_cut(nL[blockIdx.x], (long long)blockIdx.x * cap, u_right, depth, st_dist);
 }
@@ -377,11 +378,18 @@ static int same_geometry(const orbx_extractor *L, const orbx_extractor *R)
     return 1;
 }
 
+extern "C" int orbx_stereo_row_table_available(const orbx_extractor *R, const void *d_kR, int img_r0, int batch, int cap)
+{
+    return R && d_kR && img_r0 >= 0 && batch >= 1 && R->d_rt_off && R->rt_kps && cap == R->rt_cap && img_r0 + batch <= R->rt_batch &&
+           (const char *)d_kR == (const char *)R->rt_kps + (size_t)img_r0 * cap * sizeof(orbx_keypoint);
+}
+
 extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orbx_extractor *R, int img_r0, int batch,
                                               const void *d_kL, const void *d_dL, const void *d_nL,
                                               const void *d_kR, const void *d_dR, const void *d_nR, int cap,
-                                              float bf, float min_z, void *d_u_right, void *d_depth, void *stream)
+                                              float bf, float min_z, void *d_u_right, void *d_depth, int row_table, void *stream)
 {
+    if (row_table != ORBX_ROWTAB_FROM_KEYPOINTS && row_table != ORBX_ROWTAB_OF_EXTRACTION) { orbx_set_error("row_table: unknown source %d", row_table); return ORBX_E_INVALID; }
     if (!L || !R || !d_kL || !d_dL || !d_nL || !d_kR || !d_dR || !d_nR || !d_u_right || !d_depth || batch < 1 || cap < 1 ||
         img_l0 < 0 || img_r0 < 0 || img_l0 + batch > L->last_batch || img_r0 + batch > R->last_batch || !(min_z > 0)) {
         orbx_set_error("orbx_stereo_match_batch_device: invalid argument");
@@ -417,9 +425,13 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
     const int reach = (int)ceilf(2.0f * L->sf[L->nlevels - 1]) + 1;   // centre rows whose band can hold a given row: |c - row| <= ceil(r) + 1
     void *d_row_off, *d_entries;
     int row_ent_cap = ent_cap;
-    // the right extractor's last launch wrote exactly these keypoints: its by-product row table serves (desc_rowtab)
-    const bool by_product = R->d_rt_off && R->rt_kps && cap == R->rt_cap && img_r0 + batch <= R->rt_batch &&
-                            (const char *)d_kR == (const char *)R->rt_kps + (size_t)img_r0 * cap * sizeof(orbx_keypoint);
+    // the caller states that the right extractor's last launch wrote exactly these keypoints: its by-product row table serves (desc_rowtab).
+    // The source is an argument, never inferred from addresses; the address check below only refuses an impossible claim.
+    const bool by_product = row_table == ORBX_ROWTAB_OF_EXTRACTION;
+    if (by_product && !orbx_stereo_row_table_available(R, d_kR, img_r0, batch, cap)) {
+        orbx_set_error("ORBX_ROWTAB_OF_EXTRACTION: the right handle's last extraction left no row table for this keypoint buffer / capacity / image range");
+        return ORBX_E_INVALID;
+    }
     if (by_product) {
         d_row_off = R->d_rt_off + (size_t)img_r0 * (rows + 1);
         d_entries = R->d_rt_entries + (size_t)img_r0 * R->rt_ent_cap * sizeof(uint4);
@@ -453,16 +465,15 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
     if (!by_product)
         hipLaunchKernelGGL(k_stereo_prep, dim3(batch), dim3(256), (size_t)2 * ((rows + 4) & ~3) * sizeof(int), s, L->d_geom,
                            (const orbx_keypoint *)d_kR, (const int *)d_nR, cap, tabs, (int *)d_row_off, (uint4 *)d_entries, ent_cap);
-    const char *kpw_env = getenv("ORBX_STEREO_KPW");                     // tests: both forms on the same input
-    const int kpw_forced = kpw_env && (*kpw_env == '1' || *kpw_env == '4') ? *kpw_env - '0' : 0;
+    const int kpw_forced = L->stereo_kpw_forced;                          // tests: both forms on the same input (ORBX_STEREO_KPW, read when the handle is created)
     const int kpw = kpw_forced ? kpw_forced : (long long)batch * cap <= 2560 ? 1 : 4;    // a frame or two: one keypoint per wave (see k_stereo; 4 frames 111 vs 115 us, 8 frames 139 vs 154 with four)
     const bool fold = kpw == 1;
     hipLaunchKernelGGL((fold ? k_stereo<true> : k_stereo<false>), dim3((cap + 4 * kpw - 1) / (4 * kpw), batch), dim3(256), 0, s, L->d_geom, pl, pr, img_l0, img_r0,
                        (const orbx_keypoint *)d_kL, (const uint32_t *)d_dL, (const int *)d_nL,
                        (const orbx_keypoint *)d_kR, (const uint32_t *)d_dR, (const int *)d_nR, cap, bf, max_d, tabs,
-                       (float *)d_u_right, (float *)d_depth, L->d_st_dist, (const int *)d_row_off, (const uint4 *)d_entries, row_ent_cap, reach,
+                       Published<float>((float *)d_u_right), Published<float>((float *)d_depth), Published<int>(L->d_st_dist), (const int *)d_row_off, (const uint4 *)d_entries, row_ent_cap, reach,
                        L->d_st_arrive, kpw);
-    if (!fold) hipLaunchKernelGGL(k_stereo_cut, dim3(batch), dim3(256), 0, s, (const int *)d_nL, cap, (float *)d_u_right, (float *)d_depth, L->d_st_dist);
+    if (!fold) hipLaunchKernelGGL(k_stereo_cut, dim3(batch), dim3(256), 0, s, (const int *)d_nL, cap, Published<float>((float *)d_u_right), Published<float>((float *)d_depth), Published<int>(L->d_st_dist));
     orbx_prof_end(L, s);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
@@ -503,7 +514,7 @@ extern "C" int orbx_stereo_match(orbx_extractor *L, orbx_extractor *R,
     }
     ORBX_HIP(hipMemcpyAsync(bn, counts, sizeof counts, hipMemcpyHostToDevice, s));
     L->prof_chain = false;
-    rc = orbx_stereo_match_batch_device(L, 0, R, 0, 1, bkL, bdL, bn, bkR, bdR, (int *)bn + 1, cap, bf, min_z, bu, bz, s);
+    rc = orbx_stereo_match_batch_device(L, 0, R, 0, 1, bkL, bdL, bn, bkR, bdR, (int *)bn + 1, cap, bf, min_z, bu, bz, ORBX_ROWTAB_FROM_KEYPOINTS, s);
     if (rc) return rc;
     ORBX_HIP(hipMemcpyAsync(u_right, bu, 4 * (size_t)nL, hipMemcpyDeviceToHost, s));
     ORBX_HIP(hipMemcpyAsync(depth, bz, 4 * (size_t)nL, hipMemcpyDeviceToHost, s));

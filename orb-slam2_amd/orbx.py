@@ -57,6 +57,7 @@ def lib():
     ip, fp = C.POINTER(C.c_int), C.POINTER(C.c_float)
     L.orbx_last_error.restype = C.c_char_p
     L.orbx_device_count.restype = i
+    L.orbx_device_identity.argtypes = [i, C.c_char_p, i]
     L.orbx_extractor_create.argtypes = [C.POINTER(vp), i, f, i, i, i, i, i, i, i]
     L.orbx_extractor_set_cv_profile.argtypes = [vp, i]
     L.orbx_extractor_set_pyramid_group_limit.argtypes = [vp, i]
@@ -83,7 +84,8 @@ def lib():
     L.orbx_sync.argtypes = [vp, vp]
     L.orbx_pyramid_level.argtypes = [vp, i, i, vp, sz, ip, ip]
     L.orbx_stereo_match.argtypes = [vp, vp, vp, vp, i, vp, vp, i, f, f, vp, vp]
-    L.orbx_stereo_match_batch_device.argtypes = [vp, i, vp, i, i, vp, vp, vp, vp, vp, vp, i, f, f, vp, vp, vp]
+    L.orbx_stereo_match_batch_device.argtypes = [vp, i, vp, i, i, vp, vp, vp, vp, vp, vp, i, f, f, vp, vp, i, vp]
+    L.orbx_stereo_row_table_available.argtypes = [vp, vp, i, i, i]
     L.orbx_hamming.argtypes = [vp, vp]
     FS = C.POINTER(FeatSet)
     L.orbx_search_by_bow_kf_f.argtypes = [i, FS, FS, f, i, vp, ip]
@@ -140,6 +142,13 @@ def lib():
     return L
 
 
+def device_identity(device):
+    """"<pci bus id> <uuid hex> <gcn arch>" of a visible device (orbx_device_identity)"""
+    buf = C.create_string_buffer(160)
+    _check(lib().orbx_device_identity(int(device), buf, len(buf)))
+    return buf.value.decode(errors="replace")
+
+
 def pipeline_depth():
     return lib().orbx_pipeline_depth()
 
@@ -164,7 +173,8 @@ def pinned_array(shape, dtype=np.uint8):
     return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
-CV_PROFILE_3_2, CV_PROFILE_3_4_2 = 0, 1
+CV_TAPS_257, CV_TAPS_256 = 0, 1                 # named by what they are: the 7 taps sum to 257 (cvRound(k * 256)) or to 256 (error-diffused)
+CV_PROFILE_3_2, CV_PROFILE_3_4_2 = 0, 1         # older names; which OpenCV release has which table is parity unpinned (include/orbx.h)
 
 
 def gaussian_taps(profile):
@@ -425,9 +435,19 @@ def ComputeStereoMatches(extractorLeft, extractorRight, mvKeys, mDescriptors, mv
     return ur, dp
 
 
-def stereo_match_batch_device(L, imgL0, R, imgR0, batch, d_kL, d_dL, d_nL, d_kR, d_dR, d_nR, cap, bf, min_z, d_ur, d_depth, stream=None):
+ROWTAB_FROM_KEYPOINTS, ROWTAB_OF_EXTRACTION = 0, 1
+
+
+def stereo_match_batch_device(L, imgL0, R, imgR0, batch, d_kL, d_dL, d_nL, d_kR, d_dR, d_nR, cap, bf, min_z, d_ur, d_depth, stream=None,
+                              row_table=ROWTAB_FROM_KEYPOINTS):
+    """row_table: ROWTAB_FROM_KEYPOINTS (always correct: the table is built from d_kR) or ROWTAB_OF_EXTRACTION (the caller asserts that
+    d_kR still holds what R's last extract_batch_device wrote: that launch's by-product table is used; refused if it cannot be)"""
     _check(lib().orbx_stereo_match_batch_device(L._h, imgL0, R._h, imgR0, batch, d_kL, d_dL, d_nL, d_kR, d_dR, d_nR, cap,
-                                                bf, min_z, d_ur, d_depth, stream))
+                                                bf, min_z, d_ur, d_depth, row_table, stream))
+
+
+def stereo_row_table_available(R, d_kR, imgR0, batch, cap):
+    return bool(lib().orbx_stereo_row_table_available(R._h, d_kR, imgR0, batch, cap))
 
 
 class ORBVocabulary:
@@ -482,10 +502,22 @@ class DeviceKeyFrame:
         self._h, self.n, self.device = h, s.n, device
 
     def __del__(self):
-        h = getattr(self, "_h", None)
-        if h and _lib is not None:
-            _lib.orbx_kf_destroy(h)
+        # at interpreter shutdown the module globals (and ctypes itself) may already be torn down: never raise from a finaliser
+        try:
+            h, L = getattr(self, "_h", None), _lib
+            if h and L is not None:
+                L.orbx_kf_destroy(h)
             self._h = None
+        except Exception:
+            pass
+
+
+def _flags_for(flag, kf, who):
+    """per-feature flag array of a resident keyframe: one byte per feature of THAT keyframe (the library reads kf.n bytes)"""
+    fl = np.ascontiguousarray(flag, np.uint8)
+    if fl.ndim != 1 or len(fl) != kf.n:
+        raise OrbxError(-1, f"{who}: flag array has {fl.size} entries, the keyframe has {kf.n} features")
+    return fl
 
 
 class BowDatabase:
@@ -607,14 +639,16 @@ class ORBmatcher:
     # ---- the same searches on resident keyframes (DeviceKeyFrame): flags travel per call
     def SearchByBoWResident(self, kf, kf_flag, frame):
         """SearchByBoW(pKF, F) with both sides resident -> (match_f, nmatches)"""
-        fl = np.ascontiguousarray(kf_flag, np.uint8)
+        fl = _flags_for(kf_flag, kf, "SearchByBoWResident")
         out = np.full(frame.n, -1, np.int32); n = C.c_int()
         _check(lib().orbx_kf_search_by_bow_kf_f(kf._h, _p(fl), frame._h, self.mfNNratio, int(self.mbCheckOrientation), _p(out), C.byref(n)))
         return out, n.value
 
     def SearchByBoWKeyFramesResident(self, kf1, flag1, kfs2, flags2):
-        f1 = np.ascontiguousarray(flag1, np.uint8)
-        f2 = [np.ascontiguousarray(x, np.uint8) for x in flags2]
+        f1 = _flags_for(flag1, kf1, "SearchByBoWKeyFramesResident")
+        if len(flags2) != len(kfs2):
+            raise OrbxError(-1, "SearchByBoWKeyFramesResident: one flag array per second keyframe")
+        f2 = [_flags_for(x, k, "SearchByBoWKeyFramesResident") for x, k in zip(flags2, kfs2)]
         hs = (C.c_void_p * len(kfs2))(*[k._h for k in kfs2])
         fp = (C.c_void_p * len(kfs2))(*[x.ctypes.data for x in f2])
         out = np.full((len(kfs2), kf1.n), -1, np.int32); n = np.zeros(len(kfs2), np.int32)
@@ -622,8 +656,10 @@ class ORBmatcher:
         return out, n
 
     def SearchForTriangulationResident(self, kf1, flag1, kfs2, flags2, F12s, epipoles, scaleFactors2, levelSigma2_2, bOnlyStereo=False):
-        f1 = np.ascontiguousarray(flag1, np.uint8) if flag1 is not None else None
-        f2 = [np.ascontiguousarray(x, np.uint8) for x in flags2] if flags2 is not None else None
+        f1 = _flags_for(flag1, kf1, "SearchForTriangulationResident") if flag1 is not None else None
+        if flags2 is not None and len(flags2) != len(kfs2):
+            raise OrbxError(-1, "SearchForTriangulationResident: one flag array per second keyframe")
+        f2 = [_flags_for(x, k, "SearchForTriangulationResident") for x, k in zip(flags2, kfs2)] if flags2 is not None else None
         hs = (C.c_void_p * len(kfs2))(*[k._h for k in kfs2])
         fp = (C.c_void_p * len(kfs2))(*[x.ctypes.data for x in f2]) if f2 is not None else None
         F = np.ascontiguousarray(np.asarray(F12s, np.float32).reshape(len(kfs2), 9))

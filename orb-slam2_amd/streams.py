@@ -33,8 +33,9 @@ def init(backend, rank=None, world=None, device_id=None):
     return rank, world
 
 
-def timed_steps(step, steps, local_sync, world, device=None):
-    """barrier + local sync, run `steps` steps, local sync + barrier; returns MAX-over-ranks seconds"""
+def timed_steps(step, steps, local_sync, world, device=None, detail=None):
+    """barrier + local sync, run `steps` steps, local sync + barrier; returns MAX-over-ranks seconds.
+    `detail` (a dict) additionally receives this rank's own seconds under "own" and, for world > 1, every rank's under "per_rank"."""
     import torch
     import torch.distributed as dist
 
@@ -48,13 +49,54 @@ def timed_steps(step, steps, local_sync, world, device=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    local_sync()
+    own = time.perf_counter() - t0          # this rank's own work, before it waits for the others: a straggler shows in the per-rank list
     fence()
     elapsed = time.perf_counter() - t0
+    if detail is not None:
+        detail["own"] = own
+        detail["per_rank"] = gather_floats(own, world, device)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
+
+
+def gather_floats(x, world, device=None):
+    """every rank's value of `x`, in rank order, on every rank (all-gather of one float64)"""
+    if world <= 1:
+        return [float(x)]
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([x], dtype=torch.float64, device=device if device is not None else "cpu")
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
+def ranks_seen(world, device=None):
+    """SUM-all-reduce of a one per rank: equals `world` exactly when every rank of the launch reached this point"""
+    if world <= 1:
+        return 1
+    import torch
+    import torch.distributed as dist
+    t = torch.ones(1, dtype=torch.int32, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def gather_strings(s, world, device=None, width=160):
+    """every rank's string, in rank order (all-gather of fixed-width byte rows): the per-rank device identities of an N-GPU line"""
+    if world <= 1:
+        return [s]
+    import torch
+    import torch.distributed as dist
+    raw = s.encode()[:width].ljust(width, b"\0")
+    mine = torch.tensor(list(raw), dtype=torch.uint8, device=device if device is not None else "cpu")
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [bytes(t.cpu().tolist()).rstrip(b"\0").decode(errors="replace") for t in out]
 
 
 def aggregate_rate(units_per_rank_per_step, steps, world, elapsed_max):

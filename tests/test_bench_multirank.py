@@ -33,3 +33,69 @@ def test_bench_two_ranks_one_gpu():
     assert k2["value"] > 0 and k2["keypoints_per_image"] > 1900
     assert d["cpu_baseline"] is None and "host_fed" not in d["config"]      # rank-0, N = 1 legs only
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    _check_rank_evidence(d, 2)
+
+
+def _check_rank_evidence(d, n):
+    """what makes an N-rank line self-evidencing: the ranks that met, the card each held, each rank's own rate,
+    and both north-star shapes (1241x376 and 640x480) as barrier-aligned whole-job legs"""
+    c = d["config"]
+    assert c["ranks_seen"] == n and len(c["rank_devices"]) == n and len(c["per_rank_frames_per_s"]) == n
+    assert all(len(x.split()) >= 3 for x in c["rank_devices"])            # "<pci bus id> <uuid> <arch>"
+    assert all(x.split()[-1].startswith("gfx950") for x in c["rank_devices"])
+    assert min(c["per_rank_frames_per_s"]) * n >= d["value"] * 0.999          # value = n * B * K / (slowest rank's time + the closing barrier)
+    t = c["tum640_frames_per_s"]
+    assert t["value"] > 0 and len(t["per_rank_frames_per_s"]) == n and 900 < t["keypoints_per_image"] < 1100
+    assert t["verified"]["bit_exact"] is True
+    assert c["kitti2000_frames_per_s"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher on the command line and WORLD_SIZE unset: the parent starts the two ranks as child
+    processes (before any GPU call of its own), relays rank 0's one JSON line and the exit code"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ORBX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "8", "--distinct", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["config"]["backend"] == "gloo"
+    assert d["verified"]["bit_exact"] is True
+    _check_rank_evidence(d, 2)
+
+
+def test_parent_never_touches_the_gpu(tmp_path):
+    """CPU: with a stand-in `torch.distributed.run` first on PYTHONPATH (it shadows torch altogether: an `import torch` + any
+    torch.cuda call in the parent would raise), `bench.py --gpus 3` must spawn it with the same arguments, relay its one JSON line
+    and its exit code, and exit -- without importing torch or loading liborbx.so itself"""
+    pk = tmp_path / "torch" / "distributed"
+    pk.mkdir(parents=True)
+    (tmp_path / "torch" / "__init__.py").write_text("")
+    (pk / "__init__.py").write_text("")
+    (pk / "run.py").write_text(
+        "import json, os, sys\n"
+        "a = sys.argv[1:]\n"
+        "assert '--nproc-per-node' in a and a[a.index('--nproc-per-node') + 1] == '3', a\n"
+        "assert a[a.index('--master-addr') + 1] == '127.0.0.1'\n"
+        "i = [k for k, x in enumerate(a) if x.endswith('bench.py')][0]\n"
+        "print('rank chatter')\n"
+        "print(json.dumps({'launcher_args': a[:i], 'bench_args': a[i + 1:], 'ipc': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}))\n"
+        "sys.exit(int(os.environ.get('FAKE_RC', '0')))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PYTHONPATH"] = str(tmp_path) + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1", "--batch", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and "rank chatter" in out.stdout
+    d = json.loads(lines[0])
+    assert d["bench_args"] == ["--gpus", "3", "--steps", "2", "--warmup", "1", "--batch", "4"] and d["ipc"] == "0"
+    # the launcher's failure is the parent's failure
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=dict(env, FAKE_RC="7"), cwd=str(tmp_path))
+    assert out.returncode == 7
+    # under a launcher (WORLD_SIZE set) the same command does NOT spawn: it goes on to import torch (the empty stand-in here) and fails there
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="3", RANK="0"), cwd=str(tmp_path))
+    assert out.returncode != 0 and "launcher_args" not in out.stdout

@@ -360,8 +360,10 @@ def test_stereo_launch_forms(pkg, oracle, monkeypatch, kpw, rowtab):
 
 
 def test_stereo_row_table_sources_device(pkg, oracle):
-    """orbx_stereo_match_batch_device takes the row table the right image's extraction left behind only when it is handed that very
-    keypoint buffer; a copy at another address -- also one the caller has edited -- gets a table built from what it holds"""
+    """where orbx_stereo_match_batch_device takes its row table from is an ARGUMENT (never inferred from addresses): ROWTAB_OF_EXTRACTION
+    = the by-product of the right image's extraction (refused when the buffer / capacity / image range cannot be that extraction's),
+    ROWTAB_FROM_KEYPOINTS = built from whatever keypoints are handed in -- also the extraction's own buffer EDITED IN PLACE, the case
+    the pointer-identity rule of round 3 got silently wrong"""
     import torch
     w, h, nf = 1241, 376, 1000
     bf, b = 386.1448, 386.1448 / 718.856
@@ -377,25 +379,36 @@ def test_stereo_row_table_sources_device(pkg, oracle):
     ex.extract_batch_device(imgs.data_ptr(), h * pitch, pitch, 2, w, h, kps.data_ptr(), desc.data_ptr(), cap, n.data_ptr(), None)
     oL, oR = oracle.Oracle(nf, 1.2, 8, 20, 7), oracle.Oracle(nf, 1.2, 8, 20, 7)
     okL, odL = oL.extract(left); okR, odR = oR.extract(right)
+    X, K = pkg.orbx.ROWTAB_OF_EXTRACTION, pkg.orbx.ROWTAB_FROM_KEYPOINTS
 
-    def run(kr_ptr):
+    def run(kr_ptr, src):
         pkg.orbx.stereo_match_batch_device(ex, 0, ex, 1, 1, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), kr_ptr, desc[1:].data_ptr(), n[1:].data_ptr(),
-                                           cap, bf, b, ur.data_ptr(), dp.data_ptr(), None)
+                                           cap, bf, b, ur.data_ptr(), dp.data_ptr(), None, row_table=src)
         ex.sync()
         nl = int(n[0].item())
         return ur.cpu().numpy()[:nl].copy(), dp.cpu().numpy()[:nl].copy()
     our, odp = oracle.stereo_match(oL, oR, okL, odL, okR, odR, bf, b)
-    g_ur, g_dp = run(kps[1:].data_ptr())                        # the extraction's own buffer: by-product table
-    assert g_ur.tobytes() == our.tobytes() and g_dp.tobytes() == odp.tobytes() and (our >= 0).sum() > 50
+    assert pkg.orbx.stereo_row_table_available(ex, kps[1:].data_ptr(), 1, 1, cap)
+    for src in (X, K):                                           # the extraction's own buffer: by-product table, or one built from it
+        g_ur, g_dp = run(kps[1:].data_ptr(), src)
+        assert g_ur.tobytes() == our.tobytes() and g_dp.tobytes() == odp.tobytes() and (our >= 0).sum() > 50
     clone = kps[1:].clone()                                      # the same keypoints at another address: k_stereo_prep
-    g_ur, g_dp = run(clone.data_ptr())
+    g_ur, g_dp = run(clone.data_ptr(), K)
     assert g_ur.tobytes() == our.tobytes() and g_dp.tobytes() == odp.tobytes()
+    assert not pkg.orbx.stereo_row_table_available(ex, clone.data_ptr(), 1, 1, cap)
+    with pytest.raises(pkg.OrbxError):                           # a buffer that cannot be the extraction's: the claim is refused, not believed
+        run(clone.data_ptr(), X)
+    with pytest.raises(pkg.OrbxError):
+        run(kps[1:].data_ptr(), 7)
     ed = okR.copy()                                              # an edited copy: a third of the right keypoints moved 40 rows down
     ed["y"][::3] += 40.0
-    clone2 = torch.from_numpy(np.pad(ed.view(np.uint8).reshape(len(ed), 28), ((0, cap - len(ed)), (0, 0))).copy()).cuda()
+    edited = torch.from_numpy(np.pad(ed.view(np.uint8).reshape(len(ed), 28), ((0, cap - len(ed)), (0, 0))).copy()).cuda()
     eur, edp = oracle.stereo_match(oL, oR, okL, odL, ed, odR, bf, b)
-    g_ur, g_dp = run(clone2.data_ptr())
+    g_ur, g_dp = run(edited.data_ptr(), K)
     assert g_ur.tobytes() == eur.tobytes() and g_dp.tobytes() == edp.tobytes() and eur.tobytes() != our.tobytes()
+    kps[1].view(torch.uint8).view(-1)[:edited.numel()] = edited.view(-1)     # ... and the extraction's own buffer edited IN PLACE
+    g_ur, g_dp = run(kps[1:].data_ptr(), K)
+    assert g_ur.tobytes() == eur.tobytes() and g_dp.tobytes() == edp.tobytes()
 
 
 def test_stereo_rejects_bad_octave(pkg):

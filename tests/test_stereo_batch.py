@@ -76,7 +76,7 @@ def test_stereo_match_batch_one_handle(pkg, oracle, nf, B):
         ex.extract_batch_device(imgs.data_ptr(), H * pitch, pitch, 2 * B, W, H, kps.data_ptr(), desc.data_ptr(), cap, nout.data_ptr(), sp)
         pkg.orbx.stereo_match_batch_device(ex, 0, ex, B, B, kps.data_ptr(), desc.data_ptr(), nout.data_ptr(),
                                            kps[B:].data_ptr(), desc[B:].data_ptr(), nout[B:].data_ptr(), cap,
-                                           BF, MIN_Z, ur.data_ptr(), dp.data_ptr(), sp)
+                                           BF, MIN_Z, ur.data_ptr(), dp.data_ptr(), sp, row_table=pkg.orbx.ROWTAB_OF_EXTRACTION)
         ex.sync(sp)
         n_h = nout.cpu().numpy()
         k_h = kps.cpu().numpy().view(np.uint8).reshape(2 * B, cap, 28)
@@ -117,7 +117,7 @@ def test_stereo_match_batch_two_handles_offset(pkg, oracle):
     exR.sync()
     pkg.orbx.stereo_match_batch_device(exL, 2, exR, 1, B, kl[2:].data_ptr(), dsl[2:].data_ptr(), nl[2:].data_ptr(),
                                        kr[1:].data_ptr(), dsr[1:].data_ptr(), nr[1:].data_ptr(), cap,
-                                       BF, MIN_Z, ur.data_ptr(), dp.data_ptr(), None)
+                                       BF, MIN_Z, ur.data_ptr(), dp.data_ptr(), None, row_table=pkg.orbx.ROWTAB_OF_EXTRACTION)
     exL.sync()
     nl_h, nr_h = nl.cpu().numpy(), nr.cpu().numpy()
     kl_h = kl.cpu().numpy().view(np.uint8).reshape(NL, cap, 28); kr_h = kr.cpu().numpy().view(np.uint8).reshape(NR, cap, 28)

@@ -23,7 +23,11 @@ def _worker(rank, world, port, q):
     delay = 0.02 * (rank + 1)          # rank 1 is slower: the MAX must be reported on every rank
     done = []
     elapsed = st.timed_steps(lambda: (time.sleep(delay), done.append(1)), 5, lambda: None, world)
-    q.put((rank, mine, [st.stream_seed(s) for s in mine], elapsed, len(done)))
+    det = {}
+    st.timed_steps(lambda: time.sleep(delay), 2, lambda: None, world, detail=det)
+    ev = (st.ranks_seen(world), st.gather_strings(f"0000:0{rank}:00.0 uuid{rank} gfx950", world), det["per_rank"], det["own"],
+          st.gather_floats(float(rank) + 0.5, world))
+    q.put((rank, mine, [st.stream_seed(s) for s in mine], elapsed, len(done), ev))
     import torch.distributed as dist
     dist.destroy_process_group()
 
@@ -45,6 +49,10 @@ def test_two_rank_gloo():
     seeds = [s for r in res for s in r[2]]
     assert len(set(seeds)) == 4
     assert all(r[4] == 5 for r in res)                                             # exactly K steps each
+    for r in res:       # the evidence every N-rank bench line carries: ranks that met, per-rank device strings and per-rank times, in rank order
+        seen, devs, per_rank, own, fl = r[5]
+        assert seen == 2 and devs == ["0000:00:00.0 uuid0 gfx950", "0000:01:00.0 uuid1 gfx950"] and fl == [0.5, 1.5]
+        assert len(per_rank) == 2 and per_rank[r[0]] == own and per_rank[1] > per_rank[0] >= 2 * 0.02 * 0.95
     e0, e1 = res[0][3], res[1][3]
     assert abs(e0 - e1) < 1e-9 and e0 >= 5 * 0.04 * 0.95                            # both report the slow rank's time
 

@@ -24,7 +24,7 @@ def setup(B, seed):
 def step(d):
     B=d['B']; sp=d['stream'].cuda_stream; cap=d['cap']
     d['ex'].extract_batch_device(d['imgs'].data_ptr(),H*d['pitch'],d['pitch'],2*B,W,H,d['kps'].data_ptr(),d['desc'].data_ptr(),cap,d['n'].data_ptr(),sp)
-    orbx.stereo_match_batch_device(d['ex'],0,d['ex'],B,B,d['kps'].data_ptr(),d['desc'].data_ptr(),d['n'].data_ptr(),d['kps'][B:].data_ptr(),d['desc'][B:].data_ptr(),d['n'][B:].data_ptr(),cap,BF,MINZ,d['ur'].data_ptr(),d['dp'].data_ptr(),sp)
+    orbx.stereo_match_batch_device(d['ex'],0,d['ex'],B,B,d['kps'].data_ptr(),d['desc'].data_ptr(),d['n'].data_ptr(),d['kps'][B:].data_ptr(),d['desc'][B:].data_ptr(),d['n'][B:].data_ptr(),cap,BF,MINZ,d['ur'].data_ptr(),d['dp'].data_ptr(),sp,row_table=orbx.ROWTAB_OF_EXTRACTION)
 for nstreams, B in ((1,256),(2,128),(4,64),(4,128),(8,64)):
     ds=[setup(B,1000+10*i) for i in range(nstreams)]
     for _ in range(3):

@@ -39,7 +39,9 @@ while time.time() - t0 < budget:
     n = torch.zeros(2 * B, dtype=torch.int32, device="cuda"); ur = torch.zeros((B, cap), device="cuda"); dp = torch.zeros((B, cap), device="cuda")
     ex.extract_batch_device(imgs.data_ptr(), h * pitch, pitch, 2 * B, w, h, kps.data_ptr(), desc.data_ptr(), cap, n.data_ptr(), None)
     pkg.orbx.stereo_match_batch_device(ex, 0, ex, B, B, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), kps[B:].data_ptr(), desc[B:].data_ptr(), n[B:].data_ptr(),
-                                       cap, bf, min_z, ur.data_ptr(), dp.data_ptr(), None)
+                                       cap, bf, min_z, ur.data_ptr(), dp.data_ptr(), None,
+                                       row_table=pkg.orbx.ROWTAB_OF_EXTRACTION if pkg.orbx.stereo_row_table_available(ex, kps[B:].data_ptr(), B, B, cap) and B % 2 == 0
+                                       else pkg.orbx.ROWTAB_FROM_KEYPOINTS)
     ex.sync()
     nn = n.cpu().numpy(); kk = kps.cpu().numpy().view(np.uint8).reshape(2 * B, cap, 28); dd = desc.cpu().numpy(); uu = ur.cpu().numpy(); zz = dp.cpu().numpy()
     for i in range(B):
