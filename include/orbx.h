@@ -477,6 +477,8 @@ int orbx_profile_read(orbx_extractor *e, float *ms, int *launches, int reset);
  * x,y are relative to (16,16) like the reference's vToDistributeKeys. */
 int orbx_debug_candidates(orbx_extractor *e, int image_index, int level, int32_t *x, int32_t *y, int32_t *resp, int cap, int *n);
 int orbx_debug_level_counts(orbx_extractor *e, int image_index, int32_t *counts /*[nlevels]*/);
+/* which FAST kernel the most recent extraction launched: 1 = a cell per wave (or several waves per cell), 2 = a pair of cells per wave */
+int orbx_debug_fast_form(const orbx_extractor *e);
 /* test hook: the SearchByBoW kernels exist in a latency form (one 16-wave workgroup per pair) and a throughput form
  * (LDS distance table + row fixpoint); a call picks by problem size.  form = 1 / 2 forces the wave / table form for
  * every later call of the process, 0 restores the automatic choice.  Both forms return identical matches. */

@@ -365,7 +365,7 @@ __device__ __forceinline__ int fast_score_full(const uint8_t *t, int th)
 // used to pay for.  Candidate = x | y<<12 | score<<24, (x,y) relative to (16,16).
 extern __shared__ __align__(16) unsigned char fast_smem[];
 #ifndef FAST_XG
-#define FAST_XG 4
+#define FAST_XG 2
 #endif
 // Launch constants of k_fast by value (kernel-argument segment): fetching them through the Geom pointer was one more level in
 // the chain of dependent scalar loads every wave starts with (arguments -> geometry -> cell record -> tile).
@@ -687,6 +687,295 @@ __global__ __launch_bounds__(64 * NW) void k_fast(const FastArgs fa, const CellR
             o++;
         }
         if (lane == 0) *my_cnt = min(total, rec.cand_cap);
+    }
+    STAMP(4);
+    SPAN_END(0);
+#ifdef ORBX_DIAG
+    if (lane == 0) atomicAdd(&g_fast_stamp[((blockIdx.x * 131 + blockIdx.y) & 4095) * 8 + 7], 1ull);
+#endif
+}
+
+// ---------------------------------------------------------------- K2p: FAST on PAIRS of horizontally adjacent cells (batches)
+// One wave takes two cells of a cell row, A and its right neighbour B (the last cell of a row with an odd number of columns goes
+// alone).  What one cell per wave pays per cell -- record fetch and decode, tile load and zeroing, the pretest prologue, a prefix sum
+// and a bit walk for the list, one for the emission -- is paid once per pair, the score / maximum iterations (64 candidates each)
+// run on ONE concatenated candidate list (a 31 x 32 cell lists ~127 pretest candidates: two or three iterations, the last two-thirds
+// empty; a pair lists ~254: four or five), and the 3-px halo between A and B is fetched once (72 bytes per tile row for 62 owned
+// pixels instead of 2 x 40 for 2 x 31).
+// Bit space: everything after the tile load is indexed by (row, bit), bit = tile column - 4.  The tile fetch starts xo = 1 + off bytes
+// left of cell A with off = 32 - dwA, so A's detectable pixels are bits [off, 32) and B's are bits [32, 32 + dwB): the A | B boundary
+// is a 32-bit word boundary of every bitmap row and a dword boundary of every pretest group, and "which cell" is bit 5 of a bit index.
+// (A cell that goes alone sits at bits [0, dwA).)  Per-cell semantics of src/ORBextractor.cc:953-1009 are kept exactly:
+//  * non-maximum suppression is per cell (cv::FAST sees one cell at a time: scores outside it count as 0): the score tile has a
+//    zero column between the two cells (score column = bit + 1 + (bit >> 5)), so a maximum never looks into the other cell;
+//  * the minThFAST fallback is per cell: a second pass lists only the segments of the cell(s) that kept nothing;
+//  * each cell's survivors go to its own candidate slots in its own row-major order: the emission scans a packed (A | B << 16) count.
+// Bitmap segments: 32-bit halves of a row (lane = row, half; the half is the cell) when the detect area has at most 32 rows, else
+// whole 64-bit rows (lane = row; low word = A, high word = B).
+#ifndef FAST2_P
+#define FAST2_P 72      // tile pitch: 1 + 32 - dwA + 3 + dwA + dwB + 3 <= 71 bytes
+#endif
+#ifndef FAST2_LIST_CAP
+#define FAST2_LIST_CAP 1024 // candidates listed per round: a pair lists ~350 on a textured frame, and the rounds of a fuller list walk it twice without compaction
+#endif
+#ifndef FAST2_SP
+#define FAST2_SP 68     // score pitch: rim + 32 + gap + 32 + rim = 67 bytes; 17 dwords: rows r and r + 32 share banks
+#endif
+struct PairRec {
+    short level, ncells;         // ncells: cells whose count this wave writes (1 or 2); dwa == 0: all of them skipped
+    short ini_x, ini_y;          // cell A's rectangle origin (incl. the 3-px halo), level coordinates
+    short dwa, dwb;              // detect widths of A and B (0: skipped / absent; dwb != 0 implies dwa == the level's cell width)
+    int cell;                    // index of cell A in the image's cell arrays (B = cell + 1)
+    int pitch, cand_cap;
+    unsigned gpr_magic;          // multiply-high division by gpr = pretest groups per row = (bits used + 3) >> 2
+    int th;                      // tile rows (detect rows + 6)
+    long long pyr_off, cand_slot;
+};
+static_assert(sizeof(PairRec) == 48, "PairRec layout");
+
+template <int P, int SP>
+__global__ __launch_bounds__(64) void k_fast2(const FastArgs fa, const PairRec *__restrict__ pairs, int total_pairs, PyrRef pr,
+                                              int *__restrict__ cell_cnt, uint32_t *__restrict__ cand, uint32_t *__restrict__ cand_prim)
+{
+    constexpr int DWR = P / 4;      // dwords per tile row
+    constexpr int RPL = 64 / DWR;   // whole tile rows per direct load
+#ifdef ORBX_FAST_PAD
+    asm volatile(".fill %0, 4, 0xBF800000" :: "n"(ORBX_FAST_PAD));
+#endif
+    uint8_t *tile = fast_smem;
+    uint8_t *sc = fast_smem + fa.lds_sc;
+    uint16_t *list = reinterpret_cast<uint16_t *>(fast_smem + fa.lds_list);
+    uint32_t *bm = reinterpret_cast<uint32_t *>(fast_smem + fa.lds_bm); // candidate bitmap, then survivor bitmap: u64 per row
+    uint32_t *sv = bm + 2 * fa.bm_rows;
+    const int ini_th = fa.ini_th, min_th = fa.min_th;
+    const int b = blockIdx.y, lane = threadIdx.x;
+    int pi;
+    {   // FAST_XG neighbouring pairs of a cell row on the same XCD (see k_fast)
+        const int bx = blockIdx.x, grp = bx / (8 * FAST_XG), r = bx - grp * (8 * FAST_XG);
+        pi = grp * (8 * FAST_XG) + (r & 7) * FAST_XG + (r >> 3);
+        if (pi >= total_pairs) return;
+    }
+#ifdef ORBX_DIAG
+    unsigned long long _t_prev = __builtin_amdgcn_s_memtime();
+#endif
+    SPAN_BEGIN();
+    int level, ncells, ini_x, ini_y, dwa, dwb, cell0, rpitch, cand_cap, th;
+    unsigned gpr_magic;
+    long long pyr_off, cand_slot;
+    {
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(pairs + pi);
+        uint32_t w[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) w[i] = cw[i];
+        level = (short)(w[0] & 0xFFFF); ncells = (short)(w[0] >> 16);
+        ini_x = (short)(w[1] & 0xFFFF); ini_y = (short)(w[1] >> 16);
+        dwa = (short)(w[2] & 0xFFFF); dwb = (short)(w[2] >> 16);
+        cell0 = (int)w[3]; rpitch = (int)w[4]; cand_cap = (int)w[5]; gpr_magic = w[6]; th = (int)w[7];
+        pyr_off = (long long)(((unsigned long long)w[9] << 32) | w[8]);
+        cand_slot = (long long)(((unsigned long long)w[11] << 32) | w[10]);
+    }
+    int *my_cnt = cell_cnt + (long long)b * fa.total_cells + cell0;
+    if (dwa == 0) { // src/ORBextractor.cc:961-976 skip rules, evaluated on the host (a skipped A has no B to its right that is not skipped)
+        if (lane < ncells) my_cnt[lane] = 0;
+        return;
+    }
+    const int off = dwb ? 32 - dwa : 0, xo = 1 + off;   // bit of A's first detectable pixel; bytes fetched left of cell A
+    const int nbits = off + dwa + dwb;                  // bits [off, nbits) are detectable pixels
+    const int tw = dwa + dwb + 6, dh = th - 6;
+    const int pitch = level == 0 ? pr.img0_pitch : rpitch;
+    const uint8_t *img = level == 0 ? pr.img0 + (long long)b * pr.img0_stride : pr.pyr + (long long)b * pr.pyr_stride + pyr_off;
+    // ---- 1. tile (cell A, cell B and the halo around both) -> LDS by direct loads, RPL whole rows per instruction
+    {
+        const int lr0 = lane / DWR, lc = lane - lr0 * DWR;
+        const int ndw = (tw + xo + 3) >> 2;             // dwords per row that hold tile pixels (<= 18)
+        const uint8_t *base = img + (long long)ini_y * pitch + (ini_x - xo);
+        const unsigned voff = (unsigned)(lr0 * pitch + 4 * lc);
+        const int full = th / RPL;
+        if (lc < ndw && lr0 < RPL) {
+            for (int k = 0; k < full; k++, base += (long long)RPL * pitch)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(base + voff), reinterpret_cast<uint32_t *>(tile + RPL * P * k), 4, 0, 0);
+            if (full * RPL + lr0 < th)      // the last, partial group of rows never reads below the cells
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(base + voff), reinterpret_cast<uint32_t *>(tile + RPL * P * full), 4, 0, 0);
+        }
+    }
+    {   // meanwhile: zero score tile (rim and the column between the cells included) and both bitmaps
+        uint4 *z = reinterpret_cast<uint4 *>(sc);
+        for (int i = lane; i < ((dh + 2) * SP + 15) / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
+        uint4 *zb = reinterpret_cast<uint4 *>(bm);
+        for (int i = lane; i < fa.bm_rows; i += 64) zb[i] = make_uint4(0, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    STAMP(0);
+    const uint8_t *t0 = tile + 3 * P + 4;               // detect row 0, bit 0
+    // pretest geometry: tile dwords 1 .. gpr of a row hold bits 0 .. 4 gpr - 1; one iteration = rpi whole rows
+    const int gpr = (nbits + 3) >> 2;
+    const int lq = gpr == 1 ? lane : (int)__umulhi((unsigned)lane, gpr_magic);
+    const int rpi = min(gpr == 1 ? 64 : (int)__umulhi(64u, gpr_magic), 8);
+    const int lr = min(lq, rpi), gq = lane - lq * gpr;
+    unsigned vmask = 0;
+    {   // bytes of this lane's group whose bit is a detectable pixel: bits [max(off, 4 gq), min(nbits, 4 gq + 4))
+        const int lo = min(max(off - 4 * gq, 0), 4), hi = min(max(nbits - 4 * gq, 0), 4);
+        if (lr < rpi && hi > lo) vmask = (0x80808080u >> (8 * (4 - hi))) & (0x80808080u << (8 * lo));
+    }
+    const int bm_sh = 4 * (gq & 7);
+    uint32_t *slot = cand + (long long)b * fa.cand_total + cand_slot;
+    uint32_t *prim = cand_prim + ((long long)b * fa.total_cells + cell0) * ORBX_CAND_PRIM;
+    const bool half_mode = dh <= 32;
+    const int brow = half_mode ? lane >> 1 : lane;
+    const int half = half_mode ? lane & 1 : 0;
+    const unsigned bsh = 32u * (unsigned)half;
+    int th_cur = ini_th;
+    unsigned s_lo = 0, s_hi = 0;                        // this lane's survivor bits
+    bool need_a = true, need_b = dwb != 0;              // cells listed by the current pass
+    for (int pass = 0; pass < 2; pass++) {
+        // ---- 2. SWAR pretest (see k_fast): both cells, 4 adjacent bits per lane
+        {
+            const unsigned s7 = (unsigned)((th_cur + 1) >> 1) * 0x01010101u;
+            const uint8_t *pc = tile + (lr + 3) * P + 4 * (1 + gq);
+            uint32_t *pb = bm + lr * 2 + (gq >> 3);
+            for (int r0 = 0; r0 < dh; r0 += rpi, pc += rpi * P, pb += rpi * 2) {
+                const uint32_t *rc = reinterpret_cast<const uint32_t *>(pc);
+                const unsigned C = rc[0], Wd = rc[-1], Ed = rc[1], N = rc[3 * DWR], S = rc[-3 * DWR];
+                const unsigned Wv = __builtin_amdgcn_alignbyte(C, Wd, 1), Ev = __builtin_amdgcn_alignbyte(Ed, C, 3);
+                const unsigned c7 = (C >> 1) & 0x7f7f7f7fu, n7 = (N >> 1) & 0x7f7f7f7fu, u7 = (S >> 1) & 0x7f7f7f7fu,
+                               e7 = (Ev >> 1) & 0x7f7f7f7fu, w7 = (Wv >> 1) & 0x7f7f7f7fu;
+                const unsigned R = (c7 | 0x80808080u) - s7, RD = R | 0x80808080u;
+                const unsigned RB = ((c7 ^ 0x7f7f7f7fu) | 0x80808080u) - s7, KB = (RB | 0x80808080u) - 0x7f7f7f7fu;
+                const unsigned dark = ((RD - n7) | (RD - u7)) & ((RD - e7) | (RD - w7)) & R;
+                const unsigned bright = ((KB + n7) | (KB + u7)) & ((KB + e7) | (KB + w7)) & RB;
+                const unsigned any = (dark | bright) & vmask;
+                const unsigned nib = (((any >> 7) * 0x01020408u) >> 24) << bm_sh;
+                if (nib) atomicOr(pb, nib);   // rows >= dh of the last iteration land in bitmap rows that are never read
+            }
+        }
+        __syncthreads();
+        STAMP(1);
+        // ---- 3. bitmap -> ordered list of (row << 6 | bit): lane = segment; only the cells this pass is for
+        unsigned c_lo = 0, c_hi = 0;
+        if (brow < dh) {
+            const uint2 m = *reinterpret_cast<const uint2 *>(bm + 2 * brow);
+            if (half_mode) c_lo = half ? (need_b ? m.y : 0u) : (need_a ? m.x : 0u);
+            else { c_lo = need_a ? m.x : 0u; c_hi = need_b ? m.y : 0u; }
+        }
+        const int c_cnt = __popc(c_lo) + __popc(c_hi);
+        const int c_incl = wave_incl_scan(c_cnt);
+        const int nlist = __builtin_amdgcn_readlane(c_incl, 63);
+        const unsigned rowbits = ((unsigned)brow << 6) | bsh;
+        // ---- 4. full score of the listed pixels; corners packed to the front of the list in place (order kept)
+        auto score_entries = [&](int n, bool compact) -> int {
+            int n2 = 0;
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
+                int e = 0, s = 0;
+                if (i < n) {
+                    e = list[i];
+                    const int py = e >> 6, bx = e & 63;
+                    s = fast_score_full<P>(t0 + py * P + bx, th_cur);
+                    sc[(py + 1) * SP + bx + 1 + (bx >> 5)] = (uint8_t)s;
+                }
+                if (compact) {
+                    const unsigned long long m = __ballot(s > 0);
+                    if (s > 0) list[n2 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (uint16_t)e;
+                    n2 += __popcll(m);
+                }
+            }
+            return compact ? n2 : n;
+        };
+        // ---- 5. strict 3x3 maximum inside the pixel's own cell -> survivor bitmap
+        auto mark_maxima = [&](int n) {
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
+                if (i < n) {
+                    const int e = list[i], py = e >> 6, bx = e & 63;
+                    const uint8_t *c = sc + (py + 1) * SP + bx + 1 + (bx >> 5);
+                    const int s = c[0];
+                    const int nb = max(max(max((int)c[-1], (int)c[1]), max((int)c[-SP - 1], (int)c[-SP])),
+                                       max(max((int)c[-SP + 1], (int)c[SP - 1]), max((int)c[SP], (int)c[SP + 1])));
+                    if (s > nb) atomicOr(sv + 2 * py + (bx >> 5), 1u << (bx & 31));
+                }
+            }
+        };
+        constexpr int list_cap = FAST2_LIST_CAP;
+        if (nlist <= list_cap) {
+            unsigned lo = c_lo, hi = c_hi;
+            uint16_t *lp = list + (c_incl - c_cnt);
+            while (lo) { *lp++ = (uint16_t)(rowbits | (unsigned)__builtin_ctz(lo)); lo &= lo - 1; }
+            while (hi) { *lp++ = (uint16_t)(rowbits | 32u | (unsigned)__builtin_ctz(hi)); hi &= hi - 1; }
+            __syncthreads();
+            STAMP(5);
+            const int ncorner = score_entries(nlist, true);
+            STAMP(6);
+            __syncthreads();
+            STAMP(2);
+            mark_maxima(ncorner);
+            __syncthreads();
+        } else {
+            auto list_round = [&](int base) {   // the candidates of rank base .. base + CAP - 1
+                unsigned lo = c_lo, hi = c_hi;
+                int r = c_incl - c_cnt - base;
+                while (lo) { if ((unsigned)r < (unsigned)list_cap) list[r] = (uint16_t)(rowbits | (unsigned)__builtin_ctz(lo)); r++; lo &= lo - 1; }
+                while (hi) { if ((unsigned)r < (unsigned)list_cap) list[r] = (uint16_t)(rowbits | 32u | (unsigned)__builtin_ctz(hi)); r++; hi &= hi - 1; }
+            };
+            for (int base = 0; base < nlist; base += list_cap) {
+                list_round(base);
+                __syncthreads();
+                score_entries(min(list_cap, nlist - base), false);
+                __syncthreads();
+            }
+            STAMP(2);
+            for (int base = 0; base < nlist; base += list_cap) {
+                list_round(base);
+                __syncthreads();
+                mark_maxima(min(list_cap, nlist - base));
+                __syncthreads();
+            }
+        }
+        STAMP(3);
+        s_lo = 0; s_hi = 0;
+        if (brow < dh) { const uint2 m = *reinterpret_cast<const uint2 *>(sv + 2 * brow); s_lo = half_mode ? (half ? m.y : m.x) : m.x; s_hi = half_mode ? 0u : m.y; }
+        // a cell falls back to minThFAST only if iniThFAST kept nothing IN THAT CELL (:991-995); the second pass lists only such cells.
+        // Pretest bits, scores and survivors of the second pass are supersets of the first: nothing has to be cleared
+        if (th_cur == min_th) break;
+        const bool any_a = __any(half_mode ? (half == 0 && s_lo != 0) : s_lo != 0);
+        const bool any_b = __any(half_mode ? (half == 1 && s_lo != 0) : s_hi != 0);
+        need_a = !any_a; need_b = dwb != 0 && !any_b;
+        if (!(need_a || need_b)) break;
+        th_cur = min_th;
+    }
+    // ---- ordered (row-major per cell) emission into each cell's candidate slots: lane = bitmap segment
+    {
+        const int n_lo = __popc(s_lo), n_hi = __popc(s_hi);
+        const int v = half_mode ? n_lo << (16 * half) : n_lo | (n_hi << 16);
+        const int incl = wave_incl_scan(v);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        const int excl = incl - v;
+        const int Y = ini_y + 3 + brow - ORBX_MIN_BORDER, X0 = ini_x + 3 - ORBX_MIN_BORDER - off;     // x of bit 0
+        const uint8_t *srow = sc + (brow + 1) * SP + 1;
+        {   // low word: cell A (whole-row segments) or this lane's cell (half-row segments)
+            int o = half_mode ? (excl >> (16 * half)) & 0xFFFF : excl & 0xFFFF;
+            uint32_t *pm = prim + (half ? ORBX_CAND_PRIM : 0), *sl = slot + (half ? cand_cap : 0);
+            unsigned lo = s_lo;
+            while (lo) {
+                const int bx = (int)bsh + __builtin_ctz(lo);
+                lo &= lo - 1;
+                if (o < cand_cap) (o < ORBX_CAND_PRIM ? pm : sl)[o] = (uint32_t)(X0 + bx) | ((uint32_t)Y << 12) | ((uint32_t)srow[bx + (bx >> 5)] << 24);
+                o++;
+            }
+        }
+        if (!half_mode) {   // high word: cell B
+            int o = excl >> 16;
+            uint32_t *pm = prim + ORBX_CAND_PRIM, *sl = slot + cand_cap;
+            unsigned hi = s_hi;
+            while (hi) {
+                const int bx = 32 + __builtin_ctz(hi);
+                hi &= hi - 1;
+                if (o < cand_cap) (o < ORBX_CAND_PRIM ? pm : sl)[o] = (uint32_t)(X0 + bx) | ((uint32_t)Y << 12) | ((uint32_t)srow[bx + 1] << 24);
+                o++;
+            }
+        }
+        if (lane == 0) my_cnt[0] = min(total & 0xFFFF, cand_cap);
+        if (lane == 1 && ncells == 2) my_cnt[1] = min(total >> 16, cand_cap);
     }
     STAMP(4);
     SPAN_END(0);
@@ -2033,6 +2322,65 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
             c.cand_slot = L.cand_off + (long long)ci * L.cand_cap;
         }
     }
+    // k_fast2: pairs of horizontally adjacent cells (batches).  Usable when every cell's detect area fits 32 bits x 64 rows.
+    std::vector<PairRec> pairs;
+    {
+        bool ok = true;
+        for (int l = 0; l < e->nlevels; l++) if (G.lv[l].w_cell > 32 || G.lv[l].h_cell > 56) ok = false;
+        G.fast2_ok = ok ? 1 : 0;
+        G.total_pairs = 0;
+        if (ok) {
+            // two groups of levels, each a launch with its own LDS carve: detect areas of at most 32 rows (the 30-px grid's usual cells), then the
+            // taller ones (a level whose cell rows do not divide evenly: up to 40 rows at 1241x376) -- sized together, the tall tiles cost every
+            // wave of the launch a sixth of its occupancy
+            for (int grp = 0; grp < 2; grp++) {
+                int max_th = 0, max_dh = 0;
+                G.fast2_first[grp] = (int)pairs.size();
+                for (int l = 0; l < e->nlevels; l++) {
+                    const LevelGeom &L = G.lv[l];
+                    if ((L.h_cell <= 32 ? 0 : 1) != grp) continue;
+                    max_th = std::max(max_th, L.h_cell + 6); max_dh = std::max(max_dh, L.h_cell);
+                    for (int row = 0; row < L.n_rows; row++)
+                        for (int col = 0; col < L.n_cols; col += 2) {
+                            const CellRec &a = cells[L.cell_base + row * L.n_cols + col];
+                            const bool has_b = col + 1 < L.n_cols;
+                            PairRec q;
+                            memset(&q, 0, sizeof q);
+                            q.level = (short)l; q.ncells = has_b ? 2 : 1;
+                            q.ini_x = a.ini_x; q.ini_y = a.ini_y; q.th = a.th;
+                            q.dwa = a.skip ? 0 : (short)(a.tw - 6);
+                            q.dwb = 0;
+                            if (has_b && !a.skip) {
+                                const CellRec &bc = cells[L.cell_base + row * L.n_cols + col + 1];
+                                if (!bc.skip) {
+                                    q.dwb = (short)(bc.tw - 6);
+                                    // B starts one cell width right of A, on the same rows: the pair's tile is one rectangle
+                                    if (bc.ini_x != a.ini_x + L.w_cell || bc.ini_y != a.ini_y || bc.th != a.th || a.tw != L.w_cell + 6) ok = false;
+                                }
+                            }
+                            if (q.dwa > 32 || q.dwb > 32 || q.dwa < 0 || q.dwb < 0 || (q.dwb && q.dwa != L.w_cell)) ok = false;
+                            const int off = q.dwb ? 32 - q.dwa : 0;
+                            if (a.ini_x - (1 + off) < 0) ok = false;                   // the fetch starts 1 + off bytes left of cell A
+                            const int nbits = off + q.dwa + q.dwb, gpr = (nbits + 3) >> 2;
+                            q.gpr_magic = gpr > 0 ? 0xFFFFFFFFu / (unsigned)gpr + 1u : 0u;
+                            q.cell = L.cell_base + row * L.n_cols + col;
+                            q.pitch = L.pitch; q.cand_cap = L.cand_cap; q.pyr_off = L.pyr_off; q.cand_slot = a.cand_slot;
+                            pairs.push_back(q);
+                        }
+                }
+                G.fast2_count[grp] = (int)pairs.size() - G.fast2_first[grp];
+                // LDS carve (pitches FAST2_P / FAST2_SP): tile | score tile | candidate list | candidate + survivor bitmaps; the pretest's
+                // overrun rows alias what follows the tile (see k_fast)
+                G.fast2_lds_sc[grp] = (int)align_up((size_t)max_th * FAST2_P + 8, 16);
+                G.fast2_lds_list[grp] = G.fast2_lds_sc[grp] + (int)align_up((size_t)(max_dh + 2) * FAST2_SP, 16);
+                G.fast2_lds_bm[grp] = G.fast2_lds_list[grp] + (int)align_up((size_t)FAST2_LIST_CAP * 2 + 16, 16);
+                G.fast2_bm_rows[grp] = (max_dh + 9 + 1) & ~1;
+                G.fast2_lds_bytes[grp] = G.fast2_lds_bm[grp] + 2 * G.fast2_bm_rows[grp] * 8;
+            }
+            if (!ok) { G.fast2_ok = 0; pairs.clear(); }
+            G.total_pairs = (int)pairs.size();
+        }
+    }
     if (tree_launch_lds(G) > kTreeLdsLimit) {
         orbx_set_error("internal: %d FAST cells per level do not fit the quadtree kernel's LDS", G.max_cells_level);
         return ORBX_E_INVALID;
@@ -2046,6 +2394,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
     int rc;
     if ((rc = ensure(&e->d_tabs, &e->tabs_cap, tabs.size() * 2))) return rc;
     if ((rc = ensure(&e->d_cells, &e->cells_cap, cells.size() * sizeof(CellRec)))) return rc;
+    if (!pairs.empty() && (rc = ensure(&e->d_pairs, &e->pairs_cap, pairs.size() * sizeof(PairRec)))) return rc;
     if ((rc = ensure(&e->d_pyr, &e->pyr_cap, (size_t)G.pyr_bytes * B))) return rc;
     if ((rc = ensure(&e->d_cell_cnt, &e->cell_cnt_cap, (size_t)G.total_cells * B * 4))) return rc;
     if ((rc = ensure(&e->d_cand, &e->cand_cap, (size_t)G.cand_total * B * 4))) return rc;
@@ -2074,6 +2423,7 @@ int orbx_prepare_geometry(orbx_extractor *e, int w, int h)
     }
     ORBX_HIP(hipMemcpy(e->d_tabs, tabs.data(), tabs.size() * 2, hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(e->d_cells, cells.data(), cells.size() * sizeof(CellRec), hipMemcpyHostToDevice));
+    if (!pairs.empty()) ORBX_HIP(hipMemcpy(e->d_pairs, pairs.data(), pairs.size() * sizeof(PairRec), hipMemcpyHostToDevice));
     ORBX_HIP(hipMemcpy(e->d_geom, &G, sizeof G, hipMemcpyHostToDevice));
     {
         const void *kt[4] = { reinterpret_cast<const void *>(k_tree<256, true>), reinterpret_cast<const void *>(k_tree<256, false>),
@@ -2196,6 +2546,11 @@ extern "C" int orbx_extractor_create(orbx_extractor **out, int nfeatures, float 
         e->pipe_kcopy = !(pk && *pk == '0');
         const char *fw = getenv("ORBX_FAST_WAVES");      // tests / experiments: force k_fast's waves per cell
         e->fast_waves = fw && *fw >= '1' && *fw <= '4' ? *fw - '0' : 0;
+        // ORBX_FAST_PAIR=1: the pair kernel (k_fast2) where the geometry allows.  Off by default: bit-exact, 4 % fewer VALU instructions per cell and
+        // less halo traffic, but 5-10 % SLOWER than one cell per wave on MI355X (the kernel sits at the knee between VALU issue
+        // and latency, and a pair wave's 7.8 KB of LDS leaves 21 waves per CU against 28)
+        const char *fp = getenv("ORBX_FAST_PAIR");
+        e->fast_pair = fp && *fp == '1' ? 1 : 0;
     }
     // src/ORBextractor.cc:436-461
     e->sf[0] = 1.0f; e->sig2[0] = 1.0f;
@@ -2240,7 +2595,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *e)
     for (auto &ev : e->prof_ev) { if (ev.owns_a && ev.a) hipEventDestroy(ev.a); if (ev.b) hipEventDestroy(ev.b); }
     for (auto ev : e->prof_pool) hipEventDestroy(ev);
     if (e->ev_switch) hipEventDestroy(e->ev_switch);
-    void *ptrs[] = { e->d_cand_prim, e->d_tree_tab, e->d_cells, e->d_geom, e->d_tabs, e->d_pyr, e->d_stage_in, e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid,
+    void *ptrs[] = { e->d_cand_prim, e->d_tree_tab, e->d_cells, e->d_pairs, e->d_geom, e->d_tabs, e->d_pyr, e->d_stage_in, e->d_cell_cnt, e->d_cand, e->d_tree_pts, e->d_tree_nid,
                      e->d_lvl_cnt, e->d_lvl_kp, e->d_out_kps, e->d_out_desc, e->d_out_n, e->d_out_ur, e->d_out_depth, e->d_st_dist, e->d_st_entries, e->d_rt_off, e->d_rt_entries, e->d_st_arrive };
     for (void *p : ptrs) if (p) hipFree(p);
     for (void *p : e->scratch) if (p) hipFree(p);
@@ -2377,6 +2732,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
             else for (int l = e->pyr_groups[gi].first; l < e->pyr_groups[gi].first + e->pyr_groups[gi].n; l++) launch_level(l);
         }
     orbx_prof_begin(e, ORBX_STAGE_FAST, s);
+    e->last_fast_form = 1;
     {
         FastArgs fa;
         fa.total_cells = G.total_cells; fa.lds_sc = G.fast_lds_sc; fa.lds_list = G.fast_lds_list; fa.lds_bm = G.fast_lds_bm;
@@ -2389,8 +2745,21 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *e, const void *d_imgs, 
             const int nw = e->fast_waves ? e->fast_waves : waves1 * 4 <= 16384 ? 4 : waves1 * 2 <= 16384 ? 2 : 1;    // (tools/sweep_small.sh: one frame 4, two frames 2, more 1)
             int lds_bytes = G.fast_lds_bytes;
             if (nw > 1) { fa.list_cap = G.fast_list_cap_big; fa.lds_bm = G.fast_lds_bm_big; lds_bytes = G.fast_lds_bytes_big; }
+            // one wave per PAIR of horizontally adjacent cells (k_fast2): opt-in experiment form (ORBX_FAST_PAIR=1)
+            if (G.fast2_ok && e->fast_pair == 1) {
+                e->last_fast_form = 2;
+                fa.list_cap = FAST2_LIST_CAP;
+                for (int grp = 0; grp < 2; grp++) {
+                    if (!G.fast2_count[grp]) continue;
+                    fa.lds_sc = G.fast2_lds_sc[grp]; fa.lds_list = G.fast2_lds_list[grp]; fa.lds_bm = G.fast2_lds_bm[grp]; fa.bm_rows = G.fast2_bm_rows[grp];
+                    const dim3 grid2((G.fast2_count[grp] + 8 * FAST_XG - 1) / (8 * FAST_XG) * (8 * FAST_XG), batch);
+                    hipLaunchKernelGGL((k_fast2<FAST2_P, FAST2_SP>), grid2, dim3(64), G.fast2_lds_bytes[grp], s, fa, (const PairRec *)e->d_pairs + G.fast2_first[grp],
+                                       G.fast2_count[grp], pr, e->d_cell_cnt, e->d_cand, e->d_cand_prim);
+                }
+            } else
 #define LAUNCH_FAST(NW_) hipLaunchKernelGGL((k_fast<48, 40, NW_>), grid, dim3(64 * NW_), lds_bytes, s, fa, e->d_cells, pr, e->d_cell_cnt, e->d_cand, e->d_cand_prim)
-            if (nw == 4) LAUNCH_FAST(4); else if (nw == 3) LAUNCH_FAST(3); else if (nw == 2) LAUNCH_FAST(2); else LAUNCH_FAST(1);
+            if (nw == 4) LAUNCH_FAST(4); else if (nw == 3) LAUNCH_FAST(3); else if (nw == 2) LAUNCH_FAST(2);
+            else LAUNCH_FAST(1);
 #undef LAUNCH_FAST
         }
         else
@@ -3000,6 +3369,9 @@ extern "C" int orbx_pyramid_level(orbx_extractor *e, int image_index, int level,
     ORBX_HIP(hipMemcpy2D(dst, dst_stride, src, pitch, L.w, L.h, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
+
+// which FAST kernel the most recent extraction launched: 1 = k_fast (a cell per wave, or several waves per cell), 2 = k_fast2 (a pair of cells per wave)
+extern "C" int orbx_debug_fast_form(const orbx_extractor *e) { return e ? e->last_fast_form : ORBX_E_INVALID; }
 
 extern "C" int orbx_debug_level_counts(orbx_extractor *e, int image_index, int32_t *counts)
 {

@@ -54,6 +54,9 @@ struct Geom {
     int fast_lds_sc, fast_lds_list, fast_lds_bm, fast_bm_rows, fast_lds_bytes; // LDS carve of k_fast
     int fast_small;         // 1: k_fast<48,40> (every cell <= 38 px wide), 0: k_fast<80,64>
     int fast_list_cap_big, fast_lds_bm_big, fast_lds_bytes_big;   // the carve with a candidate list that holds a whole cell (several waves per cell)
+    int fast2_ok, total_pairs;   // k_fast2 (a wave per pair of adjacent cells) is usable for this geometry; pair records per image
+    int fast2_first[2], fast2_count[2];   // two launches: levels whose detect areas have at most 32 rows, then the taller ones
+    int fast2_lds_sc[2], fast2_lds_list[2], fast2_lds_bm[2], fast2_bm_rows[2], fast2_lds_bytes[2];
     LevelGeom lv[ORBX_MAX_LEVELS];
 };
 
@@ -103,6 +106,9 @@ struct orbx_extractor {
     Geom *d_geom;        // device copy
     int16_t *d_tabs; size_t tabs_cap;      // resize tables
     CellRec *d_cells; size_t cells_cap;    // per-cell records of k_fast
+    void *d_pairs; size_t pairs_cap;       // per-pair records of k_fast2 (PairRec, orbx_extract.hip)
+    int last_fast_form;                    // debug: 1 = k_fast, 2 = k_fast2 ran in the most recent extraction
+    int fast_pair;                         // ORBX_FAST_PAIR: -1 = k_fast2 for batches, 0 = never, 1 = always
     // workspace (sized for max_w x max_h x max_batch)
     uint8_t *d_pyr; size_t pyr_cap;        // levels >= 1, all images
     uint8_t *d_stage_in; size_t stage_in_cap; // host-API input staging (level 0)

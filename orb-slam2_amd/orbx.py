@@ -136,6 +136,7 @@ def lib():
     L.orbx_profile_read.argtypes = [vp, vp, vp, i]
     L.orbx_debug_candidates.argtypes = [vp, i, i, vp, vp, vp, i, ip]
     L.orbx_debug_level_counts.argtypes = [vp, i, vp]
+    L.orbx_debug_fast_form.argtypes = [vp]
     L.orbx_debug_set_bow_form.argtypes = [i]
     L.orbx_debug_match_timing.argtypes = [vp]
     _lib = L
@@ -249,6 +250,10 @@ class ORBextractor:
     def set_pyramid_group_limit(self, max_images):
         """tuning only (results do not change): launches of at most max_images images build several pyramid levels per launch; 0 = never"""
         _check(self._L.orbx_extractor_set_pyramid_group_limit(self._h, int(max_images)))
+
+    def debug_fast_form(self):
+        """1 = k_fast, 2 = k_fast2 (a pair of cells per wave) ran in the most recent extraction"""
+        return self._L.orbx_debug_fast_form(self._h)
 
     def GetLevels(self): return self._L.orbx_get_levels(self._h)
     def GetScaleFactor(self): return self._L.orbx_get_scale_factor(self._h)

@@ -116,6 +116,45 @@ def test_fast_waves_per_cell(pkg, oracle, monkeypatch, nw):
         _check_stages(ex, orc, img, f"{w}x{h} {kind} fast waves {nw}")
 
 
+@pytest.mark.parametrize("pair", ["0", "1"])
+def test_fast_pair_kernel(pkg, oracle, monkeypatch, pair):
+    """k_fast2 (batches: one wave per PAIR of horizontally adjacent FAST cells, shared halo, one concatenated candidate list) against
+    k_fast (one cell per wave) on the same inputs, both against the oracle stage by stage: per-cell non-maximum suppression across the
+    A | B boundary, the per-cell minThFAST fallback (only the cell that kept nothing runs again), odd column counts (a cell alone),
+    narrow / skipped last columns, detect areas taller than 32 rows (whole-row bitmap segments), candidate lists beyond the cap
+    (rounds), and shapes whose cells are wider than 32 px (the pair kernel must step aside)"""
+    monkeypatch.setenv("ORBX_FAST_PAIR", pair)
+    monkeypatch.setenv("ORBX_FAST_WAVES", "1")
+    rng = np.random.Generator(np.random.PCG64(17))
+    cases = [(1241, 376, 1000, "scene"), (640, 480, 800, "checker"), (333, 257, 300, "scene"), (640, 480, 500, "lowcontrast"),
+             (752, 480, 1000, "halfflat"), (1920, 1080, 2000, "scene"), (783, 814, 1500, "scene"), (401, 299, 400, "noise"), (262, 226, 200, "scene")]
+    for (w, h, nf, kind) in cases:
+        if kind == "scene":
+            img = synth.image(w + 3, w, h, nshapes=int(w * h / 300) + 50)
+        elif kind == "checker":          # dense corners: candidate lists beyond ORBX_FAST_LIST_CAP
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = (((xx // 3 + yy // 3) & 1) * 200 + 20).astype(np.uint8)
+        elif kind == "noise":
+            img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        elif kind == "halfflat":         # columns alternate between textured and low-contrast 31-px stripes: in most pairs exactly ONE cell falls back to minThFAST
+            img = synth.image(23, w, h, nshapes=1500)
+            low = (100 + (img.astype(np.int32) - 100) // 14).astype(np.uint8)
+            stripe = ((np.arange(w) - 16) // 31) % 2 == 1
+            img = np.where(stripe[None, :], low, img).astype(np.uint8)
+        else:                            # contrast between minThFAST and iniThFAST: every cell takes the second pass
+            img = (100 + (synth.image(9, w, h).astype(np.int32) - 100) // 14).astype(np.uint8)
+        orc = oracle.Oracle(nf, 1.2, 8, 20, 7)
+        ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7, device=0, max_size=(w, h))
+        _check_stages(ex, orc, img, f"{w}x{h} {kind} pair kernel {pair}")
+        # the form really ran (k_fast2 needs every cell at most 32 px wide: 640x480 has 33-px cells at levels 2 and 5)
+        # the form really ran: k_fast2 needs every cell at most 32 px wide (640x480 and 752x480 have a level of 33-px cells)
+        pair_ok = all(-(-(lw - 32) // ((lw - 32) // 30)) <= 32 for lw in [int(np.rint(np.float32(w) / s_)) for s_ in np.cumprod([1.0] + [np.float32(1.2)] * 7, dtype=np.float32)])
+        assert ex.debug_fast_form() == (2 if pair == "1" and pair_ok else 1), (w, h, ex.debug_fast_form())
+    for sf, nl in ((1.5, 4), (1.1, 6)):
+        img = synth.image(7, 640, 480)
+        _check_stages(pkg.ORBextractor(800, sf, nl, 20, 7, device=0, max_size=(640, 480)), oracle.Oracle(800, sf, nl, 20, 7), img, f"sf={sf} pair kernel {pair}")
+
+
 def test_extract_fhd_4000(pkg, oracle):
     img = synth.image(5, 1920, 1080, nshapes=4000)
     ex = _extractor(pkg, 4000, 1920, 1080)

@@ -24,10 +24,11 @@ for _ in range(5): step()
 ex.sync()
 L.orbx_diag_fast_stamps(out,1)
 w=out[7]
-names=["load+zero","pretest","fullscore","nms","emit"]
-tot=sum(out[i] for i in range(5))
-print("waves",w, "avg cycles/wave", tot/w)
-for i,nm in enumerate(names): print(f"  {nm:10s} {out[i]/w:9.1f} cycles  {100*out[i]/tot:5.1f}%")
+names={0:"load+zero",1:"pretest",5:"list",6:"score",2:"barrier",3:"nms",4:"emit"}
+tot=sum(out[i] for i in names)
+print("k_fast form", ex.debug_fast_form(), "waves",w, "avg cycles/wave", tot/w)
+for i in (0,1,5,6,2,3,4): print(f"  {names[i]:10s} {out[i]/w:9.1f} cycles  {100*out[i]/tot:5.1f}%")
+if os.environ.get("ORBX_DIAG_FAST_ONLY"): sys.exit(0)
 
 L.orbx_diag_desc_stamps(out,1)
 for _ in range(5): step()

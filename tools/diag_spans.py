@@ -60,3 +60,12 @@ print("slowest k_fast waves:")
 for i in order[:8]: print("  ", show(i))
 print("median-ish waves:")
 for i in order[len(order) // 2: len(order) // 2 + 3]: print("  ", show(i))
+# mean phase durations over the logged waves of the last launch (those that ran all phases)
+full = [i for i in ids if ph[i, 4] and ph[i, 0] and ph[i, 5] and ph[i, 6]]
+if full:
+    f = np.array(full)
+    t0 = o[0, f, 0]
+    seq = [("load+zero", ph[f, 0] - t0), ("pretest", ph[f, 1] - ph[f, 0]), ("list", ph[f, 5] - ph[f, 1]), ("score", ph[f, 6] - ph[f, 5]), ("barrier", ph[f, 2] - ph[f, 6]),
+           ("nms", ph[f, 3] - ph[f, 2]), ("emit", ph[f, 4] - ph[f, 3])]
+    print("k_fast form", ex.debug_fast_form(), "mean phase durations over", len(f), "waves (us):", {k: round(float(v.mean()) / 100.0, 2) for k, v in seq},
+          "life", round(float((o[0, f, 1] - t0).mean()) / 100.0, 2))
