@@ -8,6 +8,7 @@
 #include <stdexcept>
 
 #include "orbx_adapter.h"
+#include "orbx_batch.h"
 
 using namespace std;
 
@@ -56,6 +57,26 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint *> &vpMapPo
 
 int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &vpMatches12)
 {
+    // both keyframes resident in HBM (orbx_adapter::KeyFrameCache: a batched call has seen them, or the KeyFrame constructor registered
+    // them): only the map-point flags, the node intersection and the result row cross PCIe
+    orbx_adapter::KeyFrameCache &cache = orbx_adapter::KeyFrameCache::instance();
+    if (const orbx_kf *r1 = cache.find(pKF1))
+        if (const orbx_kf *r2 = cache.find(pKF2)) {
+            vector<MapPoint *> vp1, vp2;
+            vector<uint8_t> fl1, fl2;
+            orbx_adapter::GoodPointFlags(pKF1, vp1, fl1);
+            orbx_adapter::GoodPointFlags(pKF2, vp2, fl2);
+            static const uint8_t none = 0;
+            const uint8_t *f2 = fl2.empty() ? &none : &fl2[0];
+            vector<int32_t> m12(pKF1->N > 0 ? pKF1->N : 1);
+            int n = 0;
+            if (orbx_kf_search_by_bow_kf_kf(r1, fl1.empty() ? &none : &fl1[0], &r2, &f2, 1, mfNNratio, mbCheckOrientation ? 1 : 0, &m12[0], &n) != ORBX_OK)
+                throw std::runtime_error(orbx_last_error());
+            vpMatches12 = vector<MapPoint *>(vp1.size(), static_cast<MapPoint *>(NULL));
+            for (int i = 0; i < pKF1->N; i++)
+                if (m12[i] >= 0) vpMatches12[i] = vp2[m12[i]];
+            return n;
+        }
     const vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches();
     const vector<MapPoint *> vpMapPoints2 = pKF2->GetMapPointMatches();
     Side k1, k2;
@@ -110,6 +131,28 @@ int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++)
             f12[3 * r + c] = F12.at<float>(r, c);
+    {   // both keyframes resident (orbx_adapter::KeyFrameCache): see SearchByBoW(KeyFrame*, KeyFrame*)
+        orbx_adapter::KeyFrameCache &cache = orbx_adapter::KeyFrameCache::instance();
+        const orbx_kf *r1 = cache.find(pKF1), *r2 = r1 ? cache.find(pKF2) : NULL;
+        if (r1 && r2) {
+            vector<uint8_t> fl1, fl2;
+            orbx_adapter::HasPointFlags(pKF1, fl1);
+            orbx_adapter::HasPointFlags(pKF2, fl2);
+            const uint8_t *f2 = fl2.empty() ? NULL : &fl2[0];
+            const float ep[2] = { ex, ey };
+            const int cap = pKF1->N > 0 ? pKF1->N : 1;
+            vector<int32_t> pairs(2 * (size_t)cap);
+            int npairs = 0;
+            if (orbx_kf_search_for_triangulation(r1, fl1.empty() ? NULL : &fl1[0], &r2, &f2, 1, f12, ep, &pKF2->mvScaleFactors[0], &pKF2->mvLevelSigma2[0],
+                                                 (int)pKF2->mvScaleFactors.size(), bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0, &pairs[0], cap, &npairs) != ORBX_OK)
+                throw std::runtime_error(orbx_last_error());
+            vMatchedPairs.clear();
+            vMatchedPairs.reserve(npairs);
+            for (int i = 0; i < npairs; i++)
+                vMatchedPairs.push_back(make_pair((size_t)pairs[2 * i], (size_t)pairs[2 * i + 1]));
+            return npairs;
+        }
+    }
     Side k1, k2;
     triangulation_side(pKF1, k1);
     triangulation_side(pKF2, k2);

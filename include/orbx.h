@@ -304,6 +304,10 @@ void orbx_thread_release(void);
 /* SearchByBoW(pKF, F): kf_flag as orbx_search_by_bow_kf_f's kf->flag; match_f[f's n] */
 int orbx_kf_search_by_bow_kf_f(const orbx_kf *kf, const uint8_t *kf_flag, const orbx_kf *f,
                                float nnratio, int check_orientation, int32_t *match_f, int *nmatches);
+/* Tracking::Relocalization's loop (src/Tracking.cc:1661-1682): SearchByBoW(pKF, mCurrentFrame) for nkf candidate RESIDENT keyframes against one
+ * frame as ONE call; the frame lives one frame time and is given as host pointers (f->flag is not read): match_f[nkf][f->n], nmatches[nkf] */
+int orbx_kf_search_by_bow_kfs_f(const orbx_kf *const *kfs, const uint8_t *const *kf_flags, int nkf, const orbx_featset *f,
+                                float nnratio, int check_orientation, int32_t *match_f, int *nmatches);
 /* SearchByBoW(pKF1, pKF2) for n2 candidates: match12[n2][k1's n], nmatches[n2] */
 int orbx_kf_search_by_bow_kf_kf(const orbx_kf *k1, const uint8_t *flag1, const orbx_kf *const *k2s, const uint8_t *const *flags2, int n2,
                                 float nnratio, int check_orientation, int32_t *match12, int *nmatches);

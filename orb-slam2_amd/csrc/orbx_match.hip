@@ -1054,6 +1054,29 @@ extern "C" int orbx_kf_search_by_bow_kf_f(const orbx_kf *kf, const uint8_t *kf_f
     return rc;
 }
 
+// Tracking::Relocalization (src/Tracking.cc:1661-1682): SearchByBoW(pKF, mCurrentFrame) for every candidate keyframe, one launch.  The keyframes are
+// resident; the frame lives one frame time and comes as host pointers (packed into the call's blob and read by the kernel over PCIe: an upload of
+// its own would cost more than the whole call)
+extern "C" int orbx_kf_search_by_bow_kfs_f(const orbx_kf *const *kfs, const uint8_t *const *kf_flags, int nkf, const orbx_featset *f,
+                                           float nnratio, int check_orientation, int32_t *match_f, int *nmatches)
+{
+    const char *who = "orbx_kf_search_by_bow_kfs_f";
+    if (!kfs || !kf_flags || nkf < 1 || !f || !match_f || !nmatches) { orbx_set_error("%s: invalid argument", who); return ORBX_E_INVALID; }
+    if (!orbx_feat_validate(f, 0, 1)) { orbx_set_error("%s: malformed frame feature set", who); return ORBX_E_INVALID; }
+    std::vector<HSide> sides((size_t)nkf + 1);
+    std::vector<int> pa((size_t)nkf), pb((size_t)nkf, nkf);
+    for (int i = 0; i < nkf; i++) {
+        if (!kfs[i] || !kf_flags[i] || kfs[i]->device != kfs[0]->device) { orbx_set_error("%s: keyframe %d is null, has no flags or is on another device", who, i); return ORBX_E_INVALID; }
+        hside_from_kf(&sides[(size_t)i], kfs[i], kf_flags[i], 0);
+        pa[(size_t)i] = i;
+    }
+    hside_from_set(&sides[(size_t)nkf], f, 1);
+    const int rc = match_call(0, kfs[0]->device, sides.data(), nkf + 1, pa.data(), pb.data(), nkf, nullptr, nullptr, nullptr, nullptr, 0, nnratio, check_orientation, 0, 0,
+                              match_f, (size_t)f->n, nmatches);
+    if (rc == M_NOT_APPLICABLE) { orbx_set_error("%s: a vocabulary node holds more than %d features", who, M_GREEDY_MAX_COLS); return ORBX_E_INVALID; }
+    return rc;
+}
+
 extern "C" int orbx_kf_search_by_bow_kf_kf(const orbx_kf *k1, const uint8_t *flag1, const orbx_kf *const *k2s, const uint8_t *const *flags2, int n2,
                                            float nnratio, int check_orientation, int32_t *match12, int *nmatches)
 {

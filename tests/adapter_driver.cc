@@ -11,6 +11,10 @@
 //                                      compiled adaptors; built with -DORBX_ADAPTER_CAPTURE so that the inputs each search handed to the
 //                                      ABI are written next to its results (the test gives the CPU oracle the same inputs)
 //   adapter_driver map in.bin out.txt  the relocalisation / local-mapping / loop-closing searches (adapter/ORBmatcher_fuse.cc) the same way
+//   adapter_driver batch in.bin out.txt [reps]   the loops of LocalMapping::CreateNewMapPoints / LoopClosing::ComputeSim3 / Tracking::Relocalization over
+//                                      20 derived keyframes through adapter/ORBmatcher_batch.cc (resident keyframes, one call per loop), the same
+//                                      pairs through the single-pair adaptors (cache-aware), every keyframe's data written out for the oracle, and
+//                                      adaptor-inclusive timings (flags + flatten + call + map-back, std::chrono) as "time_*" lines in nanoseconds
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -25,6 +29,10 @@
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
 #include "orbx_adapter.h"
+#include "orbx_batch.h"
+
+#include <algorithm>
+#include <chrono>
 
 using namespace ORB_SLAM2;
 
@@ -64,10 +72,11 @@ static void dump_mat(FILE *f, const char *name, const cv::Mat &m)
 
 // the synthetic vocabulary node of a descriptor (the tests use the same rule): bytes 0 of the descriptor picks one of 16
 // nodes, features whose byte 1 is a multiple of 8 are "stopped" (in no node)
+static int g_fv_nodes = 16;     // batch mode: 100 (a FeatureVector at levelsup = 4 of the k = 10, L = 6 vocabulary has up to 100 nodes, src/Frame.cc:464)
 static void feature_vector(const cv::Mat &desc, DBoW2::FeatureVector &fv)
 {
     for (int i = 0; i < desc.rows; i++)
-        if (desc.at<uchar>(i, 1) % 8 != 0) fv.addFeature(100 + (desc.at<uchar>(i, 0) & 15), (unsigned)i);
+        if (desc.at<uchar>(i, 1) % 8 != 0) fv.addFeature(100 + (g_fv_nodes == 16 ? (desc.at<uchar>(i, 0) & 15) : desc.at<uchar>(i, 0) % g_fv_nodes), (unsigned)i);
 }
 
 static int mode_csr()
@@ -577,11 +586,214 @@ static int mode_map(const char *in_path, const char *out_path)
 #endif
 
 
+// ---------------------------------------------------------------- batch mode: resident keyframes + the three loops as one call each
+
+// keyframe k of the batch scene: the features of eye (k odd: right, even: left) rotated by 37 k positions, ~4 % of the descriptor bits flipped by
+// a per-keyframe LCG (so that matches exist but differ), map-point pattern (bad_every, none_every) depending on k
+static void derived_keyframe(KeyFrame &kf, std::vector<MapPoint> &store, int k, const std::vector<cv::KeyPoint> &keys, const cv::Mat &desc,
+                             const std::vector<float> &uRight, const std::vector<float> &sf, const std::vector<float> &s2)
+{
+    const int n = (int)keys.size(), rot = n ? (37 * k) % n : 0;
+    std::vector<cv::KeyPoint> kk(n);
+    cv::Mat dd(n, 32, CV_8UC1);
+    std::vector<float> ur(n, -1.0f);
+    uint32_t lcg = 12345u + 977u * (uint32_t)k;
+    for (int i = 0; i < n; i++) {
+        const int j = (i + rot) % n;
+        kk[i] = keys[j];
+        if (j < (int)uRight.size()) ur[i] = uRight[j];
+        for (int b = 0; b < 32; b++) {
+            uint8_t v = desc.at<uchar>(j, b);
+            if (k > 0 && b >= 2) {           // bytes 0 / 1 pick the synthetic vocabulary node: kept, so that the keyframes share nodes
+                lcg = lcg * 1664525u + 1013904223u;
+                if ((lcg >> 24) < 82) v ^= (uint8_t)(1u << ((lcg >> 16) & 7));      // one bit in ~ a third of the bytes
+            }
+            dd.at<uchar>(i, b) = v;
+        }
+    }
+    fill_keyframe(kf, kk, dd, ur, store, 4 + k % 5, 3 + k % 3, sf, s2);
+}
+
+static void dump_keyframe(FILE *fo, const char *pre, KeyFrame &kf)
+{
+    char nm[64];
+    snprintf(nm, sizeof nm, "%skeys", pre); dump_keys(fo, nm, kf.mvKeysUn);
+    snprintf(nm, sizeof nm, "%sdesc", pre); dump_mat(fo, nm, kf.mDescriptors);
+    snprintf(nm, sizeof nm, "%suright", pre); dump_f(fo, nm, kf.mvuRight);
+    std::vector<int> good(kf.N), has(kf.N);
+    for (int i = 0; i < kf.N; i++) { has[i] = kf.mvpMapPoints[i] ? 1 : 0; good[i] = kf.mvpMapPoints[i] && !kf.mvpMapPoints[i]->isBad() ? 1 : 0; }
+    snprintf(nm, sizeof nm, "%sgood", pre); dump_i(fo, nm, good);
+    snprintf(nm, sizeof nm, "%shas", pre); dump_i(fo, nm, has);
+}
+
+static std::vector<int> held_in(const std::vector<MapPoint *> &v, const std::vector<MapPoint> &store)
+{
+    std::vector<int> o(v.size(), -1);
+    for (size_t i = 0; i < v.size(); i++) if (v[i]) o[i] = (int)(v[i] - &store[0]);
+    return o;
+}
+
+static long long median_ns(std::vector<long long> &v) { std::sort(v.begin(), v.end()); return v.empty() ? 0 : v[v.size() / 2]; }
+
+static int mode_batch(const char *in_path, const char *out_path, int reps)
+{
+    FILE *fi = fopen(in_path, "rb");
+    if (!fi) { fprintf(stderr, "cannot open %s\n", in_path); return 2; }
+    int hdr[2];
+    if (fread(hdr, 4, 2, fi) != 2) return 2;
+    const int w = hdr[0], h = hdr[1];
+    cv::Mat imL(h, w, CV_8UC1), imR(h, w, CV_8UC1);
+    if (fread(imL.data, 1, (size_t)w * h, fi) != (size_t)w * h || fread(imR.data, 1, (size_t)w * h, fi) != (size_t)w * h) return 2;
+    fclose(fi);
+    FILE *fo = fopen(out_path, "w");
+    if (!fo) return 2;
+    ORBextractor exL(1000, 1.2f, 8, 20, 7);
+    std::vector<cv::KeyPoint> kl, kr; cv::Mat dl, dr; std::vector<float> ur, dp;
+    exL.ExtractStereo(imL, imR, 386.1448f, 386.1448f / Frame::fx, kl, dl, kr, dr, ur, dp);
+    const std::vector<float> sf = exL.GetScaleFactors(), s2 = exL.GetScaleSigmaSquares();
+    dump_f(fo, "scaleFactors", sf); dump_f(fo, "levelSigma2", s2);
+
+    const int NK = 20;
+    g_fv_nodes = 100;
+    KeyFrame cur;
+    std::vector<MapPoint> storeC;
+    derived_keyframe(cur, storeC, 0, kl, dl, ur, sf, s2);
+    std::vector<KeyFrame> nb(NK);
+    std::vector<std::vector<MapPoint> > storeN(NK);
+    std::vector<KeyFrame *> vpN(NK);
+    std::vector<cv::Mat> vF12(NK);
+    cur.Ow = cv::Mat(3, 1, CV_32F); cur.Ow.at<float>(0) = 0.5372f; cur.Ow.at<float>(1) = 0.01f; cur.Ow.at<float>(2) = 0.02f;
+    std::vector<float> f12all;
+    for (int k = 0; k < NK; k++) {
+        derived_keyframe(nb[k], storeN[k], k + 1, (k & 1) ? kl : kr, (k & 1) ? dl : dr, (k & 1) ? ur : std::vector<float>(), sf, s2);
+        vpN[k] = &nb[k];
+        nb[k].Rcw = cv::Mat(3, 3, CV_32F);
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) nb[k].Rcw.at<float>(r, c) = r == c ? 1.f : 0.f;
+        nb[k].tcw = cv::Mat(3, 1, CV_32F);
+        nb[k].tcw.at<float>(0) = 0.05f * (float)k; nb[k].tcw.at<float>(1) = 0.f; nb[k].tcw.at<float>(2) = 0.25f + 0.01f * (float)k;
+        vF12[k] = cv::Mat(3, 3, CV_32F);
+        const float g = 1.f / (718.856f + 3.f * (float)k);       // a family of near-rectified epipolar geometries
+        const float f12[9] = { 0.f, 0.f, 0.f, 0.f, 0.f, -g, 0.f, g, 0.0001f * (float)k };
+        for (int i = 0; i < 9; i++) { vF12[k].at<float>(i / 3, i % 3) = f12[i]; f12all.push_back(f12[i]); }
+        char pre[32];
+        snprintf(pre, sizeof pre, "nb%d_", k);
+        dump_keyframe(fo, pre, nb[k]);
+        std::vector<float> pose(3);
+        for (int i = 0; i < 3; i++) pose[i] = nb[k].tcw.at<float>(i);
+        snprintf(pre, sizeof pre, "nb%d_tcw", k); dump_f(fo, pre, pose);
+    }
+    dump_keyframe(fo, "cur_", cur);
+    dump_f(fo, "F12s", f12all);
+    std::vector<float> ow(3);
+    for (int i = 0; i < 3; i++) ow[i] = cur.Ow.at<float>(i);
+    dump_f(fo, "cur_Ow", ow);
+    // the frame of the relocalisation loop: the left eye as extracted
+    Frame F;
+    F.N = (int)kl.size(); F.mvKeys = kl; F.mvKeysUn = kl; F.mDescriptors = dl;
+    feature_vector(F.mDescriptors, F.mFeatVec);
+
+    orbx_adapter::KeyFrameCache &cache = orbx_adapter::KeyFrameCache::instance();
+    // ---- single-pair adaptors BEFORE anything is resident: host-pointer path (reference for "cache on == cache off")
+    std::vector<std::pair<size_t, size_t> > pairs_h;
+    ORBmatcher tri(0.6f, false), bow(0.75f, true);
+    tri.SearchForTriangulation(&cur, vpN[3], vF12[3], pairs_h, false);
+    std::vector<MapPoint *> vp12_h;
+    const int n12_h = bow.SearchByBoW(&cur, vpN[4], vp12_h);
+    if (cache.size() != 0) { fprintf(stderr, "cache not empty\n"); return 4; }
+
+    // ---- LocalMapping::CreateNewMapPoints: all neighbours in one call
+    std::vector<std::vector<std::pair<size_t, size_t> > > vvPairs;
+    const int total_tri = orbx_adapter::SearchForTriangulationBatch(&cur, vpN, vF12, vvPairs, false);
+    for (int k = 0; k < NK; k++) {
+        std::vector<long long> flat;
+        for (size_t i = 0; i < vvPairs[k].size(); i++) { flat.push_back((long long)vvPairs[k][i].first); flat.push_back((long long)vvPairs[k][i].second); }
+        char nm[32]; snprintf(nm, sizeof nm, "tri%d", k); dump_i(fo, nm, flat);
+    }
+    std::vector<std::vector<std::pair<size_t, size_t> > > vvPairsS;
+    orbx_adapter::SearchForTriangulationBatch(&cur, vpN, vF12, vvPairsS, true);        // bOnlyStereo
+    for (int k = 0; k < NK; k += 7) {
+        std::vector<long long> flat;
+        for (size_t i = 0; i < vvPairsS[k].size(); i++) { flat.push_back((long long)vvPairsS[k][i].first); flat.push_back((long long)vvPairsS[k][i].second); }
+        char nm[32]; snprintf(nm, sizeof nm, "triStereo%d", k); dump_i(fo, nm, flat);
+    }
+    // ---- LoopClosing::ComputeSim3: all candidates in one call
+    std::vector<std::vector<MapPoint *> > vv12; std::vector<int> vn12;
+    orbx_adapter::SearchByBoWBatch(&cur, vpN, vv12, vn12);
+    for (int k = 0; k < NK; k++) { char nm[32]; snprintf(nm, sizeof nm, "bow12_%d", k); dump_i(fo, nm, held_in(vv12[k], storeN[k])); }
+    dump_i(fo, "bow12_n", vn12);
+    // ---- Tracking::Relocalization: all candidates against the frame in one call
+    std::vector<std::vector<MapPoint *> > vvF; std::vector<int> vnF;
+    orbx_adapter::SearchByBoWBatch(vpN, F, vvF, vnF);
+    for (int k = 0; k < NK; k++) { char nm[32]; snprintf(nm, sizeof nm, "bowF_%d", k); dump_i(fo, nm, held_in(vvF[k], storeN[k])); }
+    dump_i(fo, "bowF_n", vnF);
+    dump_i(fo, "cache_size", std::vector<int>(1, (int)cache.size()));
+
+    // ---- the single-pair adaptors again, now on resident keyframes: the same answers as the host-pointer path and as the batch
+    std::vector<std::pair<size_t, size_t> > pairs_r;
+    tri.SearchForTriangulation(&cur, vpN[3], vF12[3], pairs_r, false);
+    std::vector<MapPoint *> vp12_r;
+    const int n12_r = bow.SearchByBoW(&cur, vpN[4], vp12_r);
+    const int same = (pairs_r == pairs_h && pairs_r == vvPairs[3] && vp12_r == vp12_h && vp12_r == vv12[4] && n12_r == n12_h && n12_r == vn12[4]) ? 1 : 0;
+    dump_i(fo, "single_equals_batch", std::vector<int>(1, same));
+    cache.drop(vpN[4]);
+    std::vector<MapPoint *> vp12_d;
+    const int n12_d = bow.SearchByBoW(&cur, vpN[4], vp12_d);                            // dropped: host-pointer path again
+    dump_i(fo, "after_drop_equal", std::vector<int>(1, (vp12_d == vp12_h && n12_d == n12_h && cache.size() == (size_t)NK) ? 1 : 0));
+    cache.get(vpN[4]);
+
+    // ---- adaptor-inclusive timing: what ORB-SLAM2's threads would see (flags under the keyframe mutexes, epipoles, call, map-back)
+    typedef std::chrono::steady_clock clk;
+    std::vector<long long> t_tri_b, t_bow_b, t_rel_b, t_tri_1, t_bow_1, t_tri_h, t_bow_h, t_bowF_h;
+    for (int r = 0; r < reps; r++) {
+        clk::time_point t0 = clk::now();
+        orbx_adapter::SearchForTriangulationBatch(&cur, vpN, vF12, vvPairs, false);
+        clk::time_point t1 = clk::now();
+        orbx_adapter::SearchByBoWBatch(&cur, vpN, vv12, vn12);
+        clk::time_point t2 = clk::now();
+        orbx_adapter::SearchByBoWBatch(vpN, F, vvF, vnF);
+        clk::time_point t3 = clk::now();
+        tri.SearchForTriangulation(&cur, vpN[r % NK], vF12[r % NK], pairs_r, false);      // resident single pair
+        clk::time_point t4 = clk::now();
+        bow.SearchByBoW(&cur, vpN[r % NK], vp12_r);
+        clk::time_point t5 = clk::now();
+        t_tri_b.push_back(std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count());
+        t_bow_b.push_back(std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count());
+        t_rel_b.push_back(std::chrono::duration_cast<std::chrono::nanoseconds>(t3 - t2).count());
+        t_tri_1.push_back(std::chrono::duration_cast<std::chrono::nanoseconds>(t4 - t3).count());
+        t_bow_1.push_back(std::chrono::duration_cast<std::chrono::nanoseconds>(t5 - t4).count());
+    }
+    cache.clear();                                                                       // host-pointer single pairs (round-3 adaptor path)
+    for (int r = 0; r < reps; r++) {
+        clk::time_point t0 = clk::now();
+        tri.SearchForTriangulation(&cur, vpN[r % NK], vF12[r % NK], pairs_r, false);
+        clk::time_point t1 = clk::now();
+        bow.SearchByBoW(&cur, vpN[r % NK], vp12_r);
+        clk::time_point t2 = clk::now();
+        bow.SearchByBoW(vpN[r % NK], F, vp12_r);
+        clk::time_point t3 = clk::now();
+        t_tri_h.push_back(std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count());
+        t_bow_h.push_back(std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count());
+        t_bowF_h.push_back(std::chrono::duration_cast<std::chrono::nanoseconds>(t3 - t2).count());
+    }
+    std::vector<long long> tm;
+    tm.push_back(median_ns(t_tri_b)); tm.push_back(median_ns(t_bow_b)); tm.push_back(median_ns(t_rel_b)); tm.push_back(median_ns(t_tri_1)); tm.push_back(median_ns(t_bow_1));
+    tm.push_back(median_ns(t_tri_h)); tm.push_back(median_ns(t_bow_h)); tm.push_back(median_ns(t_bowF_h));
+    dump_i(fo, "time_ns", tm);       // [tri batch of 20, bow(KF,KF) batch of 20, bow(KFs,F) batch of 20, tri resident single, bow resident single, tri host, bow(KF,KF) host, bow(KF,F) host]
+    dump_i(fo, "time_reps", std::vector<int>(1, reps));
+    dump_i(fo, "features", std::vector<int>(1, cur.N));
+    fclose(fo);
+    printf("adaptor batch ok: %d keyframes x %d features, %d triangulation pairs; us per pair: tri batch %.2f, bow12 batch %.2f, bowF batch %.2f; single resident tri %.1f bow %.1f; "
+           "single host tri %.1f bow12 %.1f bowF %.1f\n", NK, cur.N, total_tri, tm[0] / 1e3 / NK, tm[1] / 1e3 / NK, tm[2] / 1e3 / NK, tm[3] / 1e3, tm[4] / 1e3, tm[5] / 1e3, tm[6] / 1e3, tm[7] / 1e3);
+    return 0;
+}
+
+
 int main(int argc, char **argv)
 {
     try {
         if (argc >= 2 && !strcmp(argv[1], "csr")) return mode_csr();
         if (argc >= 4 && !strcmp(argv[1], "run")) return mode_run(argv[2], argv[3]);
+        if (argc >= 4 && !strcmp(argv[1], "batch")) return mode_batch(argv[2], argv[3], argc >= 5 ? atoi(argv[4]) : 50);
 #ifdef ORBX_ADAPTER_CAPTURE
         if (argc >= 5 && !strcmp(argv[1], "track")) return mode_track(argv[2], argv[3], argv[4]);
         if (argc >= 4 && !strcmp(argv[1], "map")) return mode_map(argv[2], argv[3]);

@@ -18,7 +18,7 @@ from tools import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ADAPTER = [os.path.join(ROOT, "adapter", f) for f in ("ORBextractor.cc", "Frame_stereo.cc", "ORBmatcher_bow.cc", "ORBmatcher_proj.cc", "ORBmatcher_fuse.cc",
-                                                       "Frame_bow.cc", "MapPoint_distinctive.cc")]
+                                                       "Frame_bow.cc", "MapPoint_distinctive.cc", "ORBmatcher_batch.cc")]
 INC = ["-I", os.path.join(ROOT, "adapter"), "-I", os.path.join(ROOT, "tests", "cvstub"), "-I", os.path.join(ROOT, "include")]
 REF = "/root/reference"
 
@@ -32,7 +32,7 @@ def _build_driver(tmpdir, real_dbow2=False):
         inc = ["-I", REF] + inc
         extra = [os.path.join(REF, "Thirdparty/DBoW2/DBoW2", f) for f in ("FeatureVector.cpp", "BowVector.cpp")]
     # ORBX_ADAPTER_CAPTURE: the projection adaptors keep a copy of what they hand to the ABI (the `track` mode writes it out)
-    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-Wextra", "-DORBX_ADAPTER_CAPTURE"] + inc + [os.path.join(ROOT, "tests", "adapter_driver.cc")] + ADAPTER + extra +
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-DORBX_ADAPTER_CAPTURE"] + inc + [os.path.join(ROOT, "tests", "adapter_driver.cc")] + ADAPTER + extra +
                           ["-L", os.path.join(ROOT, "orb-slam2_amd"), "-lorbx", "-Wl,-rpath," + os.path.join(ROOT, "orb-slam2_amd"), "-o", exe])
     return exe
 
@@ -122,9 +122,9 @@ def _keys(a, pkg):
     return k
 
 
-def _featset(desc, kp, flag, u_right):
+def _featset(desc, kp, flag, u_right, nodes=16):
     keep = desc[:, 1] % 8 != 0
-    node = 100 + (desc[:, 0] & 15).astype(np.uint32)
+    node = 100 + ((desc[:, 0] & 15) if nodes == 16 else desc[:, 0] % nodes).astype(np.uint32)
     ids = np.unique(node[keep])
     feat = np.concatenate([np.nonzero(keep & (node == i))[0] for i in ids]).astype(np.uint32)
     off = np.concatenate([[0], np.cumsum([int((keep & (node == i)).sum()) for i in ids])]).astype(np.int32)
@@ -379,3 +379,53 @@ def test_adapter_map_searches(pkg, oracle, tmp_path):
     assert not (p12["valid"] & ~(has_L & ~bad_L & (pre < 0))).any() and p12["valid"].sum() > 200 and p21["valid"].sum() > 200
     exp, en = oracle.search_by_sim3(kf1, kf2, p12, p21, sf, sf, 7.5)
     assert int(r["sim3_n"][0]) == en and (r["sim3_held"] == np.where(exp >= 0, exp, pre)).all() and en > 20
+
+
+@pytest.mark.gpu
+def test_adapter_batched_resident_matchers(pkg, oracle, tmp_path):
+    """adapter/ORBmatcher_batch.cc: the loops of LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:241-309), LoopClosing::ComputeSim3
+    (src/LoopClosing.cc:293-323) and Tracking::Relocalization (src/Tracking.cc:1661-1682) over 20 keyframes, each as ONE call on resident
+    keyframes (orbx_adapter::KeyFrameCache), against the oracle's per-pair loop on the data the driver wrote out; the single-pair adaptors
+    give the same answers whether the keyframes are resident or not, and after a drop()"""
+    w, h = 1241, 376
+    left, right, _ = synth.stereo_pair(616, w, h)
+    inp, outp = os.path.join(tmp_path, "in.bin"), os.path.join(tmp_path, "out.txt")
+    with open(inp, "wb") as f:
+        f.write(np.array([w, h], np.int32).tobytes()); f.write(left.tobytes()); f.write(right.tobytes())
+    exe = _build_driver(str(tmp_path))
+    run = subprocess.run([exe, "batch", inp, outp, "30"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    print(run.stdout.strip())
+    r = _parse(outp)
+    NK = 20
+    assert int(r["cache_size"][0]) == NK + 1 and int(r["single_equals_batch"][0]) == 1 and int(r["after_drop_equal"][0]) == 1
+    sf, s2 = _f32(r["scaleFactors"]), _f32(r["levelSigma2"])
+    fx, cx, cy = np.float32(718.856), np.float32(607.1928), np.float32(185.2157)
+
+    def kf(pre, flag_key):
+        kp = _keys(r[pre + "keys"], pkg)
+        return _featset(_u8(r[pre + "desc"]).reshape(-1, 32), kp, r[pre + flag_key], _f32(r[pre + "uright"]), nodes=100)
+    cur_tri, cur_bow = kf("cur_", "has"), kf("cur_", "good")
+    frame = dict(cur_bow); frame["flag"] = np.zeros(len(frame["desc"]), np.uint8)     # the frame of the relocalisation loop = the left eye as extracted
+    ow = _f32(r["cur_Ow"]); F12s = _f32(r["F12s"]).reshape(NK, 9)
+    total = 0
+    for k in range(NK):
+        pre = f"nb{k}_"
+        nb_tri, nb_bow = kf(pre, "has"), kf(pre, "good")
+        c2 = (ow + _f32(r[pre + "tcw"])).astype(np.float32)          # R2w = identity
+        invz = np.float32(1.0) / c2[2]
+        ex = np.float32(np.float32(fx * c2[0]) * invz) + cx
+        ey = np.float32(np.float32(fx * c2[1]) * invz) + cy
+        exp = oracle.search_for_triangulation(cur_tri, nb_tri, F12s[k], float(ex), float(ey), sf, s2, 0.6, False, False)
+        assert (r[f"tri{k}"].reshape(-1, 2) == exp.reshape(-1, 2)).all() and len(r[f"tri{k}"]) == exp.size, f"triangulation, neighbour {k}"
+        total += len(exp.reshape(-1, 2))
+        if k % 7 == 0:
+            exps = oracle.search_for_triangulation(cur_tri, nb_tri, F12s[k], float(ex), float(ey), sf, s2, 0.6, False, True)
+            assert (r[f"triStereo{k}"].reshape(-1, 2) == exps.reshape(-1, 2)).all() and len(r[f"triStereo{k}"]) == exps.size, f"bOnlyStereo, neighbour {k}"
+        e12, n12 = oracle.search_by_bow_kf_kf(cur_bow, nb_bow, 0.75, True)
+        assert int(r["bow12_n"][k]) == n12 and (r[f"bow12_{k}"] == e12).all(), f"SearchByBoW(KF, KF), candidate {k}"
+        ef, nf = oracle.search_by_bow_kf_f(nb_bow, frame, 0.75, True)
+        assert int(r["bowF_n"][k]) == nf and (r[f"bowF_{k}"] == ef).all(), f"SearchByBoW(KF, F), candidate {k}"
+    assert total > 100 and int(r["bow12_n"].sum()) > 200 and int(r["bowF_n"].sum()) > 200      # not vacuous
+    t = r["time_ns"]
+    assert len(t) == 8 and (t > 0).all()

@@ -51,6 +51,42 @@ def make_sets(seed=5, n=1000, nkf=20, flip=0.04):
     return cur, kfs, Fs, eps, sf.astype(np.float32), (sf * sf).astype(np.float32)
 
 
+def adapter_timing(reps=60):
+    """the batched / resident matcher forms through the COMPILED C++ adaptor (adapter/ORBmatcher_batch.cc, ORBmatcher_bow.cc), timed by the
+    driver's own std::chrono clock around each adaptor call: map-point flags under the keyframe's accessors, FeatureVector flatten (host-pointer
+    forms), epipoles, the ABI call and the mapping of the indices back to MapPoint* -- what ORB-SLAM2's threads would see.  Scene: the 1005
+    left-eye features of a synthetic KITTI-shape frame and 20 derived keyframes over a 100-node vocabulary rule (tests/adapter_driver.cc, mode
+    `batch`; tests/test_adapter.py::test_adapter_batched_resident_matchers compares every result of that mode with the oracle)."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "examples", "adapter_bench")
+    if not os.path.exists(exe):
+        return {"error": "examples/adapter_bench not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    w, h = 1241, 376
+    left, right, _ = synth.stereo_pair(616, w, h)
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "in.bin"), os.path.join(td, "out.txt")
+        with open(inp, "wb") as f:
+            f.write(np.array([w, h], np.int32).tobytes()); f.write(left.tobytes()); f.write(right.tobytes())
+        run = subprocess.run([exe, "batch", inp, outp, str(reps)], capture_output=True, text=True, timeout=300)
+        if run.returncode != 0:
+            return {"error": (run.stderr or run.stdout)[-300:]}
+        r = {}
+        for line in open(outp):
+            t = line.split(None, 2)
+            if t[0] in ("time_ns", "time_reps", "features", "single_equals_batch", "after_drop_equal"):
+                r[t[0]] = [int(v) for v in t[2].split()]
+    t = r["time_ns"]
+    nk = 20
+    return {"unit": "us, median of %d adaptor calls, std::chrono inside the C++ driver" % r["time_reps"][0], "features_per_keyframe": r["features"][0], "pairs_per_batch": nk,
+            "batch_us_per_pair": {"SearchForTriangulationBatch (LocalMapping::CreateNewMapPoints)": round(t[0] / 1e3 / nk, 2),
+                                  "SearchByBoWBatch(KF, KFs) (LoopClosing::ComputeSim3)": round(t[1] / 1e3 / nk, 2),
+                                  "SearchByBoWBatch(KFs, F) (Tracking::Relocalization)": round(t[2] / 1e3 / nk, 2)},
+            "single_resident_us": {"SearchForTriangulation": round(t[3] / 1e3, 1), "SearchByBoW(KF, KF)": round(t[4] / 1e3, 1)},
+            "single_host_pointers_us": {"SearchForTriangulation": round(t[5] / 1e3, 1), "SearchByBoW(KF, KF)": round(t[6] / 1e3, 1), "SearchByBoW(KF, F)": round(t[7] / 1e3, 1)},
+            "single_pair_adaptors_equal_batch": bool(r["single_equals_batch"][0] and r["after_drop_equal"][0])}
+
+
 def _median_us(fn, reps, warm=5):
     for _ in range(warm):
         fn()
@@ -187,6 +223,10 @@ def measure(pkg, oracle_py=None, reps=200, cpu_reps=40, nbatch=20, device=0):
         same = same and np_g == np_o and bool((pairs[:np_g] == o_pairs[:np_o]).all())
         res["verified"] = same
         res["gpu_over_cpu"] = {k: round(res["gpu"][k] / res["cpu_oracle"][k], 2) for k in gpu}
+    try:
+        res["adapter_us"] = adapter_timing()
+    except Exception as exc:      # measurement leg only
+        res["adapter_us"] = {"error": str(exc)[:300]}
     return res
 
 
