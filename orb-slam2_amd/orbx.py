@@ -99,6 +99,7 @@ def lib():
     L.orbx_kf_size.argtypes = [vp]
     L.orbx_kf_search_by_bow_kf_f.argtypes = [vp, vp, vp, f, i, vp, ip]
     L.orbx_kf_search_by_bow_kf_kf.argtypes = [vp, vp, vp, vp, i, f, i, vp, vp]
+    L.orbx_kf_search_by_bow_kfs_f.argtypes = [vp, vp, i, FS, f, i, vp, vp]
     L.orbx_kf_search_for_triangulation.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, i, i, i, vp, i, vp]
     L.orbx_bowdb_create.argtypes = [i, FS, i, C.POINTER(vp)]
     L.orbx_bowdb_search.argtypes = [vp, FS, f, i, vp, vp]
@@ -648,6 +649,19 @@ class ORBmatcher:
         out = np.full(frame.n, -1, np.int32); n = C.c_int()
         _check(lib().orbx_kf_search_by_bow_kf_f(kf._h, _p(fl), frame._h, self.mfNNratio, int(self.mbCheckOrientation), _p(out), C.byref(n)))
         return out, n.value
+
+    def SearchByBoWKeyFramesFrameResident(self, kfs, kf_flags, frame):
+        """Tracking::Relocalization's loop (src/Tracking.cc:1661-1682) as one call: SearchByBoW(pKF, F) for every resident keyframe of `kfs`
+        against one frame given as a host feature set (dict) -> (match_f[nkf][nF], nmatches[nkf])"""
+        if len(kf_flags) != len(kfs):
+            raise OrbxError(-1, "SearchByBoWKeyFramesFrameResident: one flag array per keyframe")
+        fl = [_flags_for(x, k, "SearchByBoWKeyFramesFrameResident") for x, k in zip(kf_flags, kfs)]
+        hs = (C.c_void_p * len(kfs))(*[k._h for k in kfs])
+        fp = (C.c_void_p * len(kfs))(*[x.ctypes.data for x in fl])
+        fs, keep = make_featset(frame)
+        out = np.full((len(kfs), fs.n), -1, np.int32); n = np.zeros(len(kfs), np.int32)
+        _check(lib().orbx_kf_search_by_bow_kfs_f(hs, fp, len(kfs), C.byref(fs), self.mfNNratio, int(self.mbCheckOrientation), _p(out), _p(n)))
+        return out, n
 
     def SearchByBoWKeyFramesResident(self, kf1, flag1, kfs2, flags2):
         f1 = _flags_for(flag1, kf1, "SearchByBoWKeyFramesResident")

@@ -140,6 +140,10 @@ def test_resident_keyframes(pkg, oracle):
             g, c = m.SearchByBoWResident(dk[i], kf["flag"], dcur)
             e, ec = oracle.search_by_bow_kf_f(kf, cur, 0.75, True)
             assert c == ec and (g == e).all(), (rnd, i)
+        g, c = m.SearchByBoWKeyFramesFrameResident(dk, [k["flag"] for k in kfs], cur)     # Tracking::Relocalization's loop as one call
+        for i, kf in enumerate(kfs):
+            e, ec = oracle.search_by_bow_kf_f(kf, cur, 0.75, True)
+            assert c[i] == ec and (g[i] == e).all(), (rnd, i)
         g, c = m.SearchByBoWKeyFramesResident(dcur, cur["flag"], dk, [k["flag"] for k in kfs])
         for i, kf in enumerate(kfs):
             e, ec = oracle.search_by_bow_kf_kf(cur, kf, 0.75, True)
