@@ -124,3 +124,47 @@ def test_stereo_match_batch_two_handles_offset(pkg, oracle):
     dl_h, dr_h, ur_h, dp_h = dsl.cpu().numpy(), dsr.cpu().numpy(), ur.cpu().numpy(), dp.cpu().numpy()
     for p in range(B):
         _compare("two handles", p, exp[p], int(nl_h[2 + p]), int(nr_h[1 + p]), kl_h[2 + p], dl_h[2 + p], kr_h[1 + p], dr_h[1 + p], ur_h[p], dp_h[p])
+
+
+def test_host_fed_batches_equal_oracle(pkg, oracle):
+    """bench.py's batched host-fed path (HostFedPipeline: pinned host images -> H2D on a copy stream under the previous batch's kernels -> extraction +
+    stereo match -> D2H of all results, four buffer sets going round): every frame of several consecutive batches with DIFFERENT contents, read from
+    the pinned result blocks, equals the oracle byte for byte -- a batch is neither computed from a half-uploaded image block nor overwritten
+    before it has been downloaded"""
+    import torch
+    import bench
+    W_, H_, NF, B = 640, 480, 800, 6
+    dev = torch.device("cuda", 0)
+    pipe = bench.HostFedPipeline(pkg, torch, dev, 0, W_, H_, NF, B, depth=4)
+    nb = 9                                              # more batches than buffer sets: every set is reused at least once
+    pairs = [synth.stereo_pair(700 + i, W_, H_)[:2] for i in range(5)]
+    oL, oR = oracle.Oracle(NF, 1.2, 8, 20, 7), oracle.Oracle(NF, 1.2, 8, 20, 7)
+    exp = []
+    for l, r in pairs:
+        kL, dL = oL.extract(l); kR, dR = oR.extract(r)
+        ur, dp = oracle.stereo_match(oL, oR, kL, dL, kR, dR, BF, MIN_Z)
+        exp.append((kL, dL, kR, dR, ur, dp))
+    pending = []
+    checked = 0
+
+    def check(j, which):
+        n, k, d, ur, dp = pipe.results(j)
+        for i, pi in enumerate(which):
+            kL, dL, kR, dR, our, odp = exp[pi]
+            nl, nr = int(n[i]), int(n[B + i])
+            assert nl == len(kL) and nr == len(kR), (which, i)
+            assert k[i, :nl].tobytes() == kL.tobytes() and d[i, :nl].tobytes() == dL.tobytes()
+            assert k[B + i, :nr].tobytes() == kR.tobytes() and d[B + i, :nr].tobytes() == dR.tobytes()
+            assert ur[i, :nl].tobytes() == our.tobytes() and dp[i, :nl].tobytes() == odp.tobytes()
+    for b in range(nb):
+        if len(pending) == pipe.depth:                  # the buffer set about to be refilled: collect its results first
+            j, which = pending.pop(0)
+            check(j, which); checked += 1
+        which = [(3 * b + i) % len(pairs) for i in range(B)]          # every batch a different mix of the pairs
+        hi = pipe.host_images(pipe.k % pipe.depth).numpy()
+        for i, pi in enumerate(which):
+            hi[i, :, :W_] = pairs[pi][0]; hi[B + i, :, :W_] = pairs[pi][1]
+        pending.append((pipe.submit(), which))
+    for j, which in pending:
+        check(j, which); checked += 1
+    assert checked == nb
