@@ -151,6 +151,10 @@ int orbx_extract_stereo(orbx_extractor *e, const uint8_t *img_left, const uint8_
  * Replaces the per-frame sequence of Frame::Frame(imLeft, imRight, ...) (src/Frame.cc:82-97) in the frame loop of
  * Examples/Stereo/stereo_kitti.cc:68-117. */
 int orbx_pipeline_depth(void);
+/* Makes and touches every pipeline slot and kernel lane of the pipelined forms for images of w x h by running one scratch frame through each
+ * (tens of milliseconds, once).  orbx_extract_stereo_submit does this by itself on the first frame of a size; a camera loop that wants that
+ * first frame on time as well (Examples/Stereo/stereo_kitti.cc:83-117 times every frame) calls it before the loop. */
+int orbx_pipeline_warm(orbx_extractor *e, int w, int h);
 int orbx_extract_stereo_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t *img_right, int w, int h, size_t stride,
                                float bf, float min_z, int *ticket);
 int orbx_extract_stereo_wait(orbx_extractor *e, int ticket, orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out,

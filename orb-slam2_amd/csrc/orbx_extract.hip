@@ -3312,6 +3312,43 @@ static int pipe_wait(orbx_extractor *e, int ticket, int eyes, orbx_keypoint *kps
     return ORBX_OK;
 }
 
+// Every pipeline slot and every kernel lane (the handle and its shadow handles: own stream, pyramid / candidate / quadtree / stereo workspaces,
+// pinned result block) of the pipelined forms is made and touched by running ONE frame of a textured scratch image through each, so that the
+// frames that follow all see the steady-state latency.  Called by the first submit of a handle (and again when the image size changes); a
+// caller that wants even its first frame on time calls it beforehand.  Round 3 made lanes and slots lazily, one per frame: the first four
+// frames of a stream -- inside any timed window -- took 3-19 ms each against 0.2 ms.
+extern "C" int orbx_pipeline_warm(orbx_extractor *e, int w, int h)
+{
+    if (!e || w < 1 || h < 1) { orbx_set_error("orbx_pipeline_warm: invalid argument"); return ORBX_E_INVALID; }
+    if (e->max_batch < 2) { orbx_set_error("orbx_pipeline_warm needs an extractor created with max_batch >= 2"); return ORBX_E_INVALID; }
+    if (e->pipe_warm_w == w && e->pipe_warm_h == h) return ORBX_OK;
+    for (const PipeSlot &s : e->pipe) if (s.busy) { orbx_set_error("orbx_pipeline_warm: frames are in flight"); return ORBX_E_INVALID; }
+    std::vector<uint8_t> img((size_t)w * h);
+    unsigned lcg = 2463534242u;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            lcg = lcg * 1664525u + 1013904223u;
+            img[(size_t)y * w + x] = (uint8_t)((((x >> 4) * 37 + (y >> 4) * 91) & 127) + 40 + (lcg >> 29));   // 16-px blocks: corners on every level
+        }
+    e->pipe_warm_w = w; e->pipe_warm_h = h;      // (set first: the submits below must not come back here)
+    const int need = orbx_max_keypoints(e, w, h);
+    int rc = need < 0 ? need : ORBX_OK;
+    std::vector<orbx_keypoint> kps(rc ? 0 : 2 * (size_t)need);
+    std::vector<uint8_t> desc(rc ? 0 : (size_t)64 * need);
+    std::vector<float> ur(rc ? 0 : (size_t)need), z(rc ? 0 : (size_t)need);
+    int tickets[ORBX_PIPE_DEPTH], n[2], nsub = 0;
+    for (int i = 0; i < ORBX_PIPE_DEPTH && !rc; i++) {          // one frame per slot; the lanes go round with the slots
+        rc = pipe_submit(e, img.data(), img.data(), 2, w, h, (size_t)w, 386.1448f, 0.5372f, &tickets[i]);
+        if (!rc) nsub++;
+    }
+    for (int i = 0; i < nsub; i++) {
+        const int wrc = pipe_wait(e, tickets[i], 2, kps.data(), desc.data(), need, n, ur.data(), z.data());
+        if (wrc && !rc) rc = wrc;
+    }
+    if (rc) { e->pipe_warm_w = 0; e->pipe_warm_h = 0; }
+    return rc;
+}
+
 extern "C" int orbx_extract_stereo_submit(orbx_extractor *e, const uint8_t *img_left, const uint8_t *img_right, int w, int h, size_t stride,
                                           float bf, float min_z, int *ticket)
 {
@@ -3320,6 +3357,11 @@ extern "C" int orbx_extract_stereo_submit(orbx_extractor *e, const uint8_t *img_
         return ORBX_E_INVALID;
     }
     if (e->max_batch < 2) { orbx_set_error("orbx_extract_stereo_submit needs an extractor created with max_batch >= 2"); return ORBX_E_INVALID; }
+    if (e->pipe_warm_w != w || e->pipe_warm_h != h) {           // first frame of this size: make every lane and slot now, not one per frame
+        bool idle = true;
+        for (const PipeSlot &s : e->pipe) idle = idle && !s.busy;
+        if (idle) { const int wrc = orbx_pipeline_warm(e, w, h); if (wrc) return wrc; }
+    }
     return pipe_submit(e, img_left, img_right, 2, w, h, stride, bf, min_z, ticket);
 }
 

@@ -132,6 +132,7 @@ struct orbx_extractor {
     void *scratch[8]; size_t scratch_cap[8]; // host-API upload buffers
     // pipelined stereo frames: copies ride their own streams so that frame i+1 uploads and frame i-1 downloads while frame i computes
     PipeSlot pipe[ORBX_PIPE_DEPTH]; hipStream_t copy_in, copy_out; unsigned pipe_next;
+    int pipe_warm_w, pipe_warm_h;    // the image size every lane / slot of the pipelined forms has been run on once (orbx_pipeline_warm); 0 = none yet
     bool pipe_counted;               // this handle is counted in the process-wide number of pipelined handles
     orbx_extractor *lanes[ORBX_PIPE_DEPTH - 1];   // further kernel lanes of the pipelined forms (shadow handles with their own stream and
                                      // workspaces): submission i runs on lane i % pipe_lanes, so the launch chains of neighbouring frames

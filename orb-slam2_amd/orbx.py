@@ -75,6 +75,7 @@ def lib():
     L.orbx_extract_stereo_submit.argtypes = [vp, vp, vp, i, i, sz, f, f, ip]
     L.orbx_extract_stereo_wait.argtypes = [vp, i, vp, vp, i, vp, vp, vp]
     L.orbx_extract_submit.argtypes = [vp, vp, i, i, sz, ip]
+    L.orbx_pipeline_warm.argtypes = [vp, i, i]
     L.orbx_extract_wait.argtypes = [vp, i, vp, vp, i, vp]
     L.orbx_pinned_alloc.argtypes = [sz]; L.orbx_pinned_alloc.restype = vp
     L.orbx_pinned_free.argtypes = [vp]; L.orbx_pinned_free.restype = None
@@ -251,6 +252,10 @@ class ORBextractor:
     def set_pyramid_group_limit(self, max_images):
         """tuning only (results do not change): launches of at most max_images images build several pyramid levels per launch; 0 = never"""
         _check(self._L.orbx_extractor_set_pyramid_group_limit(self._h, int(max_images)))
+
+    def pipeline_warm(self, w, h):
+        """make and touch every pipeline slot / kernel lane of the pipelined forms for w x h images now (orbx_pipeline_warm)"""
+        _check(self._L.orbx_pipeline_warm(self._h, int(w), int(h)))
 
     def debug_fast_form(self):
         """1 = k_fast, 2 = k_fast2 (a pair of cells per wave) ran in the most recent extraction"""
