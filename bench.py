@@ -444,6 +444,8 @@ def run_workload(ctx, args):
         bow = {"db": pkg.BowDatabase(kfs, device=local), "voc": voc, "frames": frames_fs, "ms": 0.0, "tms": 0.0, "queries": 0, "matches": 0,
                "fr": pkg.BowFrames(NI, cap, device=local),
                "d_match": torch.zeros((NI, NKF, cap), dtype=torch.int32, device=dev), "d_nm": torch.zeros((NI, NKF), dtype=torch.int32, device=dev),
+               # compact result form (orbx_bowdb_search_batch_device_compact): per (frame, keyframe) the (frame feature, keyframe feature) pairs
+               "cap_pairs": cap, "d_pairs": torch.zeros((NI, NKF, cap, 2), dtype=torch.int32, device=dev), "compact": not args.bow_dense,   # (capacity = every feature: a list is never cut; only the matches are written)
                "kfs": kfs, "vocab_arrays": (par, leaf, nd, wt),
                "ev": [], "host_path": args.bow_host_path, "kf_feats": int(sum(len(k_["desc"]) for k_ in kfs)),
                "kf_list": int(sum(len(k_["feat"]) for k_ in kfs)), "kf_nodes": int(sum(len(k_["node_id"]) for k_ in kfs))}
@@ -461,7 +463,10 @@ def run_workload(ctx, args):
             e0.record(stream)
             bow["fr"].transform(bow["voc"], kps.data_ptr(), desc.data_ptr(), nout.data_ptr(), B, 4, sp)
             e1.record(stream)
-            bow["fr"].search(bow["db"], B, bow["d_match"].data_ptr(), bow["d_nm"].data_ptr(), 0.75, True, sp)
+            if bow["compact"]:
+                bow["fr"].search_compact(bow["db"], B, bow["d_pairs"].data_ptr(), bow["cap_pairs"], bow["d_nm"].data_ptr(), 0.75, True, sp)
+            else:
+                bow["fr"].search(bow["db"], B, bow["d_match"].data_ptr(), bow["d_nm"].data_ptr(), 0.75, True, sp)
             e2.record(stream)
             bow["ev"].append((e0, e1, e2))
             bow["queries"] += B
@@ -541,7 +546,17 @@ def run_workload(ctx, args):
             bow_cpu = {"ovoc": ovoc, "kfs": bow["kfs"]}
             if not bow["host_path"]:
                 nkc, nfc = NKF, min(B, 4)          # EVERY keyframe of the map (config 3: all 500) x the first four frames of the launch
-                dm = bow["d_match"][:nfc, :nkc].cpu().numpy(); dn = bow["d_nm"][:nfc, :nkc].cpu().numpy()
+                # both result forms of the last launch's inputs: the timed one as it stands, the other from one more (untimed) launch
+                dn_c = dn_d = None
+                if bow["compact"]:
+                    dn_c = bow["d_nm"][:nfc, :nkc].cpu().numpy().copy(); dpairs = bow["d_pairs"][:nfc, :nkc].cpu().numpy()
+                    bow["fr"].search(bow["db"], B, bow["d_match"].data_ptr(), bow["d_nm"].data_ptr(), 0.75, True, sp); stream.synchronize()
+                    dn_d = bow["d_nm"][:nfc, :nkc].cpu().numpy().copy()
+                else:
+                    dn_d = bow["d_nm"][:nfc, :nkc].cpu().numpy().copy()
+                    bow["fr"].search_compact(bow["db"], B, bow["d_pairs"].data_ptr(), bow["cap_pairs"], bow["d_nm"].data_ptr(), 0.75, True, sp); stream.synchronize()
+                    dn_c = bow["d_nm"][:nfc, :nkc].cpu().numpy().copy(); dpairs = bow["d_pairs"][:nfc, :nkc].cpu().numpy()
+                dm = bow["d_match"][:nfc, :nkc].cpu().numpy(); dn = dn_d
                 badp = []
                 same_fv = []
                 for kq in range(nkc):               # the keyframes' FeatureVectors re-derived by the oracle, once each
@@ -554,10 +569,14 @@ def run_workload(ctx, args):
                     q = dict(desc=od_, node_id=t["fv_node_id"], node_off=t["fv_node_off"], feat=t["fv_feat"], flag=np.zeros(len(od_), np.uint8), angle=ok_["angle"].copy())
                     for kq in range(nkc):
                         exp, en = oracle_py.search_by_bow_kf_f(bow["kfs"][kq], q, 0.75, True)
-                        if not (same_fv[kq] and en == int(dn[f, kq]) and np.array_equal(dm[f, kq, :len(exp)], exp)):
+                        slots = np.nonzero(exp >= 0)[0]
+                        nc_ = int(dn_c[f, kq])
+                        ok_compact = nc_ == en and nc_ <= bow["cap_pairs"] and np.array_equal(dpairs[f, kq, :nc_, 0], slots) and np.array_equal(dpairs[f, kq, :nc_, 1], exp[slots])
+                        if not (same_fv[kq] and en == int(dn[f, kq]) and np.array_equal(dm[f, kq, :len(exp)], exp) and ok_compact):
                             badp.append((f, kq))
-                verified["bow"] = {"pairs_checked": nfc * nkc, "what": f"search rows of keyframes 0..{nkc - 1} x frames 0..{nfc - 1} of the last launch, and those keyframes' FeatureVectors, "
-                                                                      "against oracle ComputeBoW + SearchByBoW", "mismatching_pairs": badp[:8]}
+                verified["bow"] = {"pairs_checked": nfc * nkc, "what": f"search results of keyframes 0..{nkc - 1} x frames 0..{nfc - 1} of the last launch in BOTH forms (dense rows and compact (frame feature, keyframe feature) lists), "
+                                                                      "and those keyframes' FeatureVectors, against oracle ComputeBoW + SearchByBoW", "timed_form": "compact" if bow["compact"] else "dense",
+                                       "mismatching_pairs": badp[:8]}
                 verified["bit_exact"] = verified["bit_exact"] and not badp
 
     # dominant kernel + roofline (per launch: total stage time / launches; resize = 7 launches per step)
@@ -581,8 +600,10 @@ def run_workload(ctx, args):
             # `per_pair_model_bytes` for comparison.
             frame_side = B * nkp_avg * (32 + 1 + 4 + 4) + B * 100 * 8
             map_side = bow["kf_list"] * 33 + bow["kf_nodes"] * 8 + bow["kf_feats"] * 4
-            bytes_per_launch = map_side + frame_side + NKF * B * 4 * nkp_avg
-            bow_models = {"compulsory_bytes": int(bytes_per_launch), "of_which_match_rows_out": int(NKF * B * 4 * nkp_avg),
+            # results out: dense = one int32 row per pair; compact = 8 bytes per match + the count
+            out_bytes = NKF * B * 4 * nkp_avg if not bow["compact"] else 8 * bow["matches"] / len(bow["ev"]) + 4 * NKF * B
+            bytes_per_launch = map_side + frame_side + out_bytes
+            bow_models = {"compulsory_bytes": int(bytes_per_launch), "of_which_results_out": int(out_bytes), "result_form": "compact" if bow["compact"] else "dense",
                           "per_pair_model_bytes": int(NKF * B * (32 + 4 + 1 + 4) * 2 * nkp_avg + NKF * B * 4 * nkp_avg)}
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # HBM bytes per launch from the rocprofv3 PMC passes (tools/collect_pmc.py): a committed file, not this run -- stamped with its
@@ -634,7 +655,8 @@ def run_workload(ctx, args):
                 "mono": f"mono {W}x{H}, nFeatures={NFEAT}, 8 levels, FAST 20/7: extract only",
                 "bow": f"mono {W}x{H}, nFeatures={NFEAT}: extract + ComputeBoW (synthetic k=10 L=6 vocabulary on device) + SearchByBoW(ratio 0.75, "
                        f"checkOri) of every frame against a device-resident {NKF}-keyframe synthetic map; device-resident chain "
-                       "(orbx_bow_transform_batch_device -> orbx_bowdb_search_batch_device), matches stay in HBM"}[kind]
+                       "(orbx_bow_transform_batch_device -> orbx_bowdb_search_batch_device[_compact]), matches stay in HBM as " +
+                       ("dense match rows" if args.bow_dense else "compact (frame feature, keyframe feature) lists, what Tracking::Relocalization hands to its PnP solver")}[kind]
     out = {"metric": metric, "value": round(value, 2),
            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
@@ -799,6 +821,7 @@ def main():
                     help="stereo1000 is the BASELINE.json headline metric; the others are the remaining single-GPU configs")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames of the CPU-baseline sample (0 = skip; default 240 stereo / 6 otherwise)")
     ap.add_argument("--bow-host-path", action="store_true", help="euroc_bow: per-frame host-pointer ComputeBoW + search (round-1 form)")
+    ap.add_argument("--bow-dense", action="store_true", help="BoW workloads: time the dense match rows instead of the compact (frame feature, keyframe feature) lists")
     ap.add_argument("--keyframes", type=int, default=0, help="BoW workloads: keyframes of the synthetic map (0 = 500; euroc_track: 1)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs / images (tiled to the batch)")
     ap.add_argument("--extras", type=int, default=1, help="0 = only the timed headline region (profiling runs): no batch sweep, host-fed, other-config or matcher legs")

@@ -369,6 +369,11 @@ int orbx_bow_frames_read(orbx_bow_frames *f, int index, void *stream, uint32_t *
  * d_nmatches[batch][nkf], both device memory; asynchronous on `stream`. */
 int orbx_bowdb_search_batch_device(orbx_bowdb *db, const orbx_bow_frames *f, int batch, float nnratio, int check_orientation,
                                    void *d_match, void *d_nmatches, void *stream);
+/* The same search with compact results: d_pairs[batch][nkf][cap_pairs][2] int32 receives, per (frame, keyframe), the first
+ * min(count, cap_pairs) matches as (frame feature, keyframe feature) in frame-feature order -- what Tracking::Relocalization hands to its PnP
+ * solver next (src/Tracking.cc:1682-1693) -- and d_nmatches[batch][nkf] the counts (a count above cap_pairs says the list was cut). */
+int orbx_bowdb_search_batch_device_compact(orbx_bowdb *db, const orbx_bow_frames *f, int batch, float nnratio, int check_orientation,
+                                           void *d_pairs, int cap_pairs, void *d_nmatches, void *stream);
 
 typedef struct {
     int n;

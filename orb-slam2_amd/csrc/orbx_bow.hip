@@ -108,6 +108,9 @@ extern __shared__ __align__(16) unsigned char bow_smem[];
 #define BOW_MATCAP 8192
 #endif
 #define BOW_DCLAMP 253
+#ifndef BOW_P1_UNROLL
+#define BOW_P1_UNROLL 4      // second-side descriptors in flight per thread in the distance phase
+#endif
 #define BOW_CHUNK 256
 
 template <int MODE>
@@ -203,37 +206,74 @@ extern "C" int orbx_diag_bow_stats(unsigned long long *out, int reset)
 #define BOW_STAT(i, v) do { } while (0)
 #endif
 
+// ---------------------------------------------------------------- k_bow2: the throughput form without a distance table (round 4)
+// Counters of k_bow on config 3 (profiles/r04_sq_bow_before.txt): 6100 VALU wave-instructions per wave, 71 % VALU busy -- NOT latency-bound as
+// rounds 2-3 believed: a third of them in the fixpoint's walks over whole table rows (one byte and one `own` word per column, per row, per
+// round), the rest in the distance phase and its bookkeeping.  What the greedy walk of a node needs from a first-side row is its best and
+// second-best column among those no EARLIER row holds; claims only ever REMOVE columns, so
+//   * a row whose smallest distance fails the TH_LOW test can never match: it leaves the fixpoint at once;
+//   * the three smallest keys (distance << 16 | column, first column wins ties as the reference's strict `<` does) decide the row whenever
+//     at least two of them are free -- and even with one free, when best1 < nnratio * d3 already holds (best2 >= d3);
+//   * only the rest (two of the top three taken AND the ratio test open) walks the node's columns again, straight from global memory.
+// So the distance phase keeps three keys per row in REGISTERS (thread t owns rows t, t + 256, ...), there is no table, hence no passes over
+// a pair (one pass per 1024 first-side rows instead of one per 8192 table entries: 2.1 -> 1.0 passes per 1000 x 1000 pair), no clamped byte
+// distances (exact for every nnratio) and 19 KB of LDS per workgroup instead of 25.  The match row lives in LDS until the pair is done and
+// leaves either as the dense row (coalesced, written once: it used to be initialised, scattered into and filtered in global memory) or as
+// the compact list of (slot, value) pairs in slot order that Tracking::Relocalization hands to its PnP solver next (src/Tracking.cc:1682-1693).
+#ifndef BOW2_ROWS
+#define BOW2_ROWS 1024                          // first-side rows per pass: BOW2_RPT per thread
+#endif
+#define BOW2_RPT (BOW2_ROWS / 256)
+#define BOW2_SENT 0x0100FFFFu                   // "no column": distance 256, column 0xFFFF -- above every real key
+
+// the rare full walk of a row: best / second best among the columns no earlier row of the node holds (own: tag << 16 | earliest row)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a, const DevFeat *__restrict__ sides_b,
-                                            int b_shared, float nnratio, int check_ori, int32_t *__restrict__ match_out,
-                                            int match_stride, int *__restrict__ nmatches)
+__device__ __noinline__ void bow2_row_scan(const DevFeat &A, const DevFeat &B, long long pa, long long pb0, int bcn, const unsigned *own, int boff,
+                                           unsigned r, unsigned tag, int *best1, int *best2, int *bj)
+{
+    uint32_t da[8];
+    load_desc(A.sdesc, pa, da);
+    int b1 = 256, b2 = 256, j1 = -1;
+    for (int j = 0; j < bcn; j++) {
+        if (MODE == 1 && !B.sflag[pb0 + j]) continue;
+        const unsigned v = own[boff + j];
+        if ((v >> 16) == tag && (v & 0xFFFFu) < r) continue;
+        uint32_t db[8];
+        load_desc(B.sdesc, pb0 + j, db);
+        const int d = hamming256(da, db);
+        if (d < b1) { b2 = b1; b1 = d; j1 = j; } else if (d < b2) b2 = d;
+    }
+    *best1 = b1; *best2 = b2; *bj = j1;
+}
+
+// OUT 0: match_out = dense rows [frame][pair][match_stride]; OUT 1: match_out = compact lists [frame][pair][2 * match_stride] of (slot, value)
+// in slot order, the first min(count, match_stride) of them; nmatches[frame][pair] = count either way
+template <int MODE, int OUT>
+__global__ __launch_bounds__(256) void k_bow2(const DevFeat *__restrict__ sides_a, const DevFeat *__restrict__ sides_b,
+                                             int b_shared, float nnratio, int check_ori, int32_t *__restrict__ match_out,
+                                             int match_stride, int *__restrict__ nmatches)
 {
     __shared__ int hist[BOW_HISTO];
     __shared__ int keep3[3];
     __shared__ int s_cnt;
     __shared__ int s_w[4];
     __shared__ int s_npass, s_nfall;
-    // node tables of the current chunk (compacted: shared nodes only), filled in node order
-    __shared__ int c_aoff[BOW_CHUNK], c_boff[BOW_CHUNK], c_moff[BOW_CHUNK], c_roff[BOW_CHUNK];
-    __shared__ unsigned c_cnt[BOW_CHUNK];            // a_cnt | b_cnt << 16
-    __shared__ unsigned c_inv[BOW_CHUNK];            // ceil(2^32 / b_cnt)
-    __shared__ uint16_t pass_first[BOW_CHUNK + 1], pass_total[BOW_CHUNK], pass_rows[BOW_CHUNK];
+    __shared__ int c_aoff[BOW_CHUNK], c_boff[BOW_CHUNK], c_roff[BOW_CHUNK];      // node tables of the chunk (shared nodes only, node order)
+    __shared__ unsigned c_cnt[BOW_CHUNK];                                         // a_cnt | b_cnt << 16
+    __shared__ uint16_t pass_first[BOW_CHUNK + 1], pass_rows[BOW_CHUNK];
     __shared__ uint16_t fall_list[BOW_CHUNK];
-    __shared__ uint16_t choice[BOW_ROWCAP];          // per first-side row of the pass: chosen position in its node or 0xFFFF
-    __shared__ uint8_t row_node[BOW_ROWCAP];         // per row: its (compacted) node, 0..255 inside the chunk
-    __shared__ uint8_t node_dirty[2][BOW_CHUNK];     // per node: a row of it changed its choice in the previous / this round
-    // grid.y = query frame of a batched (KF set) x (frames) search (1 otherwise)
+    __shared__ uint16_t choice[BOW2_ROWS];         // per first-side row of the pass: chosen column of its node or 0xFFFF
+    __shared__ uint8_t row_node[BOW2_ROWS];
+    __shared__ uint8_t node_dirty[2][BOW_CHUNK];
     const int pair = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const DevFeat A = sides_a[pair];
     const DevFeat B = sides_b[b_shared ? frame : pair];
     const int nslots = MODE == 0 ? B.n : A.n;
-    const int mB = B.nnodes ? B.node_off[B.nnodes] : 0; // length of the second side's feature list (<= B.n)
-    uint8_t *claimed = bow_smem;                 // [B.n]   (wave fallback only)
-    uint8_t *bins = bow_smem + ((B.n + 15) & ~15); // [nslots]
-    unsigned *own = reinterpret_cast<unsigned *>(bins + ((nslots + 15) & ~15)); // [B.n] earliest row choosing a list position
-    uint8_t *mat = reinterpret_cast<uint8_t *>(own + ((B.n + 3) & ~3));          // [BOW_MATCAP]
-    int32_t *match = match_out + ((long long)frame * gridDim.x + pair) * match_stride;
-    nmatches += (long long)frame * gridDim.x;
+    const int mB = B.nnodes ? B.node_off[B.nnodes] : 0;
+    uint8_t *claimed = bow_smem;                                                   // [B.n]   (wave fallback only)
+    uint8_t *bins = bow_smem + ((B.n + 15) & ~15);                                 // [nslots]
+    unsigned *own = reinterpret_cast<unsigned *>(bins + ((nslots + 15) & ~15));    // [B.n] per list position: round tag << 16 | earliest row choosing it
+    int32_t *match = reinterpret_cast<int32_t *>(own + ((B.n + 3) & ~3));          // [nslots] the pair's match row, in LDS until the end
     for (int i = tid; i < B.n; i += 256) claimed[i] = 0;
     for (int i = tid; i < nslots; i += 256) { bins[i] = 255; match[i] = -1; }
     __syncthreads();
@@ -248,39 +288,28 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
                 bo = B.node_off[ib]; bc = B.node_off[ib + 1] - bo;
             }
         }
-        const long long pcl = (long long)ac * bc;
-        const bool shared = pcl > 0;
-        const bool big = shared && (pcl > BOW_MATCAP || ac > BOW_ROWCAP || bc > 0xFFFF);
+        const bool shared = ac > 0 && bc > 0;
+        const bool big = shared && (ac > BOW2_ROWS || bc >= 0xFFFF);
         const bool tab = shared && !big;
-        int ncomp, nbig, tot, rows_tot;
+        int ncomp, nbig, rows_tot;
         const int k = block_excl_scan256(tab ? 1 : 0, &ncomp, s_w);
         const int kb = block_excl_scan256(big ? 1 : 0, &nbig, s_w);
-        const int mo = block_excl_scan256(tab ? (int)pcl : 0, &tot, s_w);
         const int ro = block_excl_scan256(tab ? ac : 0, &rows_tot, s_w);
-        if (tab) {
-            c_aoff[k] = ao; c_boff[k] = bo; c_cnt[k] = (unsigned)ac | ((unsigned)bc << 16);
-            c_inv[k] = (unsigned)((0x100000000ull + (unsigned)bc - 1) / (unsigned)bc);
-            c_moff[k] = mo; c_roff[k] = ro; // chunk-relative; made pass-relative below when the chunk needs several passes
-        }
-        if (big) fall_list[kb] = (uint16_t)tid; // node index inside the chunk
+        if (tab) { c_aoff[k] = ao; c_boff[k] = bo; c_cnt[k] = (unsigned)ac | ((unsigned)bc << 16); c_roff[k] = ro; }
+        if (big) fall_list[kb] = (uint16_t)tid;
         __syncthreads();
-        if (tot <= BOW_MATCAP && rows_tot <= BOW_ROWCAP) { // the usual case: one pass, offsets straight from the scans
-            if (tid == 0) {
-                s_npass = ncomp ? 1 : 0; pass_first[0] = 0; pass_first[1] = ncomp; pass_total[0] = tot; pass_rows[0] = rows_tot;
-                s_nfall = nbig;
-            }
-        } else if (tid == 0) {                    // pack the nodes, in order, into passes
-            int np = 0, off = 0, roff = 0;
+        if (rows_tot <= BOW2_ROWS) {               // the usual case: the chunk is one pass
+            if (tid == 0) { s_npass = ncomp ? 1 : 0; pass_first[0] = 0; pass_first[1] = (uint16_t)ncomp; pass_rows[0] = (uint16_t)rows_tot; s_nfall = nbig; }
+        } else if (tid == 0) {                     // more than BOW2_ROWS listed first-side rows in 256 nodes: pack the nodes, in order, into passes
+            int np = 0, roff = 0;
             pass_first[0] = 0;
             for (int q = 0; q < ncomp; q++) {
-                const int an = (int)(c_cnt[q] & 0xFFFF), pc = an * (int)(c_cnt[q] >> 16);
-                if (off + pc > BOW_MATCAP || roff + an > BOW_ROWCAP) {
-                    pass_total[np] = off; pass_rows[np] = roff; np++; pass_first[np] = q; off = 0; roff = 0;
-                }
-                c_moff[q] = off; c_roff[q] = roff;
-                off += pc; roff += an;
+                const int an = (int)(c_cnt[q] & 0xFFFF);
+                if (roff + an > BOW2_ROWS) { pass_rows[np] = (uint16_t)roff; np++; pass_first[np] = (uint16_t)q; roff = 0; }
+                c_roff[q] = roff;
+                roff += an;
             }
-            pass_total[np] = off; pass_rows[np] = roff; np++; pass_first[np] = ncomp;
+            pass_rows[np] = (uint16_t)roff; np++; pass_first[np] = (uint16_t)ncomp;
             s_npass = np; s_nfall = nbig;
         }
         __syncthreads();
@@ -288,98 +317,116 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
         BOW_STAT(2, npass); BOW_STAT(3, nfall); BOW_STAT(4, base == 0);
         for (int ps = 0; ps < npass; ps++) {
             const int q0 = pass_first[ps], q1 = pass_first[ps + 1], rows = pass_rows[ps];
-            // ---- phase 1: every distance of the pass, one (node, a, b) triple per thread, four in flight.  Descriptors and
-            // flags are read from the copies stored in LIST order (sdesc / sflag): the triples of neighbouring lanes touch
-            // neighbouring 32-byte records (4 per cache line) instead of 64 unrelated lines per load instruction, and no
-            // feature index has to be fetched first.
-#ifdef ORBX_DIAG
-            unsigned long long _tb0 = __builtin_amdgcn_s_memtime();
-#endif
-            for (int q = q0 + wv; q < q1; q += 4) { // the node of every row, for phase 2
+            for (int q = q0 + wv; q < q1; q += 4) { // the node of every row
                 const int acn = (int)(c_cnt[q] & 0xFFFF), rb = c_roff[q];
                 for (int i1 = lane; i1 < acn; i1 += 64) row_node[rb + i1] = (uint8_t)q;
             }
-            __syncthreads();                      // row_node is read below
-            // lane = first-side ROW of the pass: its descriptor is fetched once and stays in registers, the columns of its node are
-            // walked four at a time (independent loads in flight); neighbouring lanes are rows of the same node and read the same
-            // second-side descriptors (one request per distinct address).  (Until round 3 a lane took one (row, column) entry and
-            // found its node by binary search in the pass's offset table: six dependent LDS reads per distance, 80 % of the kernel.)
-            for (int r = tid; r < rows; r += 256) {
+            for (int i = tid; i < mB; i += 256) own[i] = 0xFFFFFFFFu;
+            node_dirty[0][tid] = 1; node_dirty[1][tid] = 0;
+            __syncthreads();
+            // ---- distances: thread t owns rows t, t + 256, ...: its descriptor once, the node's columns four at a time, the three smallest
+            // keys kept in registers.  alive = the row can still match (flagged, and its smallest distance passes the TH_LOW test)
+            unsigned K1[BOW2_RPT], K2[BOW2_RPT], K3[BOW2_RPT];
+            unsigned alive = 0, complete = 0;
+#pragma unroll
+            for (int u4 = 0; u4 < BOW2_RPT; u4++) {
+                K1[u4] = K2[u4] = K3[u4] = BOW2_SENT;
+                const int r = tid + 256 * u4;
+                if (r >= rows) continue;
+                choice[r] = 0xFFFF;
                 const int lo = row_node[r];
                 const int bcn = (int)(c_cnt[lo] >> 16), i1 = r - c_roff[lo];
                 const long long pa = c_aoff[lo] + i1, pb0 = c_boff[lo];
-                uint8_t *row = mat + c_moff[lo] + i1 * bcn;
-                if (!A.sflag[pa]) { row[0] = 0xFE; continue; }       // the row takes no part: phase 2 looks at row[0] only
+                if (!A.sflag[pa]) continue;                       // A.flag (:205-210 / :606-613)
                 uint32_t da[8];
                 load_desc(A.sdesc, pa, da);
+                unsigned k1 = BOW2_SENT, k2 = BOW2_SENT, k3 = BOW2_SENT;
+                int nv = 0;
                 for (int j0 = 0; j0 < bcn; j0 += 4) {
-                    unsigned code[4];
+                    unsigned key[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const int j = min(j0 + u, bcn - 1);
                         uint32_t db[8];
                         load_desc(B.sdesc, pb0 + j, db);
-                        const bool bcol = MODE == 1 ? B.sflag[pb0 + j] != 0 : true;
-                        code[u] = !bcol ? 0xFFu : (unsigned)min(hamming256(da, db), BOW_DCLAMP);
+                        const bool col = j0 + u < bcn && (MODE == 1 ? B.sflag[pb0 + j] != 0 : true);
+                        key[u] = col ? ((unsigned)hamming256(da, db) << 16) | (unsigned)j : BOW2_SENT;
+                        nv += col ? 1 : 0;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        if (j0 + u < bcn) row[j0 + u] = (uint8_t)code[u];
+                    for (int u = 0; u < 4; u++) {                  // sorted insertion into (k1 <= k2 <= k3)
+                        const unsigned t = max(k1, key[u]); k1 = min(k1, key[u]);
+                        const unsigned v = max(k2, t); k2 = min(k2, t);
+                        k3 = min(k3, v);
+                    }
                 }
+                const int d1 = (int)(k1 >> 16);
+                const bool can = MODE == 0 ? d1 <= BOW_TH_LOW : d1 < BOW_TH_LOW;     // claims only remove columns: best1 never gets smaller than this
+                if (can) alive |= 1u << u4;
+                if (nv <= 3) complete |= 1u << u4;
+                K1[u4] = k1; K2[u4] = k2; K3[u4] = k3;
             }
-            for (int r = tid; r < rows; r += 256) choice[r] = 0xFFFF;
-            node_dirty[0][tid] = 1; node_dirty[1][tid] = 0;
-            BOW_STAT(0, pass_total[ps]); BOW_STAT(5, rows);
+            BOW_STAT(5, rows);
             __syncthreads();
-#ifdef ORBX_DIAG
-            unsigned long long _tb1 = __builtin_amdgcn_s_memtime();
-            BOW_STAT(6, _tb1 - _tb0);
-#endif
-            // ---- phase 2: the greedy walk as a fixpoint over rows.  choice(r) = best second-side position of row r that no
-            // EARLIER row of its node currently holds (with the runner-up taken over the same candidates), accepted by
-            // the distance / ratio tests.  Row r only depends on rows before it, so iterating all rows in parallel
-            // until nothing changes reproduces the sequential walk (a round per link of the longest conflict chain).
+            // ---- the greedy walk as a fixpoint over rows (see k_bow): choice(r) = best column no EARLIER row of the node currently holds.
+            // own[] carries the round in its high half, so it is filled once per round and never cleared.
             for (int round = 0; round <= rows; round++) {
-                for (int i = tid; i < mB; i += 256) own[i] = 0xFFFFFFFFu;
-                __syncthreads();
-                for (int r = tid; r < rows; r += 256) {
+                const unsigned tag = 0xFFFEu - (unsigned)round;
+#pragma unroll
+                for (int u4 = 0; u4 < BOW2_RPT; u4++) {
+                    const int r = tid + 256 * u4;
+                    if (!((alive >> u4) & 1u) || r >= rows) continue;
                     const unsigned c = choice[r];
-                    if (c != 0xFFFF) atomicMin(&own[c_boff[row_node[r]] + (int)c], (unsigned)r);
+                    if (c != 0xFFFF) atomicMin(&own[c_boff[row_node[r]] + (int)c], (tag << 16) | (unsigned)r);
                 }
                 __syncthreads();
                 int changed = 0;
-                // a node none of whose rows changed in the previous round is settled: the columns its rows see taken are exactly
-                // the choices of that node's own earlier rows, so recomputing them returns the same choices (most nodes settle
-                // in the first two rounds; the rounds after that only walk the few that still move)
                 const uint8_t *was = node_dirty[round & 1];
                 uint8_t *now = node_dirty[(round & 1) ^ 1];
-                for (int r = tid; r < rows; r += 256) {
+#pragma unroll
+                for (int u4 = 0; u4 < BOW2_RPT; u4++) {
+                    const int r = tid + 256 * u4;
+                    if (!((alive >> u4) & 1u) || r >= rows) continue;
                     const int lo = row_node[r];
-                    if (!was[lo]) continue;
-                    const int bcn = (int)(c_cnt[lo] >> 16), boff = c_boff[lo];
-                    const uint8_t *row = mat + c_moff[lo] + (r - c_roff[lo]) * bcn;
-                    unsigned nc = 0xFFFF;
-                    if (row[0] != 0xFE) {            // A.flag (:205-210 / :606-613)
-                        int best1 = 256, best2 = 256, bj = -1;
-                        for (int j = 0; j < bcn; j++) {
-                            const int d = row[j];
-                            if (d == 0xFF || own[boff + j] < (unsigned)r) continue;
-                            if (d < best1) { best2 = best1; best1 = d; bj = j; } // first position wins ties (strict <)
-                            else if (d < best2) best2 = d;
-                        }
-                        const bool ok_dist = MODE == 0 ? best1 <= BOW_TH_LOW : best1 < BOW_TH_LOW;
-                        if (bj >= 0 && ok_dist && (float)best1 < nnratio * (float)best2) nc = (unsigned)bj;
+                    if (!was[lo]) continue;          // a node none of whose rows changed in the previous round is settled
+                    const int boff = c_boff[lo];
+                    const unsigned k1 = K1[u4], k2 = K2[u4], k3 = K3[u4];
+                    auto taken = [&](unsigned key) -> bool {
+                        if (key == BOW2_SENT) return false;
+                        const unsigned v = own[boff + (int)(key & 0xFFFFu)];
+                        return (v >> 16) == tag && (v & 0xFFFFu) < (unsigned)r;
+                    };
+                    const bool t1 = taken(k1), t2 = taken(k2), t3 = taken(k3);
+                    // the first two free keys of the top three; `open` = the second one lies beyond them
+                    unsigned b1, b2;
+                    bool have1 = true, open = false;
+                    if (!t1) { b1 = k1; if (!t2) b2 = k2; else if (!t3) b2 = k3; else { b2 = k3; open = true; } }
+                    else if (!t2) { b1 = k2; if (!t3) b2 = k3; else { b2 = k3; open = true; } }
+                    else if (!t3) { b1 = k3; b2 = k3; open = true; }
+                    else { b1 = b2 = BOW2_SENT; have1 = false; open = true; }
+                    const bool all_known = (complete >> u4) & 1u;      // the node has at most three columns: beyond the top three there is nothing
+                    int best1 = (int)(b1 >> 16), best2 = open ? (all_known ? 256 : (int)(k3 >> 16)) : (int)(b2 >> 16), bj = (int)(b1 & 0xFFFFu);
+                    if (!have1 && all_known) { best1 = 256; bj = -1; }
+                    bool decided = all_known || !open;
+                    if (!decided && have1) {
+                        // best2 >= d3: the ratio test already holds with d3, or the distance test already fails -> no need to know best2
+                        const bool okd = MODE == 0 ? best1 <= BOW_TH_LOW : best1 < BOW_TH_LOW;
+                        if (!okd || (float)best1 < nnratio * (float)(k3 >> 16)) { decided = true; best2 = okd ? 256 : best2; }
                     }
+                    if (!decided) {
+                        const int i1 = r - c_roff[lo];
+                        bow2_row_scan<MODE>(A, B, (long long)c_aoff[lo] + i1, (long long)boff, (int)(c_cnt[lo] >> 16), own, boff, (unsigned)r, tag, &best1, &best2, &bj);
+                    }
+                    unsigned nc = 0xFFFF;
+                    const bool ok_dist = MODE == 0 ? best1 <= BOW_TH_LOW : best1 < BOW_TH_LOW;
+                    if (bj >= 0 && best1 < 256 && ok_dist && (float)best1 < nnratio * (float)best2) nc = (unsigned)bj;
                     if (nc != choice[r]) { choice[r] = (uint16_t)nc; changed = 1; now[lo] = 1; }
                 }
                 BOW_STAT(1, 1);
                 if (!__syncthreads_or(changed)) break;
-                node_dirty[round & 1][tid] = 0;     // becomes the "this round" row of the round after next
+                node_dirty[round & 1][tid] = 0;
                 __syncthreads();
             }
-#ifdef ORBX_DIAG
-            BOW_STAT(7, __builtin_amdgcn_s_memtime() - _tb1);
-#endif
             // ---- results of the pass
             for (int r = tid; r < rows; r += 256) {
                 const unsigned c = choice[r];
@@ -392,7 +439,7 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
             }
             __syncthreads();
         }
-        // ---- nodes too large for the table: one wave each, straight from global memory
+        // ---- nodes with more rows than a pass holds (or 65535+ columns): one wave each, straight from global memory
         for (int f = wv; f < nfall; f += 4) {
             const int ja = base + fall_list[f];
             const int ib = find_node(B.node_id, B.nnodes, A.node_id[ja]);
@@ -403,7 +450,25 @@ __global__ __launch_bounds__(256) void k_bow(const DevFeat *__restrict__ sides_a
     }
     __threadfence_block();
     __syncthreads();
-    histogram_filter(match, bins, nslots, check_ori, hist, keep3, &s_cnt, nmatches + pair);
+    const long long pi = (long long)frame * gridDim.x + pair;
+    histogram_filter(match, bins, nslots, check_ori, hist, keep3, &s_cnt, nmatches + pi);
+    __syncthreads();
+    if (OUT == 0) {
+        int32_t *row = match_out + pi * match_stride;
+        for (int i = tid; i < nslots; i += 256) row[i] = match[i];
+    } else {
+        int32_t *lst = match_out + pi * 2 * (long long)match_stride;
+        int run = 0;
+        for (int i0 = 0; i0 < nslots; i0 += 256) {           // (slot, value) in slot order
+            const int i = i0 + tid;
+            const int v = i < nslots ? match[i] : -1;
+            int tot;
+            const int pos = run + block_excl_scan256(v >= 0 ? 1 : 0, &tot, s_w);
+            if (v >= 0 && pos < match_stride) { lst[2 * pos] = i; lst[2 * pos + 1] = v; }
+            run += tot;
+            __syncthreads();
+        }
+    }
 }
 
 // 0 = choose by size, 1 = always the wave form, 2 = always the table form (explicit debug entry point, no environment lookup)
@@ -419,20 +484,21 @@ int orbx_bow_forced_form() { return g_bow_form.load(std::memory_order_relaxed); 
 
 // pairs < BOW_TABLE_MIN_PAIRS: too few workgroups to fill 256 CUs, the 16-wave latency form is faster per call
 #define BOW_TABLE_MIN_PAIRS 4096
+// compact = 1: d_match receives (slot, value) lists of capacity `stride` pairs per (frame, pair) instead of dense rows of `stride` ints (k_bow2 only)
 template <int MODE>
 static int bow_launch(int npairs_x, int nframes_y, int max_b, int max_slots, hipStream_t st, const DevFeat *dA, const DevFeat *dB,
-                      int b_shared, float nnratio, int check_ori, int32_t *d_match, int stride, int *d_n)
+                      int b_shared, float nnratio, int check_ori, int32_t *d_match, int stride, int *d_n, int compact = 0)
 {
     const size_t base = (size_t)((max_b + 15) & ~15) + (size_t)((max_slots + 15) & ~15) + 16;
-    bool table = (long long)npairs_x * nframes_y >= BOW_TABLE_MIN_PAIRS;
+    bool table = (long long)npairs_x * nframes_y >= BOW_TABLE_MIN_PAIRS || compact;
     const int forced = g_bow_form.load(std::memory_order_relaxed); // orbx_debug_set_bow_form: the parity tests run both forms on small inputs
-    if (forced) table = forced == 2;
-    if (!(nnratio >= 0.2f)) table = false;     // the byte table clamps distances at 253: exact only while nnratio * 253 > TH_LOW
-    const size_t lds = table ? base + 4 * (size_t)((max_b + 3) & ~3) + BOW_MATCAP : base;
-    if (lds > 150 * 1024) { orbx_set_error("feature sets too large for LDS"); return ORBX_E_INVALID; }
+    if (forced && !compact) table = forced == 2;
+    const size_t lds = table ? base + 4 * (size_t)((max_b + 3) & ~3) + 4 * (size_t)((max_slots + 3) & ~3) : base;
+    if (lds > 120 * 1024) { orbx_set_error("feature sets too large for LDS"); return ORBX_E_INVALID; }
     if (table) {
-        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_bow<MODE>, dim3(npairs_x, nframes_y), dim3(256), lds, st, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
+        void (*kern)(const DevFeat *, const DevFeat *, int, float, int, int32_t *, int, int *) = compact ? k_bow2<MODE, 1> : k_bow2<MODE, 0>;
+        ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(npairs_x, nframes_y), dim3(256), lds, st, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
     } else {
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow_wave<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_bow_wave<MODE>, dim3(npairs_x, nframes_y), dim3(1024), lds, st, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
@@ -742,6 +808,22 @@ extern "C" int orbx_bowdb_search_batch_device(orbx_bowdb *db, const orbx_bow_fra
                                  (const DevFeat *)fr->d_feats, 1, nnratio, check_orientation, (int32_t *)d_match, fr->cap, (int *)d_nmatches);
     if (rc) return rc;
     return ORBX_OK;
+}
+
+// The same search with the result in the form its consumer reads: Tracking::Relocalization hands every candidate's matches to a PnP solver
+// that walks the non-null entries of vvpMapPointMatches[i] (src/Tracking.cc:1682-1693).  Per (frame, keyframe): the number of matches and
+// the first min(count, cap_pairs) (frame feature, keyframe feature) pairs in frame-feature order -- 0.8 KB written per pair where the dense
+// row is 4 KB (500 keyframes x 32 frames: 13 MB instead of 66 MB).
+extern "C" int orbx_bowdb_search_batch_device_compact(orbx_bowdb *db, const orbx_bow_frames *fr, int batch, float nnratio, int check_orientation,
+                                                      void *d_pairs, int cap_pairs, void *d_nmatches, void *stream)
+{
+    if (!db || !fr || !d_pairs || !d_nmatches || batch < 1 || batch > fr->batch || fr->device != db->device || cap_pairs < 1) {
+        orbx_set_error("orbx_bowdb_search_batch_device_compact: invalid argument");
+        return ORBX_E_INVALID;
+    }
+    ORBX_HIP(hipSetDevice(db->device));
+    return bow_launch<0>(db->nkf, batch, fr->cap, fr->cap, stream ? (hipStream_t)stream : fr->last_stream, (const DevFeat *)db->d_blob,
+                         (const DevFeat *)fr->d_feats, 1, nnratio, check_orientation, (int32_t *)d_pairs, cap_pairs, (int *)d_nmatches, 1);
 }
 
 // ---------------------------------------------------------------- MapPoint::ComputeDistinctiveDescriptors (f3)

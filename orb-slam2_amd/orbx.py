@@ -123,6 +123,7 @@ def lib():
     L.orbx_bow_transform_batch_device.argtypes = [vp, vp, vp, vp, vp, i, i, vp]
     L.orbx_bow_frames_read.argtypes = [vp, i, vp, vp, vp, ip, vp, vp, vp, ip]
     L.orbx_bowdb_search_batch_device.argtypes = [vp, vp, i, f, i, vp, vp, vp]
+    L.orbx_bowdb_search_batch_device_compact.argtypes = [vp, vp, i, f, i, vp, i, vp, vp]
     L.orbx_undistort_keypoints.argtypes = [i, vp, i, f, f, f, f, vp, i, vp]
     L.orbx_rectifier_create.argtypes = [i, i, i, i, i, vp, vp, C.POINTER(vp)]
     L.orbx_rectifier_destroy.argtypes = [vp]; L.orbx_rectifier_destroy.restype = None
@@ -585,6 +586,11 @@ class BowFrames:
     def search(self, db, batch, d_match, d_nmatches, nnratio=0.75, checkOri=True, stream=None):
         """every keyframe of a BowDatabase against frames 0..batch-1: d_match[batch][nkf][cap], d_nmatches[batch][nkf] (device)"""
         _check(self._L.orbx_bowdb_search_batch_device(db._h, self._h, batch, nnratio, int(checkOri), d_match, d_nmatches, stream))
+
+    def search_compact(self, db, batch, d_pairs, cap_pairs, d_nmatches, nnratio=0.75, checkOri=True, stream=None):
+        """the same search with compact results: d_pairs[batch][nkf][cap_pairs][2] int32 = (frame feature, keyframe feature) in frame-feature order,
+        d_nmatches[batch][nkf] = counts (orbx_bowdb_search_batch_device_compact)"""
+        _check(self._L.orbx_bowdb_search_batch_device_compact(db._h, self._h, batch, nnratio, int(checkOri), d_pairs, int(cap_pairs), d_nmatches, stream))
 
 
 class ORBmatcher:

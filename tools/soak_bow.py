@@ -45,7 +45,7 @@ while time.time() - t0 < budget:
         if keep.any():
             sel = np.concatenate([A["feat"][A["node_off"][i]:A["node_off"][i + 1]] for i in np.nonzero(keep)[0]])
             A = featset(len(sel), np.repeat(A["node_id"][keep], np.diff(A["node_off"])[keep]), A["desc"][sel], 0.8)
-    ratio = float(rng.choice([0.6, 0.75, 0.9, 1.0])); ori = bool(trial % 2)
+    ratio = float(rng.choice([0.1, 0.3, 0.6, 0.75, 0.9, 1.0])); ori = bool(trial % 2)
     e1, n1 = O.search_by_bow_kf_f(A, B, ratio, ori)
     e2, n2 = O.search_by_bow_kf_kf(A, B, ratio, ori)
     for form in ("table", "wave"):
