@@ -248,8 +248,11 @@ __device__ __noinline__ void bow2_row_scan(const DevFeat &A, const DevFeat &B, l
 
 // OUT 0: match_out = dense rows [frame][pair][match_stride]; OUT 1: match_out = compact lists [frame][pair][2 * match_stride] of (slot, value)
 // in slot order, the first min(count, match_stride) of them; nmatches[frame][pair] = count either way
+#ifndef BOW2_WPE
+#define BOW2_WPE 8      // registers capped at 64: eight workgroups per CU (their 19 KB of LDS allow it); 4 -> 8 waves per SIMD took the launch from 0.76 to 0.60 ms
+#endif
 template <int MODE, int OUT>
-__global__ __launch_bounds__(256) void k_bow2(const DevFeat *__restrict__ sides_a, const DevFeat *__restrict__ sides_b,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BOW2_WPE, 8))) void k_bow2(const DevFeat *__restrict__ sides_a, const DevFeat *__restrict__ sides_b,
                                              int b_shared, float nnratio, int check_ori, int32_t *__restrict__ match_out,
                                              int match_stride, int *__restrict__ nmatches)
 {
