@@ -2,7 +2,7 @@
 # -> gpurun_out/final_<tag>/ (bench lines, rocprofv3 kernel-trace stats, PMC traffic, SQ counters, the other kernels' trace, the B = 1
 # launch chain, the matcher stamps, the host-fed C client); tools/publish_profiles.py then copies the summaries into profiles/.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
@@ -26,5 +26,11 @@ tail -3 $OUT/sq.log | cut -c1-300
 for w in stereo2000 fhd4000 euroc_bow; do timeout -k 10 600 python bench.py --workload $w --steps 10 2> $OUT/$w.err | tail -1 > $OUT/$w.json; cat $OUT/$w.json | cut -c1-300; done
 python tools/matcher_bench.py 2>/dev/null > $OUT/matchers.json
 python tools/diag_match_stamps.py 2>&1 | grep total > $OUT/match_stamps.txt || true
-for n in 1 2 4; do ./examples/stereo_stream --streams $n --frames 1500 --nfeat 1000 | tail -1; done > $OUT/hostfed_c.txt
-cat $OUT/hostfed_c.txt | cut -c1-120
+for n in 1 2 4; do ./examples/stereo_stream --streams $n --frames 3000 --nfeat 1000 | tail -1; done > $OUT/hostfed_c.txt
+cat $OUT/hostfed_c.txt | cut -c1-160
+python tools/pcie_bw.py > $OUT/pcie_bw.txt 2>&1; python tools/hostfed_batched_diag.py 128 30 >> $OUT/pcie_bw.txt 2>&1; tail -12 $OUT/pcie_bw.txt
+# the N-rank line started WITHOUT a launcher (two ranks share the one GPU of the box: gloo rendezvous; the driver's 8-GPU run uses nccl = RCCL)
+ORBX_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 2 --batch 64 > $OUT/bench_2ranks_gloo.json 2> $OUT/bench_2ranks_gloo.err; cut -c1-200 $OUT/bench_2ranks_gloo.json
+# the pair form of k_fast (opt-in) beside the default on the same box: the negative result of round 4
+for p in 0 1; do ORBX_FAST_PAIR=$p python tools/ab_fast_only.py; done > $OUT/fast_pair_ab.txt 2>&1; cat $OUT/fast_pair_ab.txt
+bash tools/sq_bow.sh > $OUT/sq_bow.txt 2>&1; cat $OUT/sq_bow.txt | cut -c1-300

@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", f"final_{tag}")
 dst = os.path.join(ROOT, "profiles")
 
@@ -26,6 +26,9 @@ for name, out in (("bench_default.json", f"{tag}_z_bench_default.json"), ("bench
     p = os.path.join(src, name)
     if os.path.exists(p):
         json.dump(last_json_line(p), open(os.path.join(dst, out), "w"), indent=1)
+p2 = os.path.join(src, "bench_2ranks_gloo.json")
+if os.path.exists(p2) and os.path.getsize(p2):
+    json.dump(last_json_line(p2), open(os.path.join(dst, f"{tag}_z_bench_2ranks_gloo.json"), "w"), indent=1)
 stats = glob.glob(os.path.join(src, "prof", "*", "*kernel_stats.csv"))
 if stats:
     shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, f"{tag}_z_kernel_stats.csv"))   # the newest run
@@ -37,7 +40,8 @@ others = glob.glob(os.path.join(src, "prof_others", "*", "*kernel_stats.csv"))
 if others:
     shutil.copy(max(others, key=os.path.getmtime), os.path.join(dst, f"{tag}_other_kernels_stats.csv"))
 for name, out in (("b1_chain.txt", f"{tag}_b1_launch_chain.txt"), ("matcher_kernels.txt", f"{tag}_matcher_kernels.txt"), ("matchers.json", f"{tag}_z_matchers.json"),
-                  ("match_stamps.txt", f"{tag}_match_stamps.txt"), ("hostfed_c.txt", f"{tag}_hostfed_c.txt")):
+                  ("match_stamps.txt", f"{tag}_match_stamps.txt"), ("hostfed_c.txt", f"{tag}_hostfed_c.txt"), ("pcie_bw.txt", f"{tag}_pcie_and_hostfed_batched.txt"),
+                  ("fast_pair_ab.txt", f"{tag}_fast_pair_ab.txt"), ("sq_bow.txt", f"{tag}_sq_bow.txt")):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, out))
