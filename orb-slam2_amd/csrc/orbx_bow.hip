@@ -224,11 +224,14 @@ extern "C" int orbx_diag_bow_stats(unsigned long long *out, int reset)
 #define BOW2_ROWS 1024                          // first-side rows per pass: BOW2_RPT per thread
 #endif
 #define BOW2_RPT (BOW2_ROWS / 256)
+#ifndef BOW2_U
+#define BOW2_U 4                                // second-side descriptors in flight per thread in the distance phase
+#endif
 #define BOW2_SENT 0x0100FFFFu                   // "no column": distance 256, column 0xFFFF -- above every real key
 
 // the rare full walk of a row: best / second best among the columns no earlier row of the node holds (own: tag << 16 | earliest row)
 template <int MODE>
-__device__ __noinline__ void bow2_row_scan(const DevFeat &A, const DevFeat &B, long long pa, long long pb0, int bcn, const unsigned *own, int boff,
+__device__ __forceinline__ void bow2_row_scan(const DevFeat &A, const DevFeat &B, long long pa, long long pb0, int bcn, const unsigned *own, int boff,
                                            unsigned r, unsigned tag, int *best1, int *best2, int *bj)
 {
     uint32_t da[8];
@@ -249,7 +252,9 @@ __device__ __noinline__ void bow2_row_scan(const DevFeat &A, const DevFeat &B, l
 // OUT 0: match_out = dense rows [frame][pair][match_stride]; OUT 1: match_out = compact lists [frame][pair][2 * match_stride] of (slot, value)
 // in slot order, the first min(count, match_stride) of them; nmatches[frame][pair] = count either way
 #ifndef BOW2_WPE
-#define BOW2_WPE 8      // registers capped at 64: eight workgroups per CU (their 19 KB of LDS allow it); 4 -> 8 waves per SIMD took the launch from 0.76 to 0.60 ms
+#define BOW2_WPE 6      // registers capped at 80: six workgroups per CU.  4 (103 registers): 0.76 ms per 500 x 32 launch; 5: 0.64, no spills, 107 MB of
+                        // traffic; 6: 0.60 ms, three spilled dwords per thread (194 MB, 53 of them spill writes); 7 / 8: 0.60 / 0.59 ms with 8 / 17 spilled
+                        // dwords (340 / 580 MB): the time no longer moves, the scratch traffic does
 #endif
 template <int MODE, int OUT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BOW2_WPE, 8))) void k_bow2(const DevFeat *__restrict__ sides_a, const DevFeat *__restrict__ sides_b,
@@ -345,10 +350,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BOW2_WPE, 8
                 load_desc(A.sdesc, pa, da);
                 unsigned k1 = BOW2_SENT, k2 = BOW2_SENT, k3 = BOW2_SENT;
                 int nv = 0;
-                for (int j0 = 0; j0 < bcn; j0 += 4) {
-                    unsigned key[4];
+                for (int j0 = 0; j0 < bcn; j0 += BOW2_U) {
+                    unsigned key[BOW2_U];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < BOW2_U; u++) {
                         const int j = min(j0 + u, bcn - 1);
                         uint32_t db[8];
                         load_desc(B.sdesc, pb0 + j, db);
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BOW2_WPE, 8
                         nv += col ? 1 : 0;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {                  // sorted insertion into (k1 <= k2 <= k3)
+                    for (int u = 0; u < BOW2_U; u++) {             // sorted insertion into (k1 <= k2 <= k3)
                         const unsigned t = max(k1, key[u]); k1 = min(k1, key[u]);
                         const unsigned v = max(k2, t); k2 = min(k2, t);
                         k3 = min(k3, v);
@@ -384,6 +389,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BOW2_WPE, 8
                 }
                 __syncthreads();
                 int changed = 0;
+                unsigned need_scan = 0;
                 const uint8_t *was = node_dirty[round & 1];
                 uint8_t *now = node_dirty[(round & 1) ^ 1];
 #pragma unroll
@@ -416,14 +422,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BOW2_WPE, 8
                         const bool okd = MODE == 0 ? best1 <= BOW_TH_LOW : best1 < BOW_TH_LOW;
                         if (!okd || (float)best1 < nnratio * (float)(k3 >> 16)) { decided = true; best2 = okd ? 256 : best2; }
                     }
-                    if (!decided) {
-                        const int i1 = r - c_roff[lo];
-                        bow2_row_scan<MODE>(A, B, (long long)c_aoff[lo] + i1, (long long)boff, (int)(c_cnt[lo] >> 16), own, boff, (unsigned)r, tag, &best1, &best2, &bj);
-                    }
+                    if (!decided) { need_scan |= 1u << u4; continue; }      // (walked below, outside the unrolled code: keeps this path's registers low)
                     unsigned nc = 0xFFFF;
                     const bool ok_dist = MODE == 0 ? best1 <= BOW_TH_LOW : best1 < BOW_TH_LOW;
                     if (bj >= 0 && best1 < 256 && ok_dist && (float)best1 < nnratio * (float)best2) nc = (unsigned)bj;
                     if (nc != choice[r]) { choice[r] = (uint16_t)nc; changed = 1; now[lo] = 1; }
+                }
+                if (need_scan) {
+#pragma unroll 1
+                    for (int u4 = 0; u4 < BOW2_RPT; u4++) {
+                        if (!((need_scan >> u4) & 1u)) continue;
+                        const int r = tid + 256 * u4, lo = row_node[r], boff = c_boff[lo], i1 = r - c_roff[lo];
+                        int best1, best2, bj;
+                        bow2_row_scan<MODE>(A, B, (long long)c_aoff[lo] + i1, (long long)boff, (int)(c_cnt[lo] >> 16), own, boff, (unsigned)r, tag, &best1, &best2, &bj);
+                        unsigned nc = 0xFFFF;
+                        const bool ok_dist = MODE == 0 ? best1 <= BOW_TH_LOW : best1 < BOW_TH_LOW;
+                        if (bj >= 0 && best1 < 256 && ok_dist && (float)best1 < nnratio * (float)best2) nc = (unsigned)bj;
+                        if (nc != choice[r]) { choice[r] = (uint16_t)nc; changed = 1; now[lo] = 1; }
+                    }
                 }
                 BOW_STAT(1, 1);
                 if (!__syncthreads_or(changed)) break;
