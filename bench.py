@@ -6,9 +6,13 @@ Workload (config.workload): KITTI-shape stereo, 1241x376, ORBextractor.nFeatures
 ComputeStereoMatches.  A step = one batch of `--batch` frames (2*batch images in one set of
 launches); inputs are synthetic (tools/synth.py) and already resident in HBM when timing starts.
 
-`python bench.py --gpus N --steps K --warmup W`; for N>1 launch under torch.distributed.run (one
-rank per GPU, independent camera streams per GPU, RCCL only for the start/stop barrier and the
-MAX-reduction of the elapsed time) -> "scaling": "weak".
+`python bench.py --gpus N --steps K --warmup W`.  N > 1: one rank per GPU, independent camera streams per GPU, RCCL ("nccl") only for
+the start / stop barrier and the MAX-reduction of the elapsed time -> "scaling": "weak".  The ranks come either from a launcher
+(`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: WORLD_SIZE is set) or, when the command line has no
+launcher, from bench.py itself: the process becomes the PARENT of that same launcher command before it touches the GPU (launch_ranks),
+relays rank 0's one JSON line and returns the launcher's exit code.  Every line carries what makes it self-evidencing: config.ranks_seen
+(SUM-all-reduce of ones), config.rank_devices (PCI bus id / UUID / arch of the card each rank held), config.per_rank_frames_per_s, and
+both north-star shapes as barrier-aligned whole-job legs (config.kitti2000_frames_per_s, config.tum640_frames_per_s).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (largest share of the HIP-event
 time measured live on the launch stream during the timed region) by its ALGORITHMIC bytes
@@ -21,9 +25,10 @@ Outside the timed region the headline run also (rank 0 / every rank as noted):
   * compares the LAST step's device outputs of every frame of the batch (keypoints, descriptors, uRight, depth) with the
     CPU oracle's results for the distinct synthetic pairs -> "verified"; a mismatch makes the exit code non-zero;
   * sweeps the batch size (frames per launch set) -> config.batch_sweep_frames_per_s;
-  * measures the host-fed rates -> config.host_fed: `batched` = pinned host frames -> double-buffered H2D on a copy
-    stream overlapped with compute on two handles -> D2H of all results; `single_stream_c_abi` = one camera stream through
-    orbx_extract_stereo_submit / _wait from a plain C client (examples/stereo_stream.c).  The headline `value` excludes PCIe;
+  * measures the host-fed rates -> config.host_fed (and config.host_fed_batched_frames_per_s / host_fed_single_stream_frames_per_s at
+    the top level): `batched` = pinned host frames -> H2D on a copy stream under the previous batch's kernels -> D2H of all results,
+    four buffer sets going round (HostFedPipeline); `single_stream_c_abi` = one camera stream through orbx_extract_stereo_submit / _wait
+    from a plain C client (examples/stereo_stream.c) with its latency distribution.  The headline `value` excludes PCIe;
   * times the KITTI 2000-feature workload (BASELINE configs 2 / 5) on every rank with its own barrier-aligned window ->
     config.kitti2000_frames_per_s (whole-job aggregate), so that an N-GPU line also carries BASELINE config 5;
   * runs short legs of the other BASELINE configs in the same process (N = 1, rank 0) -> config.other_configs: `tum640`
