@@ -72,8 +72,6 @@ if os.path.exists(sq):
            "issue_model": {"simds": 1024, "clock_ghz": 2.4, "fast_class_cycles": mix["fast_cycles"], "slow_class_cycles": mix["slow_cycles"],
                            "cycles_per_valu_inst": cyc, "static_mix": mix["kernels"]}}
     json.dump(doc, open(os.path.join(dst, f"{tag}_sq_counters.json"), "w"), indent=1)
-for name in ("op_cost.txt", "issue_rate.txt", "hostfed_c.log"):
-    p = os.path.join(ROOT, "gpurun_out", name)
-    if os.path.exists(p):
-        shutil.copy(p, os.path.join(dst, f"{tag}_{name.replace('.log', '.txt')}"))
+# (round 3 also copied gpurun_out/{op_cost.txt, issue_rate.txt, hostfed_c.log} -- scratch files of WHATEVER round last wrote them -- over the
+# tagged names: that is how profiles/r03_hostfed_c.txt came to hold round 2's numbers.  Only files of gpurun_out/final_<tag>/ are published now.)
 print("published:", sorted(f for f in os.listdir(dst) if f.startswith(tag)))
