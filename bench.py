@@ -649,6 +649,10 @@ def run_workload(ctx, args):
                                  "note": "MODEL-DERIVED: wave64 VALU instructions per launch (rocprofv3 SQ_INSTS_VALU from the committed counter file, not this run) / "
                                          "this run's launch time, against 1024 SIMDs x clock / mix-weighted cycles per instruction measured by "
                                          "tools/ubench/op_cost.hip (DESIGN.md section 5)"}
+            if roofline["issue"]["frac"] > 1.0:
+                roofline["issue"]["reading"] = ("above 1: the kernel issues its VALU instructions faster than the price list says is possible, i.e. the mix-weighted cost "
+                                                "(measured on micro-kernels at 8 waves per SIMD) overstates this kernel's by that much; read it as 'the vector ALUs are the "
+                                                "bound', not as a utilisation")
             if "SQ_ACTIVE_INST_VALU" in kk and kk.get("launch_ms"):
                 # counter-only figure (no price list): SIMD-cycles the vector ALUs were busy / SIMD-cycles of the launch, both from the counter run
                 roofline["issue"]["valu_busy_frac_counters"] = round(kk["SQ_ACTIVE_INST_VALU"] * 4 / (im["issue_model"]["simds"] * kk["launch_ms"] * 1e-3 * im["issue_model"]["clock_ghz"] * 1e9), 4)
