@@ -347,6 +347,73 @@ __device__ __forceinline__ int fast_score_full(const uint8_t *t, int th)
     return s > th ? s - 1 : 0;
 }
 
+// The same score for TWO pixels per lane (round 4).  gfx950 has packed three-input f16 minimum / maximum (v_pk_minimum3_f16 / v_pk_maximum3_f16)
+// at the issue cost of v_min3_u32 (4.4 cycles per wave-instruction, tools/ubench/pk3_cost.hip) -- two three-input comparisons per instruction.
+// An 8-bit pixel x travels as the half-precision bit pattern 0x4000 + x: a positive NORMAL number (2 + x / 512) whose order is the order of
+// x, so the float minimum / maximum of patterns IS the integer minimum / maximum of pixels (all 2^24 triples x both halves checked on the
+// device by the microbenchmark; no denormal mode, NaN or signed zero can be involved).  The low halves carry candidate a, the high halves
+// candidate b of the lane: the arc network below is the one of fast_score_full, instruction for instruction, on 128 candidates at a time.
+__device__ __forceinline__ unsigned pk_min3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_max3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// FAST_PK_BIAS: 0x40004000 makes every pattern a NORMAL half (0x4000 + x) at the price of one v_or_b32 per ring pixel; with 0 the patterns are the
+// half-precision SUBNORMALS 0x0000 .. 0x00FF, whose order is also the order of x and which v_pk_minimum3_f16 / v_pk_maximum3_f16 compare exactly as
+// long as the wave's float mode keeps f16 denormals (MODE.FP_DENORM[3:2] = 3: LLVM's default for every AMDGPU kernel; k_fast sets it itself on
+// entry so that the result cannot depend on a build flag).  Both forms checked over all 2^24 triples by tools/ubench/pk3_cost.hip; 0.743 -> 0.718 ms.
+#ifndef FAST_PK_BIAS
+#define FAST_PK_BIAS 0u
+#endif
+template <int P>
+__device__ __forceinline__ void fast_score_pair(const uint8_t *ta, const uint8_t *tb, int th, int *sa, int *sb)
+{
+    constexpr int off[16] = { 3 * P, 3 * P + 1, 2 * P + 2, P + 3, 3, -P + 3, -2 * P + 2, -3 * P + 1,
+                              -3 * P, -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3, 2 * P - 2, 3 * P - 1 };
+    // (the packing costs a v_perm_b32 + a v_or_b32 per ring pixel.  ds_read_u8_d16 / _d16_hi would pack in the load, but on an SRAM-ECC part
+    // -- gfx950:sramecc+ -- a d16 load clobbers the other half of its register: tried from inline assembly, wrong results, and not faster)
+    unsigned x[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        u16x2 v2;
+        v2.x = ta[off[k]]; v2.y = tb[off[k]];
+        x[k] = __builtin_bit_cast(unsigned, v2) | FAST_PK_BIAS;
+    }
+    unsigned lo3[16], hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo3[k] = pk_min3(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
+        hi3[k] = pk_max3(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
+    }
+    unsigned lo9[16], hi9[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo9[k] = pk_min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+        hi9[k] = pk_max3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+    }
+    unsigned a[5], bq[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        a[k] = pk_max3(lo9[3 * k], lo9[3 * k + 1], lo9[3 * k + 2]);
+        bq[k] = pk_min3(hi9[3 * k], hi9[3 * k + 1], hi9[3 * k + 2]);
+    }
+    const unsigned mom = pk_max3(pk_max3(a[0], a[1], a[2]), pk_max3(a[3], a[4], lo9[15]), lo9[15]);     // max over arcs of the arc minimum, both halves
+    const unsigned mox = pk_min3(pk_min3(bq[0], bq[1], bq[2]), pk_min3(bq[3], bq[4], hi9[15]), hi9[15]); // min over arcs of the arc maximum
+    const int va = ta[0], vb = tb[0];
+    const int s_a = max(va - (int)(mox & 0xFFu), (int)(mom & 0xFFu) - va);
+    const int s_b = max(vb - (int)((mox >> 16) & 0xFFu), (int)((mom >> 16) & 0xFFu) - vb);
+    *sa = s_a > th ? s_a - 1 : 0;
+    *sb = s_b > th ? s_b - 1 : 0;
+}
+
 // One wave (64-thread workgroup) per (cell, image) -- no workgroup barriers, many independent cells in flight per CU.
 // The kernel is VALU-issue bound, and on gfx950 only a few wave64 opcodes issue at the full rate (add / sub / and / or /
 // xor / lshr / mov and the 16-bit VOP2 forms: ~2.5 cycles per wave-instruction; min / max / min3 / perm / alignbyte /
@@ -437,6 +504,8 @@ __global__ __launch_bounds__(64 * NW) void k_fast(const FastArgs fa, const CellR
 #ifdef ORBX_FAST_PAD    // experiment: shift the kernel's code by ORBX_FAST_PAD dwords (s_nop 0)
     asm volatile(".fill %0, 4, 0xBF800000" :: "n"(ORBX_FAST_PAD));
 #endif
+    if (FAST_PK_BIAS == 0u)
+        __builtin_amdgcn_s_setreg((1 << 11) | (6 << 6) | 1, 3);      // hwreg(HW_REG_MODE, 6, 2) = 3: f16 / f64 denormals kept (fast_score_pair compares subnormal patterns)
     uint8_t *tile = fast_smem;
     uint8_t *sc = fast_smem + fa.lds_sc;
     uint16_t *list = reinterpret_cast<uint16_t *>(fast_smem + fa.lds_list);
@@ -578,22 +647,43 @@ __global__ __launch_bounds__(64 * NW) void k_fast(const FastArgs fa, const CellR
         // maximum search below then takes one iteration where the full list took two or three.  Returns their number.
         auto score_entries = [&](int n, bool compact) -> int {
             int n2 = 0;
-            for (int i0 = 64 * wv; i0 < n; i0 += 64 * NW) {
-                const int i = i0 + lane;
-                int e = 0, s = 0;
-                if (i < n) {
-                    e = list[i];
-                    const int py = e >> 6, px = e & 63;
-                    s = fast_score_full<P>(t0 + py * P + px, th_cur);
-                    sc[(py + 1) * SP + px + 1] = (uint8_t)s;
+            if (NW == 1) {
+                // one wave: 128 entries per iteration, two per lane (fast_score_pair); lane L takes entries i0 + L and i0 + 64 + L, so the
+                // corners of the first 64 precede those of the second 64 in the compacted list as they did in the list
+                for (int i0 = 0; i0 < n; i0 += 128) {
+                    const int ia = i0 + lane, ib = ia + 64;
+                    const bool in_a = ia < n, in_b = ib < n;
+                    const int ea = list[in_a ? ia : i0], eb = list[in_b ? ib : i0];      // (entry i0 always exists: a lane without an entry recomputes it and drops the result)
+                    const int pya = ea >> 6, pxa = ea & 63, pyb = eb >> 6, pxb = eb & 63;
+                    int sa, sb;
+                    fast_score_pair<P>(t0 + pya * P + pxa, t0 + pyb * P + pxb, th_cur, &sa, &sb);
+                    if (!in_a) sa = 0;
+                    if (!in_b) sb = 0;
+                    if (in_a) sc[(pya + 1) * SP + pxa + 1] = (uint8_t)sa;
+                    if (in_b) sc[(pyb + 1) * SP + pxb + 1] = (uint8_t)sb;
+                    if (compact) {
+                        const unsigned long long ma = __ballot(sa > 0), mb = __ballot(sb > 0);
+                        const int na = __popcll(ma);
+                        if (sa > 0) list[n2 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0u))] = (uint16_t)ea;
+                        if (sb > 0) list[n2 + na + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u))] = (uint16_t)eb;
+                        n2 += na + __popcll(mb);
+                    }
                 }
-                if (NW == 1 && compact) {     // (in place, ordered: one wave only)
-                    const unsigned long long m = __ballot(s > 0);
-                    if (s > 0) list[n2 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (uint16_t)e;
-                    n2 += __popcll(m);
-                }
+                return compact ? n2 : n;
             }
-            return NW == 1 ? n2 : n;        // several waves: the maximum search walks the whole list (entries that are no corners have score 0)
+            // several waves per cell: wave w takes the entries [128 (w + NW k), 128 (w + NW k) + 128), two per lane as above; no compaction (the
+            // maximum search walks the whole list: entries that are no corners have score 0)
+            for (int i0 = 128 * wv; i0 < n; i0 += 128 * NW) {
+                const int ia = i0 + lane, ib = ia + 64;
+                const bool in_a = ia < n, in_b = ib < n;
+                const int ea = list[in_a ? ia : i0], eb = list[in_b ? ib : i0];
+                const int pya = ea >> 6, pxa = ea & 63, pyb = eb >> 6, pxb = eb & 63;
+                int sa, sb;
+                fast_score_pair<P>(t0 + pya * P + pxa, t0 + pyb * P + pxb, th_cur, &sa, &sb);
+                if (in_a) sc[(pya + 1) * SP + pxa + 1] = (uint8_t)sa;
+                if (in_b) sc[(pyb + 1) * SP + pxb + 1] = (uint8_t)sb;
+            }
+            return n;
         };
         // ---- 5. strict 3x3 maximum of the listed pixels (only they can score > 0) -> survivor bitmap
         auto mark_maxima = [&](int n) {
