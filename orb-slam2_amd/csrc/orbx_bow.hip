@@ -229,6 +229,13 @@ extern "C" int orbx_diag_bow_stats(unsigned long long *out, int reset)
 #endif
 #define BOW2_SENT 0x0100FFFFu                   // "no column": distance 256, column 0xFFFF -- above every real key
 
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // the rare full walk of a row: best / second best among the columns no earlier row of the node holds (own: tag << 16 | earliest row)
 template <int MODE>
 __device__ __forceinline__ void bow2_row_scan(const DevFeat &A, const DevFeat &B, long long pa, long long pb0, int bcn, const unsigned *own, int boff,
@@ -362,10 +369,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BOW2_WPE, 8
                         nv += col ? 1 : 0;
                     }
 #pragma unroll
-                    for (int u = 0; u < BOW2_U; u++) {             // sorted insertion into (k1 <= k2 <= k3)
-                        const unsigned t = max(k1, key[u]); k1 = min(k1, key[u]);
-                        const unsigned v = max(k2, t); k2 = min(k2, t);
-                        k3 = min(k3, v);
+                    for (int u = 0; u < BOW2_U; u++) {             // sorted insertion into (k1 <= k2 <= k3): a minimum and two medians (v_med3_u32)
+                        const unsigned o1 = k1, o2 = k2;
+                        k1 = min(o1, key[u]);
+                        k2 = umed3(o1, key[u], o2);
+                        k3 = umed3(o2, key[u], k3);
                     }
                 }
                 const int d1 = (int)(k1 >> 16);
