@@ -854,11 +854,14 @@ def main():
         local %= max(torch.cuda.device_count(), 1)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    rank, world = st.init(backend, device_id=dev if backend == "nccl" else None)   # "nccl" is RCCL on ROCm; no-op for a single process
+    # "nccl" is RCCL on ROCm; no process group for a single process -- unless ORBX_BENCH_FORCE_DIST=1 asks for a one-rank group, so that the very
+    # calls an N-GPU run makes (init with device_id, barrier, MAX / SUM all-reduce and the all-gathers on device tensors) execute through RCCL on a one-GPU box
+    force_dist = os.environ.get("ORBX_BENCH_FORCE_DIST") == "1"
+    rank, world = st.init(backend, device_id=dev if backend == "nccl" else None, force=force_dist)
     assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE={world})"
     pkg.lib()  # fails loudly if liborbx.so is missing: there is no fallback path
     ctx = {"torch": torch, "pkg": pkg, "st": st, "dev": dev, "local": local, "rank": rank, "world": world,
-           "dist_dev": dev if backend == "nccl" else None, "backend": backend if world > 1 else "none"}
+           "dist_dev": dev if backend == "nccl" else None, "backend": backend if (world > 1 or force_dist) else "none"}
     out = run_workload(ctx, args)
     bad = out.get("verified") is not None and not out["verified"]["bit_exact"]
 
@@ -891,7 +894,7 @@ def main():
             out["config"]["matchers"] = {"error": str(exc)[:300]}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
     if bad:
         sys.exit(3)

@@ -21,11 +21,21 @@ def stream_seed(stream_id, base=1000, stride=97):
     return base + stride * stream_id
 
 
-def init(backend, rank=None, world=None, device_id=None):
+def _collective(world):
+    """collectives run when there is more than one rank -- or when a process group exists at all (a one-rank group made on purpose: the
+    rehearsal of the "nccl" = RCCL branch on a one-GPU box, ORBX_BENCH_FORCE_DIST=1)"""
+    if world > 1:
+        return True
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
+def init(backend, rank=None, world=None, device_id=None, force=False):
+    """force: make the process group even for a single rank (every collective below then really runs through the backend)"""
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", 0)) if rank is None else rank
     world = int(os.environ.get("WORLD_SIZE", 1)) if world is None else world
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         kw = {"device_id": device_id} if device_id is not None else {}
@@ -39,9 +49,11 @@ def timed_steps(step, steps, local_sync, world, device=None, detail=None):
     import torch
     import torch.distributed as dist
 
+    coll = _collective(world)
+
     def fence():
         local_sync()
-        if world > 1:
+        if coll:
             dist.barrier()
         local_sync()
 
@@ -56,7 +68,7 @@ def timed_steps(step, steps, local_sync, world, device=None, detail=None):
     if detail is not None:
         detail["own"] = own
         detail["per_rank"] = gather_floats(own, world, device)
-    if world > 1:
+    if coll:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -65,7 +77,7 @@ def timed_steps(step, steps, local_sync, world, device=None, detail=None):
 
 def gather_floats(x, world, device=None):
     """every rank's value of `x`, in rank order, on every rank (all-gather of one float64)"""
-    if world <= 1:
+    if not _collective(world):
         return [float(x)]
     import torch
     import torch.distributed as dist
@@ -77,7 +89,7 @@ def gather_floats(x, world, device=None):
 
 def ranks_seen(world, device=None):
     """SUM-all-reduce of a one per rank: equals `world` exactly when every rank of the launch reached this point"""
-    if world <= 1:
+    if not _collective(world):
         return 1
     import torch
     import torch.distributed as dist
@@ -88,7 +100,7 @@ def ranks_seen(world, device=None):
 
 def gather_strings(s, world, device=None, width=160):
     """every rank's string, in rank order (all-gather of fixed-width byte rows): the per-rank device identities of an N-GPU line"""
-    if world <= 1:
+    if not _collective(world):
         return [s]
     import torch
     import torch.distributed as dist

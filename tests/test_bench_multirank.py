@@ -99,3 +99,19 @@ def test_parent_never_touches_the_gpu(tmp_path):
     # under a launcher (WORLD_SIZE set) the same command does NOT spawn: it goes on to import torch (the empty stand-in here) and fails there
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="3", RANK="0"), cwd=str(tmp_path))
     assert out.returncode != 0 and "launcher_args" not in out.stdout
+
+
+@pytest.mark.gpu
+def test_nccl_branch_runs_with_one_rank():
+    """the "nccl" (= RCCL) branch of an N-GPU run on the one GPU of the test box: ORBX_BENCH_FORCE_DIST=1 makes a ONE-rank process group, so
+    init_process_group("nccl", device_id=...), the barriers, the MAX / SUM all-reduces and the all-gathers on device tensors all execute through
+    RCCL (two ranks cannot share a card under nccl; the 2-rank runs above use gloo)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ORBX_BENCH_BACKEND")}
+    env.update(ORBX_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "8", "--distinct", "4", "--extras", "0", "--cpu-frames", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    c = d["config"]
+    assert d["n_gpus"] == 1 and c["backend"] == "nccl" and c["ranks_seen"] == 1 and len(c["rank_devices"]) == 1 and len(c["per_rank_frames_per_s"]) == 1
+    assert d["verified"]["bit_exact"] is True
