@@ -496,6 +496,10 @@ int orbx_debug_fast_form(const orbx_extractor *e);
  * (LDS distance table + row fixpoint); a call picks by problem size.  form = 1 / 2 forces the wave / table form for
  * every later call of the process, 0 restores the automatic choice.  Both forms return identical matches. */
 int orbx_debug_set_bow_form(int form);
+/* test hook: a per-call matcher search of ONE pair with at most 144 work items hands them to its kernel by value, in the kernel-argument
+ * segment (one dependent PCIe read less per call); in_memory = 1 makes such calls read their items from mapped host memory as calls with
+ * several pairs do, 0 restores the default.  Both forms return identical matches. */
+int orbx_debug_set_match_items(int in_memory);
 /* host phases of the calling thread's most recent per-call matcher search (orbx_match.hip), microseconds:
  * [0] prepare (node intersection, participation bytes, packing), [1] launch, [2] wait for the kernel's ticket, [3] copy-out */
 int orbx_debug_match_timing(double *out4);

@@ -28,6 +28,7 @@
 // (orbx_kf_*): descriptors, FeatureVector and keypoint attributes are immutable once a keyframe exists; only the
 // map-point flags change, and those travel with each call.
 #include "orbx_device.h"
+#include <atomic>
 #include <chrono>
 #include <string.h>
 #include <vector>
@@ -213,7 +214,7 @@ __device__ void m_finalize(const MArgs &g, const MItem &it, int lane, unsigned *
 // MODE 1: SearchByBoW(KF, KF) — result row indexed by the KF1 (first-side) feature, value = KF2 feature
 // MODE 2: SearchForTriangulation — intermediate row indexed by the KF1 feature, value = KF2 feature
 template <int MODE>
-__global__ __launch_bounds__(64) void k_match(MArgs g)
+__device__ __forceinline__ void m_body(const MArgs &g, const MItem &it, const int lane M_STAMP_ARG)
 {
     __shared__ uint32_t s_rd[M_TILE * 9], s_cd[M_TILE * 9];          // row / column descriptors, 9-dword pitch
     __shared__ float s_rl[MODE == 2 ? M_TILE * 4 : 4];               // epipolar line of a row: a, b, c, a^2 + b^2
@@ -223,13 +224,6 @@ __global__ __launch_bounds__(64) void k_match(MArgs g)
     __shared__ float s_te[16], s_sg[16];
     __shared__ uint16_t s_D[MODE == 2 ? 2 : M_TILE * M_DPITCH];      // distance table of a node (greedy forms)
     __shared__ unsigned s_hist[32];
-    const int lane = threadIdx.x;
-#ifdef ORBX_DIAG
-    unsigned long long m_st[9];
-#endif
-    M_STAMP(0);
-    const MItem it = g.items[blockIdx.x];
-    M_STAMP(1);
     const uint32_t *a_desc = side_desc(it.a_base), *a_idx = side_idx(it.a_base, it.a_mp);
     const float *a_ang = side_ang(it.a_base, it.a_mp);
     const uint32_t *b_desc = side_desc(it.b_base), *b_idx = side_idx(it.b_base, it.b_mp);
@@ -496,6 +490,51 @@ __global__ __launch_bounds__(64) void k_match(MArgs g)
     m_finalize<MODE>(g, it, lane, s_hist M_STAMP_PASS);
 }
 
+template <int MODE>
+__global__ __launch_bounds__(64) void k_match(MArgs g)
+{
+    const int lane = threadIdx.x;
+#ifdef ORBX_DIAG
+    unsigned long long m_st[9];
+#endif
+    M_STAMP(0);
+    const MItem it = g.items[blockIdx.x];
+    M_STAMP(1);
+    m_body<MODE>(g, it, lane M_STAMP_PASS);
+}
+
+// A call with ONE pair (what ORB-SLAM2's own loops issue) and at most M_BYVAL_MAX items carries its work items BY VALUE in the
+// kernel-argument segment: what every item of a pair shares once (MPairV), what differs per item in 24 bytes.  The wave's item then
+// arrives with the argument fetch it makes anyway, instead of behind a second dependent read of host memory (~1.3 us over PCIe).
+struct MItemC { unsigned long long a_mask, b_mask; uint16_t a_off, a_cnt, b_off, b_cnt; };
+static_assert(sizeof(MItemC) == 24, "MItemC layout");
+#define M_BYVAL_MAX 144
+struct MItemsV { MItemC it[M_BYVAL_MAX]; };
+struct MPairV {
+    const uint8_t *a_base, *b_base, *a_part, *b_part;
+    int a_mp, b_mp, nitems, nslots, cap, cnt_idx;
+};
+static_assert(sizeof(MArgs) + sizeof(MPairV) + sizeof(MItemsV) <= 4096, "kernel-argument segment");
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_match_v(MArgs g, const MPairV pv, const MItemsV iv)
+{
+    const int lane = threadIdx.x;
+#ifdef ORBX_DIAG
+    unsigned long long m_st[9];
+#endif
+    M_STAMP(0);
+    const MItemC c = iv.it[blockIdx.x];
+    MItem it;
+    it.a_base = pv.a_base; it.b_base = pv.b_base; it.a_part = pv.a_part; it.b_part = pv.b_part;
+    it.a_mask = c.a_mask; it.b_mask = c.b_mask;
+    it.a_mp = pv.a_mp; it.b_mp = pv.b_mp;
+    it.a_off = c.a_off; it.a_cnt = c.a_cnt; it.b_off = c.b_off; it.b_cnt = c.b_cnt;
+    it.pair = 0; it.nitems = pv.nitems; it.nslots = pv.nslots; it.tmp_off = 0; it.out_off = 0; it.cap = pv.cap; it.cnt_idx = pv.cnt_idx; it.pad0 = 0;
+    M_STAMP(1);
+    m_body<MODE>(g, it, lane M_STAMP_PASS);
+}
+
 // ---------------------------------------------------------------- host side
 
 struct MatchCtx {
@@ -531,6 +570,10 @@ struct MatchCtx {
 static thread_local MatchCtx g_mctx[16];
 // the calling thread's matcher resources on every device, now (they are also released when the thread ends)
 extern "C" void orbx_thread_release(void) { for (MatchCtx &c : g_mctx) c.release(); }
+// test hook: 1 = a single-pair call reads its work items from the blob like a batch does (the k_match kernels), 0 = by value (k_match_v)
+static std::atomic<int> g_items_in_memory{0};
+extern "C" int orbx_debug_set_match_items(int in_memory) { g_items_in_memory.store(in_memory ? 1 : 0, std::memory_order_relaxed); return ORBX_OK; }
+static inline bool orbx_match_items_in_memory() { return g_items_in_memory.load(std::memory_order_relaxed) != 0; }
 static thread_local double g_mtime[4];   // host phases of this thread's most recent call, microseconds: prepare, launch, wait, copy-out
 static inline double m_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 extern "C" int orbx_debug_match_timing(double *out4) { if (!out4) return ORBX_E_INVALID; for (int i = 0; i < 4; i++) out4[i] = g_mtime[i]; return ORBX_OK; }
@@ -863,7 +906,9 @@ static int match_call(int mode, int device, HSide *sides, int nsides, const int 
         it.pad0 = 0;
     }
     if (!c->items.empty()) {
-        memcpy(c->h_blob, c->items.data(), c->items.size() * sizeof(MItem));
+        bool by_value = npairs == 1 && c->items.size() <= M_BYVAL_MAX && !orbx_match_items_in_memory();
+        if (by_value) for (const MItem &it : c->items) by_value = by_value && it.a_off < 65536 && it.a_cnt < 65536 && it.b_off < 65536 && it.b_cnt < 65536;
+        if (!by_value) memcpy(c->h_blob, c->items.data(), c->items.size() * sizeof(MItem));
         MArgs g;
         memset(&g, 0, sizeof g);
         g.items = reinterpret_cast<const MItem *>(c->d_blob);
@@ -884,7 +929,23 @@ static int match_call(int mode, int device, HSide *sides, int nsides, const int 
         t_prep = m_now_us();
         c->poisoned = true;         // until this call has its results: any error return below leaves scratch rows / counters in an unknown state
         const dim3 grid((unsigned)c->items.size()), block(64);
-        if (mode == 0) hipLaunchKernelGGL(k_match<0>, grid, block, 0, c->stream, g);
+        if (by_value) {
+            const MItem &f = c->items[0];    // one pair: tmp_off = out_off = 0, everything but masks and ranges is the same in every item
+            MPairV pv;
+            pv.a_base = f.a_base; pv.b_base = f.b_base; pv.a_part = f.a_part; pv.b_part = f.b_part;
+            pv.a_mp = f.a_mp; pv.b_mp = f.b_mp; pv.nitems = f.nitems; pv.nslots = f.nslots; pv.cap = f.cap; pv.cnt_idx = f.cnt_idx;
+            MItemsV iv;
+            for (size_t i = 0; i < c->items.size(); i++) {
+                const MItem &it = c->items[i];
+                iv.it[i].a_mask = it.a_mask; iv.it[i].b_mask = it.b_mask;
+                iv.it[i].a_off = (uint16_t)it.a_off; iv.it[i].a_cnt = (uint16_t)it.a_cnt; iv.it[i].b_off = (uint16_t)it.b_off; iv.it[i].b_cnt = (uint16_t)it.b_cnt;
+            }
+            g.items = nullptr;
+            if (mode == 0) hipLaunchKernelGGL(k_match_v<0>, grid, block, 0, c->stream, g, pv, iv);
+            else if (mode == 1) hipLaunchKernelGGL(k_match_v<1>, grid, block, 0, c->stream, g, pv, iv);
+            else hipLaunchKernelGGL(k_match_v<2>, grid, block, 0, c->stream, g, pv, iv);
+        }
+        else if (mode == 0) hipLaunchKernelGGL(k_match<0>, grid, block, 0, c->stream, g);
         else if (mode == 1) hipLaunchKernelGGL(k_match<1>, grid, block, 0, c->stream, g);
         else hipLaunchKernelGGL(k_match<2>, grid, block, 0, c->stream, g);
         ORBX_HIP(hipGetLastError());

@@ -141,6 +141,7 @@ def lib():
     L.orbx_debug_level_counts.argtypes = [vp, i, vp]
     L.orbx_debug_fast_form.argtypes = [vp]
     L.orbx_debug_set_bow_form.argtypes = [i]
+    L.orbx_debug_set_match_items.argtypes = [i]
     L.orbx_debug_match_timing.argtypes = [vp]
     _lib = L
     return L
@@ -190,6 +191,11 @@ def gaussian_taps(profile):
 def debug_set_bow_form(form):
     """test hook: "auto" / "wave" / "table" form of the SearchByBoW kernels (orbx_debug_set_bow_form)"""
     _check(lib().orbx_debug_set_bow_form({"auto": 0, "wave": 1, "table": 2}[form]))
+
+
+def debug_set_match_items(in_memory):
+    """test hook: single-pair matcher calls read their work items from mapped host memory (True) or get them by value (False, default)"""
+    _check(lib().orbx_debug_set_match_items(1 if in_memory else 0))
 
 
 def _check(rc):

@@ -114,6 +114,41 @@ def test_large_nodes(pkg, oracle, k, n):
         assert got[i].shape == exp.shape and (got[i] == exp).all()
 
 
+@pytest.mark.parametrize("in_memory", [False, True])
+@pytest.mark.parametrize("k,n", [(10, 1000), (2, 1000), (1, 300), (3, 2500)])
+def test_single_pair_item_transports(pkg, oracle, k, n, in_memory):
+    """A call with one pair hands its work items to the kernel by value (k_match_v: at most 144 items, in the kernel-argument segment)
+    or, like a batch, through mapped host memory (k_match; also what 3 x 3 nodes of 278 features split by rows -- 180 items -- take):
+    identical results, host pointers and resident keyframes"""
+    cur, kfs, Fs, eps, sf, sg = _scene(61 + k, n, (n - 11,), k=k)
+    kf = kfs[0]
+    tc = _tri_flags(cur, 4, 1); tk = _tri_flags(kf, 3, 1)
+    m = pkg.ORBmatcher(0.8, True)
+    pkg.orbx.debug_set_match_items(in_memory)
+    try:
+        for rnd in range(2):                                           # (the second call reuses the thread's context: tickets, scratch rows back at -1)
+            g, c = m.SearchByBoW(kf, cur)
+            e, ec = oracle.search_by_bow_kf_f(kf, cur, 0.8, True)
+            assert c == ec and (g == e).all()
+            b = dict(kf); b["kind"] = "keyframe"
+            g, c = m.SearchByBoW(cur, b)
+            e, ec = oracle.search_by_bow_kf_kf(cur, kf, 0.8, True)
+            assert c == ec and (g == e).all()
+            for only_stereo in (False, True):
+                got = m.SearchForTriangulation(tc, tk, Fs[0], eps[0][0], eps[0][1], sf, sg, bOnlyStereo=only_stereo)
+                exp = oracle.search_for_triangulation(tc, tk, Fs[0], eps[0][0], eps[0][1], sf, sg, 0.6, True, only_stereo)
+                assert got.shape == exp.shape and (got == exp).all()
+        dcur = pkg.DeviceKeyFrame(cur); dk = pkg.DeviceKeyFrame(kf)
+        g, c = m.SearchByBoWResident(dk, kf["flag"], dcur)
+        e, ec = oracle.search_by_bow_kf_f(kf, cur, 0.8, True)
+        assert c == ec and (g == e).all()
+        got = m.SearchForTriangulationResident(dcur, tc["flag"], [dk], [tk["flag"]], Fs, eps, sf, sg)
+        exp = oracle.search_for_triangulation(tc, tk, Fs[0], eps[0][0], eps[0][1], sf, sg, 0.6, True, False)
+        assert got[0].shape == exp.shape and (got[0] == exp).all()
+    finally:
+        pkg.orbx.debug_set_match_items(False)
+
+
 def test_node_beyond_register_form_takes_legacy_kernels(pkg, oracle):
     """one vocabulary node with more than 4096 second-side features: SearchByBoW falls back to the kernels of orbx_bow.hip"""
     cur, kfs, Fs, eps, sf, sg = _scene(21, 4300, (4200,), k=1, flip=0.02)
