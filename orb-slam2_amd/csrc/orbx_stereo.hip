@@ -250,11 +250,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const uint8_t *imR = orbx_level_ptr(prR, LV, lvl, img_r0 + p, &prr);
             const int cy = (int)svl, cxl = (int)sul;
             // each lane owns window pixels e = lane and lane+64 (< 121)
-            const int e0 = lane, e1 = lane + 64;
+            // (lanes 57..63 have no second pixel: they take the window centre, pixel 60, again -- it contributes |0 - 0| to every shift)
+            const int e0 = lane, e1 = lane + 64 < 121 ? lane + 64 : 60;
             const int dy0 = e0 / 11 - 5, dx0 = e0 % 11 - 5;
             const int dy1 = e1 / 11 - 5, dx1 = e1 % 11 - 5;
             const int cx0 = (int)sur0;
-            int lc, il0, il1, r0[11], r1[11];
+            int lc, il0, il1, r0[11], r1[11];   // raw pixels: left centre, the lane's two left pixels, their 11 right partners each
             // Fast path (every window of a keypoint the extractor produced): both windows lie inside the level, so
             // they are fetched as aligned dwords (left 11 rows x 4 dwords = 1 load instruction, right 11 x 7 = 2) into
             // the wave's LDS slice and the 24 per-lane pixels are LDS byte reads.  Gathering them straight from
@@ -288,39 +289,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 __builtin_amdgcn_wave_barrier();
                 const int ol_ = cxl - xla, or_ = cx0 - xra; // byte offset of the window centre column in a staged row
                 lc = wl[5 * 16 + ol_];
-                il0 = wl[(dy0 + 5) * 16 + ol_ + dx0] - lc;
-                il1 = e1 < 121 ? wl[(dy1 + 5) * 16 + ol_ + dx1] - lc : 0;
+                il0 = wl[(dy0 + 5) * 16 + ol_ + dx0];
+                il1 = wl[(dy1 + 5) * 16 + ol_ + dx1];
 #pragma unroll
                 for (int k = 0; k < 11; k++) {
                     r0[k] = wr[(dy0 + 5) * 28 + or_ + dx0 + k - 5];
-                    r1[k] = e1 < 121 ? wr[(dy1 + 5) * 28 + or_ + dx1 + k - 5] : 0;
+                    r1[k] = wr[(dy1 + 5) * 28 + or_ + dx1 + k - 5];
                 }
             } else {
                 lc = lvl_px(imL, pl, LV.w, LV.h, cxl, cy);
-                il0 = lvl_px(imL, pl, LV.w, LV.h, cxl + dx0, cy + dy0) - lc;
-                il1 = e1 < 121 ? lvl_px(imL, pl, LV.w, LV.h, cxl + dx1, cy + dy1) - lc : 0;
+                il0 = lvl_px(imL, pl, LV.w, LV.h, cxl + dx0, cy + dy0);
+                il1 = lvl_px(imL, pl, LV.w, LV.h, cxl + dx1, cy + dy1);
                 // all right-image loads first (independent, in flight together): the 11 shifts of window pixel
                 // (dx,dy) are the 11 consecutive columns sur0+dx-5 .. sur0+dx+5 of row cy+dy
 #pragma unroll
                 for (int k = 0; k < 11; k++) {
                     r0[k] = lvl_px(imR, prr, LV.w, LV.h, cx0 + dx0 + k - 5, cy + dy0);
-                    r1[k] = e1 < 121 ? lvl_px(imR, prr, LV.w, LV.h, cx0 + dx1 + k - 5, cy + dy1) : 0;
+                    r1[k] = lvl_px(imR, prr, LV.w, LV.h, cx0 + dx1 + k - 5, cy + dy1);
                 }
             }
             int dists[11];
-            // lane 60 is the window centre (dy = 0, dx = 0): its r0[k] is the centre pixel of shift k
+            // |(IL - IL_centre) - (IR - IR_centre)| (src/Frame.cc:694-703: both windows minus their centre pixels, L1 norm) is
+            // |(IL + IR_centre) - (IR + IL_centre)|: two sums below 511, i.e. u16 -- v_sad_u16 takes the lane's two pixels (low / high half)
+            // in ONE instruction.  Lane 60 is the window centre (dy = 0, dx = 0): its r0[k] is the centre pixel of shift k.
+            const unsigned lpk = (unsigned)il0 | ((unsigned)il1 << 16), lcc = (unsigned)lc * 0x00010001u;
+            auto shift_sad = [&](int k) -> unsigned {
+                const unsigned rc = (unsigned)__builtin_amdgcn_readlane(r0[k], 60) * 0x00010001u;
+                const unsigned rpk = (unsigned)r0[k] | ((unsigned)r1[k] << 16);
+                return __builtin_amdgcn_sad_u16(lpk + rc, rpk + lcc, 0u);
+            };
 #pragma unroll
             for (int k = 0; k < 11; k += 2) {
-                const int c_a = __shfl(r0[k], 60, WAVE);
-                int sa = abs(il0 - (r0[k] - c_a)) + (e1 < 121 ? abs(il1 - (r1[k] - c_a)) : 0);
+                const unsigned sa = shift_sad(k);
                 if (k + 1 < 11) { // two shifts per reduction: each total is <= 121*510 < 2^16
-                    const int c_b = __shfl(r0[k + 1], 60, WAVE);
-                    const int sb = abs(il0 - (r0[k + 1] - c_b)) + (e1 < 121 ? abs(il1 - (r1[k + 1] - c_b)) : 0);
-                    const unsigned tot = (unsigned)wave_sum(sa | (sb << 16));
+                    const unsigned sb = shift_sad(k + 1);
+                    const unsigned tot = (unsigned)wave_sum((int)(sa | (sb << 16)));
                     dists[k] = (int)(tot & 0xFFFFu);
                     dists[k + 1] = (int)(tot >> 16);
                 } else {
-                    dists[k] = wave_sum(sa);
+                    dists[k] = wave_sum((int)sa);
                 }
             }
             int best_sad = 0x7FFFFFFF, best_inc = 0;
