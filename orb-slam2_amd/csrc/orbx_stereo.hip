@@ -288,14 +288,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const int ol_ = cxl - xla, or_ = cx0 - xra; // byte offset of the window centre column in a staged row
-                lc = wl[5 * 16 + ol_];
-                il0 = wl[(dy0 + 5) * 16 + ol_ + dx0];
-                il1 = wl[(dy1 + 5) * 16 + ol_ + dx1];
+                // (volatile: one ds_read_u8 per pixel.  Left to itself the compiler fetches the 11 consecutive bytes as unaligned dwords and
+                // spends a shift and a mask per pixel on taking them apart -- 50 vector instructions per keypoint in a kernel that is bound
+                // by them, to save LDS instructions it has room for)
+                typedef const volatile __attribute__((address_space(3))) uint8_t *lds_bytes;
+                const lds_bytes vl_ = (lds_bytes)wl, vr_ = (lds_bytes)wr;
+                lc = vl_[5 * 16 + ol_];
+                il0 = vl_[(dy0 + 5) * 16 + ol_ + dx0];
+                il1 = vl_[(dy1 + 5) * 16 + ol_ + dx1];
 #pragma unroll
                 for (int k = 0; k < 11; k++) {
-                    r0[k] = wr[(dy0 + 5) * 28 + or_ + dx0 + k - 5];
-                    r1[k] = wr[(dy1 + 5) * 28 + or_ + dx1 + k - 5];
+                    r0[k] = vr_[(dy0 + 5) * 28 + or_ + dx0 + k - 5];
+                    r1[k] = vr_[(dy1 + 5) * 28 + or_ + dx1 + k - 5];
                 }
+                // (and opaque 32-bit values from here: otherwise the two paths are merged as bytes and every pixel is masked with 0xff after the merge)
+                asm volatile("" : "+v"(lc), "+v"(il0), "+v"(il1));
+#pragma unroll
+                for (int k = 0; k < 11; k++) asm volatile("" : "+v"(r0[k]), "+v"(r1[k]));
             } else {
                 lc = lvl_px(imL, pl, LV.w, LV.h, cxl, cy);
                 il0 = lvl_px(imL, pl, LV.w, LV.h, cxl + dx0, cy + dy0);
@@ -312,7 +321,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             // |(IL - IL_centre) - (IR - IR_centre)| (src/Frame.cc:694-703: both windows minus their centre pixels, L1 norm) is
             // |(IL + IR_centre) - (IR + IL_centre)|: two sums below 511, i.e. u16 -- v_sad_u16 takes the lane's two pixels (low / high half)
             // in ONE instruction.  Lane 60 is the window centre (dy = 0, dx = 0): its r0[k] is the centre pixel of shift k.
-            const unsigned lpk = (unsigned)il0 | ((unsigned)il1 << 16), lcc = (unsigned)lc * 0x00010001u;
+            unsigned lpk = (unsigned)il0 | ((unsigned)il1 << 16), lcc = (unsigned)lc * 0x00010001u;
+            asm volatile("" : "+v"(lcc));      // (computed once: otherwise it is re-formed as a multiply-add inside each of the 11 shifts)
             auto shift_sad = [&](int k) -> unsigned {
                 const unsigned rc = (unsigned)__builtin_amdgcn_readlane(r0[k], 60) * 0x00010001u;
                 const unsigned rpk = (unsigned)r0[k] | ((unsigned)r1[k] << 16);
