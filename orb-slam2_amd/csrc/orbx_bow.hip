@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BOW2_WPE, 8
     __shared__ int keep3[3];
     __shared__ int s_cnt;
     __shared__ int s_w[4];
-    __shared__ int s_npass, s_nfall;
+    __shared__ int s_npass, s_nfall, s_changed[2];
     __shared__ int c_aoff[BOW_CHUNK], c_boff[BOW_CHUNK], c_roff[BOW_CHUNK];      // node tables of the chunk (shared nodes only, node order)
     __shared__ unsigned c_cnt[BOW_CHUNK];                                         // a_cnt | b_cnt << 16
     __shared__ uint16_t pass_first[BOW_CHUNK + 1], pass_rows[BOW_CHUNK];
@@ -336,7 +336,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BOW2_WPE, 8
                 const int acn = (int)(c_cnt[q] & 0xFFFF), rb = c_roff[q];
                 for (int i1 = lane; i1 < acn; i1 += 64) row_node[rb + i1] = (uint8_t)q;
             }
-            for (int i = tid; i < mB; i += 256) own[i] = 0xFFFFFFFFu;
+            {   // (an opaque copy of tid: &own[tid] is loop-invariant, and kept across the passes it was the register that went to scratch --
+                // 33 MB of spill stores per launch of 16 000 workgroups)
+                int t_ = tid;
+                asm volatile("" : "+v"(t_));
+                for (int i = t_; i < mB; i += 256) own[i] = 0xFFFFFFFFu;
+            }
             node_dirty[0][tid] = 1; node_dirty[1][tid] = 0;
             __syncthreads();
             // ---- distances: thread t owns rows t, t + 256, ...: its descriptor once, the node's columns four at a time, the three smallest
@@ -383,6 +388,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BOW2_WPE, 8
                 K1[u4] = k1; K2[u4] = k2; K3[u4] = k3;
             }
             BOW_STAT(5, rows);
+            if (tid < 2) s_changed[tid] = 0;
             __syncthreads();
             // ---- the greedy walk as a fixpoint over rows (see k_bow): choice(r) = best column no EARLIER row of the node currently holds.
             // own[] carries the round in its high half, so it is filled once per round and never cleared.
@@ -450,7 +456,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BOW2_WPE, 8
                     }
                 }
                 BOW_STAT(1, 1);
-                if (!__syncthreads_or(changed)) break;
+                // "did any row change?" through a flag per round parity (set by whoever changed, read after the barrier, the other parity's
+                // flag cleared for the next round): __syncthreads_or costs two barriers, an LDS reduction and the y / z work-item ids,
+                // which went to scratch in the (KF, KF) form
+                if (changed) s_changed[round & 1] = 1;
+                __syncthreads();
+                if (!s_changed[round & 1]) break;
+                if (tid == 0) s_changed[(round & 1) ^ 1] = 0;
                 node_dirty[round & 1][tid] = 0;
                 __syncthreads();
             }

@@ -123,7 +123,9 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 template <int NT>
 __device__ __forceinline__ int block_excl_scan(int v, int *total, int *s_w)
 {
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    int t_ = threadIdx.x;
+    asm volatile("" : "+v"(t_));        // (opaque: &s_w[wv] is not kept in a register between calls -- in k_bow2 it went to scratch)
+    const int lane = t_ & (WAVE - 1), wv = t_ >> 6;
     const int inc = wave_incl_scan(v);
     if (lane == WAVE - 1) s_w[wv] = inc;
     __syncthreads();
