@@ -266,7 +266,7 @@ __device__ __forceinline__ void bow2_row_scan(const DevFeat &A, const DevFeat &B
 template <int MODE, int OUT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BOW2_WPE, 8))) void k_bow2(const DevFeat *__restrict__ sides_a, const DevFeat *__restrict__ sides_b,
                                              int b_shared, float nnratio, int check_ori, int32_t *__restrict__ match_out,
-                                             int match_stride, int *__restrict__ nmatches)
+                                             int match_stride, int *__restrict__ nmatches, int xmap_npairs, int xmap_nframes)
 {
     __shared__ int hist[BOW_HISTO];
     __shared__ int keep3[3];
@@ -280,7 +280,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BOW2_WPE, 8
     __shared__ uint16_t choice[BOW2_ROWS];         // per first-side row of the pass: chosen column of its node or 0xFFFF
     __shared__ uint8_t row_node[BOW2_ROWS];
     __shared__ uint8_t node_dirty[2][BOW_CHUNK];
-    const int pair = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // Grid: (pairs, frames), or -- a keyframe set against a batch of frames -- ONE dimension in which an XCD owns whole keyframes: workgroups are
+    // dealt round-robin over the 8 XCDs in dispatch order, so workgroup L runs on XCD L % 8; XCD x takes the keyframes x, x + 8, ... and each
+    // of them with all its frames in consecutive workgroups.  A keyframe's 41 KB then come over the fabric once (its 32 uses hit the XCD's
+    // L2 while they are fresh) instead of once per few frames, and the batch's frames (1.3 MB) stay in every L2.
+    int pair, frame, npairs_g;
+    if (xmap_nframes > 0) {
+#ifndef BOW2_XG
+#define BOW2_XG 16
+#endif
+        const unsigned L = blockIdx.x, slot = L >> 3, per = (unsigned)xmap_nframes * BOW2_XG, grp = slot / per, rem = slot - grp * per;
+        frame = (int)(rem / BOW2_XG); pair = (int)((grp * BOW2_XG + rem % BOW2_XG) * 8u + (L & 7u)); npairs_g = xmap_npairs;
+        if (pair >= npairs_g) return;
+    } else { pair = blockIdx.x; frame = blockIdx.y; npairs_g = gridDim.x; }
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const DevFeat A = sides_a[pair];
     const DevFeat B = sides_b[b_shared ? frame : pair];
     const int nslots = MODE == 0 ? B.n : A.n;
@@ -489,7 +502,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BOW2_WPE, 8
     }
     __threadfence_block();
     __syncthreads();
-    const long long pi = (long long)frame * gridDim.x + pair;
+    const long long pi = (long long)frame * npairs_g + pair;
     histogram_filter(match, bins, nslots, check_ori, hist, keep3, &s_cnt, nmatches + pi);
     __syncthreads();
     if (OUT == 0) {
@@ -535,9 +548,18 @@ static int bow_launch(int npairs_x, int nframes_y, int max_b, int max_slots, hip
     const size_t lds = table ? base + 4 * (size_t)((max_b + 3) & ~3) + 4 * (size_t)((max_slots + 3) & ~3) : base;
     if (lds > 120 * 1024) { orbx_set_error("feature sets too large for LDS"); return ORBX_E_INVALID; }
     if (table) {
-        void (*kern)(const DevFeat *, const DevFeat *, int, float, int, int32_t *, int, int *) = compact ? k_bow2<MODE, 1> : k_bow2<MODE, 0>;
+        void (*kern)(const DevFeat *, const DevFeat *, int, float, int, int32_t *, int, int *, int, int) = compact ? k_bow2<MODE, 1> : k_bow2<MODE, 0>;
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(npairs_x, nframes_y), dim3(256), lds, st, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
+#ifdef BOW2_NOXMAP
+        const bool xmap = false;
+#else
+        const bool xmap = b_shared && nframes_y >= 2 && npairs_x >= 8 && (long long)((npairs_x + 7) / 8) * 8 * nframes_y < (1ll << 30);
+#endif
+        if (xmap)    // keyframes against a batch of frames: an XCD owns whole keyframes (see the kernel)
+            hipLaunchKernelGGL(kern, dim3((unsigned)(((npairs_x + 8 * BOW2_XG - 1) / (8 * BOW2_XG)) * 8 * BOW2_XG * nframes_y)), dim3(256), lds, st, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n,
+                               npairs_x, nframes_y);
+        else
+            hipLaunchKernelGGL(kern, dim3(npairs_x, nframes_y), dim3(256), lds, st, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n, 0, 0);
     } else {
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow_wave<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_bow_wave<MODE>, dim3(npairs_x, nframes_y), dim3(1024), lds, st, dA, dB, b_shared, nnratio, check_ori, d_match, stride, d_n);
