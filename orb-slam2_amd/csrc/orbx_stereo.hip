@@ -153,6 +153,9 @@ __device__ __forceinline__ void stereo_cut(int n_l, long long o, Published<float
 // FOLD: the median cut runs in the pair's last workgroup (launches of few pairs: one launch less in a single frame's chain).  Batches
 // keep it a launch of its own (k_stereo_cut): the write-through stores and the arrival step at the end of EVERY workgroup cost a batch
 // more (0.156 against 0.149 ms per 256 pairs) than the extra launch.
+#ifndef STX_G
+#define STX_G 16
+#endif
 template <bool FOLD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_stereo(const Geom *__restrict__ g, PyrRef prL, PyrRef prR, int img_l0, int img_r0,
                                                 const orbx_keypoint *__restrict__ kL, const uint32_t *__restrict__ dL,
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                 float bf, float max_d, StereoTabs tabs, Published<float> u_right,
                                                 Published<float> depth, Published<int> st_dist,
                                                 const int *__restrict__ row_off, const uint4 *__restrict__ entries, int ent_cap, int reach,
-                                                int *__restrict__ arrive, int kpw)
+                                                int *__restrict__ arrive, int kpw, int xmap_gx, int xmap_pairs)
 {
     // A wave takes FOUR left keypoints.  Coarse stage: one keypoint per 16-lane row (a row of the table holds ~25
     // candidates, so a whole wave per keypoint left most lanes idle and paid the dependent load chain
@@ -172,10 +175,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ __align__(16) uint8_t s_win[4 * ((SW_BYTES + 15) & ~15)];
     // kpw = keypoints per wave: 4 for batches; 1 when the launch has few pairs (a single frame leaves most of the chip idle, and the
     // fine stages of a wave's keypoints run one after the other: with one keypoint per wave they all run side by side)
-    const int p = blockIdx.y, lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
-    const int il_base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kpw;
+    // Grid (keypoint groups, pairs), or -- batches -- one dimension in which an XCD owns whole stereo pairs (workgroup L runs on XCD L % 8;
+    // STX_G pairs interleaved per XCD): a pair's right-eye descriptors, row table and level windows then cross the fabric into ONE L2
+    // instead of into all eight
+    int p, bx;
+    if (xmap_gx > 0) {
+        const unsigned L = blockIdx.x, slot = L >> 3, per = (unsigned)xmap_gx * STX_G, grp = slot / per, rem = slot - grp * per;
+        bx = (int)(rem / STX_G); p = (int)((grp * STX_G + rem % STX_G) * 8u + (L & 7u));
+        if (p >= xmap_pairs) return;
+    } else { p = blockIdx.y; bx = blockIdx.x; }
+    const int lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
+    const int il_base = (bx * 4 + (threadIdx.x >> 6)) * kpw;
     const int n_l = nL[p];
-    if ((int)blockIdx.x * 4 * kpw >= n_l) return;    // the whole workgroup (the pair's last workgroup is counted among ceil(n_l / (4 kpw)))
+    if (bx * 4 * kpw >= n_l) return;    // the whole workgroup (the pair's last workgroup is counted among ceil(n_l / (4 kpw)))
     if (il_base < n_l) {                        // wave-uniform
     const int il = il_base + sub;
     const bool have = il < n_l && sub < kpw;
@@ -485,11 +497,18 @@ extern "C" int orbx_stereo_match_batch_device(orbx_extractor *L, int img_l0, orb
     const int kpw_forced = L->stereo_kpw_forced;                          // tests: both forms on the same input (ORBX_STEREO_KPW, read when the handle is created)
     const int kpw = kpw_forced ? kpw_forced : (long long)batch * cap <= 2560 ? 1 : 4;    // a frame or two: one keypoint per wave (see k_stereo; 4 frames 111 vs 115 us, 8 frames 139 vs 154 with four)
     const bool fold = kpw == 1;
-    hipLaunchKernelGGL((fold ? k_stereo<true> : k_stereo<false>), dim3((cap + 4 * kpw - 1) / (4 * kpw), batch), dim3(256), 0, s, L->d_geom, pl, pr, img_l0, img_r0,
+    const int gx = (cap + 4 * kpw - 1) / (4 * kpw);
+#ifdef STX_NOXMAP
+    const bool xmap = false;
+#else
+    const bool xmap = !fold && batch >= 16 && (long long)gx * ((batch + 8 * STX_G - 1) / (8 * STX_G)) * 8 * STX_G < (1ll << 30);   // batches: an XCD owns whole pairs (see the kernel)
+#endif
+    const dim3 grid = xmap ? dim3((unsigned)(gx * ((batch + 8 * STX_G - 1) / (8 * STX_G)) * 8 * STX_G)) : dim3(gx, batch);
+    hipLaunchKernelGGL((fold ? k_stereo<true> : k_stereo<false>), grid, dim3(256), 0, s, L->d_geom, pl, pr, img_l0, img_r0,
                        (const orbx_keypoint *)d_kL, (const uint32_t *)d_dL, (const int *)d_nL,
                        (const orbx_keypoint *)d_kR, (const uint32_t *)d_dR, (const int *)d_nR, cap, bf, max_d, tabs,
                        Published<float>((float *)d_u_right), Published<float>((float *)d_depth), Published<int>(L->d_st_dist), (const int *)d_row_off, (const uint4 *)d_entries, row_ent_cap, reach,
-                       L->d_st_arrive, kpw);
+                       L->d_st_arrive, kpw, xmap ? gx : 0, batch);
     if (!fold) hipLaunchKernelGGL(k_stereo_cut, dim3(batch), dim3(256), 0, s, (const int *)d_nL, cap, Published<float>((float *)d_u_right), Published<float>((float *)d_depth), Published<int>(L->d_st_dist));
     orbx_prof_end(L, s);
     ORBX_HIP(hipGetLastError());
