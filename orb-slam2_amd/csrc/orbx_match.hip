@@ -546,8 +546,8 @@ struct MatchCtx {
     int32_t *d_tmp = nullptr; size_t tmp_cap = 0;
     unsigned *d_cnt = nullptr; size_t cnt_cap = 0;                          // 32 counters per pair + 32 global (see MArgs::cnt)
     unsigned ticket = 0;
-    std::vector<MItem> items;
     std::vector<int> pair_first;                                            // first item of each pair (+ end)
+    std::vector<size_t> pair_out;                                           // first int of each pair's results in the result block
     std::vector<unsigned long long> bits;                                   // participation bits of the call's sides, list order
     bool poisoned = false;      // a call failed after its launch: d_tmp / d_cnt may not be back at -1 / 0 (the kernels rely on that); restored before the next call
     void release()              // stream, pinned blobs and device scratch of this thread on this device
@@ -767,19 +767,9 @@ static void hside_from_kf(HSide *s, const orbx_kf *k, const uint8_t *flag, int r
 // search): the caller takes the legacy kernels.
 #define M_NOT_APPLICABLE 1
 
-// does list position k of side S take part in a search of `mode`?  SearchByBoW: first side = features with a (good) map point
-// (:205-210), (KF, KF) both sides (:606-613, :627-631); triangulation: features WITHOUT a map point, only stereo ones under
-// bOnlyStereo (:750-763, :776-789)
-static inline bool side_on(const HSide &S, int mode, int only_stereo, int k)
-{
-    const uint32_t fi = S.feat[k];
-    if (mode == 2) {
-        if (S.flag && S.flag[fi]) return false;
-        if (only_stereo) return S.stereo_l ? S.stereo_l[k] != 0 : S.u_right[fi] >= 0;
-        return true;
-    }
-    return S.flag && S.flag[fi] != 0;
-}
+// Which list positions of a side take part in a search of `mode` (one bit each, formed in match_call).  SearchByBoW: first side = features
+// with a (good) map point (:205-210), (KF, KF) both sides (:606-613, :627-631); triangulation: features WITHOUT a map point, only stereo
+// ones under bOnlyStereo (:750-763, :776-789)
 
 // rows[p * row_stride ..]: MODE 0 / 1 the match row (nslots ints), MODE 2 the (idx1, idx2) list (2 * cap ints); counts[p]
 static int match_call(int mode, int device, HSide *sides, int nsides, const int *pa, const int *pb, int npairs,
@@ -792,7 +782,8 @@ static int match_call(int mode, int device, HSide *sides, int nsides, const int 
     MatchCtx *c;
     int rc = mctx_get(device, &c);
     if (rc) return rc;
-    {   // who takes part, once per side and call: one bit per list position (a side shared by 20 pairs is walked once)
+    {   // who takes part, once per side and call: one bit per list position (a side shared by 20 pairs is walked once).  Word at a time,
+        // without branches in the walk: this loop and the item loop below are most of what a batched call costs on the host
         size_t words = 0;
         for (int s = 0; s < nsides; s++) {
             HSide &S = sides[s];
@@ -800,12 +791,32 @@ static int match_call(int mode, int device, HSide *sides, int nsides, const int 
             S.bits_off = words;
             if (S.has_part) words += ((size_t)S.m >> 6) + 2;
         }
-        c->bits.assign(words, 0ull);
+        if (c->bits.size() < words) c->bits.resize(words);
         for (int s = 0; s < nsides; s++) {
             const HSide &S = sides[s];
             if (!S.has_part) continue;
             unsigned long long *bw = c->bits.data() + S.bits_off;
-            for (int k = 0; k < S.m; k++) if (side_on(S, mode, only_stereo, k)) bw[k >> 6] |= 1ull << (k & 63);
+            const uint32_t *feat = S.feat;
+            const uint8_t *flag = S.flag, *st_l = S.stereo_l;
+            const float *ur = S.u_right;
+            const int m = S.m, nw = (m >> 6) + 2;
+            for (int w = 0; w < nw; w++) {
+                const int k0 = w << 6, n = m - k0 < 64 ? (m - k0 > 0 ? m - k0 : 0) : 64;
+                unsigned long long v = 0;
+                if (mode != 2) {                       // SearchByBoW: features with a (good) map point
+                    if (flag) for (int j = 0; j < n; j++) v |= (unsigned long long)(flag[feat[k0 + j]] != 0) << j;
+                } else {                               // triangulation: features WITHOUT a map point, only stereo ones under bOnlyStereo
+                    if (flag) for (int j = 0; j < n; j++) v |= (unsigned long long)(flag[feat[k0 + j]] == 0) << j;
+                    else v = n == 64 ? ~0ull : (1ull << n) - 1ull;
+                    if (only_stereo) {
+                        unsigned long long sv = 0;
+                        if (st_l) for (int j = 0; j < n; j++) sv |= (unsigned long long)(st_l[k0 + j] != 0) << j;
+                        else for (int j = 0; j < n; j++) sv |= (unsigned long long)(ur[feat[k0 + j]] >= 0) << j;
+                        v &= sv;
+                    }
+                }
+                bw[w] = v;
+            }
         }
     }
     // the (at most 64) participation bits of list positions [off, off + cnt) of a side
@@ -817,17 +828,53 @@ static int match_call(int mode, int device, HSide *sides, int nsides, const int 
         if (sh) v |= bw[w + 1] << (64 - sh);
         return cnt >= 64 ? v : v & ((1ull << cnt) - 1ull);
     };
-    // ---- work items: the merge join of the two FeatureVectors (same node set as :193-302 / :588-673 / :737-838)
-    c->items.clear();
+    // ---- everything whose size is known before the node intersection: result rows, scratch rows and the blob
+    //      [per-pair F12 / epipole | participation bytes | host-pointer sides | work items], so that the items can be written where the
+    //      kernel reads them, final (no staging vector, no pointer pass, no copy)
+    const bool geom = mode == 2;
+    if (nsides >= 65536) { orbx_set_error("matcher call too large"); return ORBX_E_INVALID; }
     c->pair_first.assign((size_t)npairs + 1, 0);
-    size_t tmp_total = 0, out_total = 0;
+    c->pair_out.resize((size_t)npairs);
+    size_t tmp_total = 0, out_total = 0, item_bound = 0;
+    for (int p = 0; p < npairs; p++) {
+        const HSide &A = sides[pa[p]], &B = sides[pb[p]];
+        const int nslots = mode == 0 ? B.n : A.n;
+        c->pair_out[(size_t)p] = out_total;
+        tmp_total += (size_t)((nslots + 3) & ~3);
+        out_total += mode == 2 ? 2 * (size_t)cap : (size_t)nslots;
+        // items of a pair: one per shared node, plus (triangulation) the row splits of nodes above M_SPLIT_PAIRS (row, column) pairs:
+        // ceil(a / floor(S / b)) <= 2 a b / S + 1 per node
+        item_bound += (size_t)(A.nnodes < B.nnodes ? A.nnodes : B.nnodes) + (mode == 2 ? 2 * (size_t)A.m * (size_t)B.m / M_SPLIT_PAIRS : 0);
+    }
+    const size_t cnt_base = out_total;
+    out_total += (size_t)npairs;
+    if (tmp_total >= (1ull << 31) || out_total >= (1ull << 31) || item_bound >= (1ull << 24)) { orbx_set_error("matcher call too large"); return ORBX_E_INVALID; }
+    size_t off = 0;
+    const size_t off_tri = off;
+    if (mode == 2 && npairs > 1) off += m_a16((size_t)npairs * sizeof(MTri));
+    for (int s = 0; s < nsides; s++) {
+        HSide &S = sides[s];
+        S.part_off = 0;
+        if (S.has_part) { S.part_off = off; off += m_a16((size_t)S.mp + 1); }
+    }
+    for (int s = 0; s < nsides; s++)
+        if (sides[s].pack) { sides[s].blob_off = off; off += m_a16(side_bytes(sides[s].mp, geom)); }
+    off = (off + 127) & ~(size_t)127;
+    const size_t off_items = off;
+    off += item_bound * sizeof(MItem);
+    if ((rc = mctx_reserve(c, off, out_total, tmp_total, (size_t)npairs))) return rc;
+    // ---- work items: the merge join of the two FeatureVectors (same node set as :193-302 / :588-673 / :737-838)
+    MItem *const items = reinterpret_cast<MItem *>(c->h_blob + off_items);
+    size_t n_items = 0, tmp_off = 0;
     int live = 0;
     bool need_part_bytes = false;
     for (int p = 0; p < npairs; p++) {
         const HSide &A = sides[pa[p]], &B = sides[pb[p]];
         const int nslots = mode == 0 ? B.n : A.n;
-        const size_t first = c->items.size();
+        const size_t first = n_items;
         c->pair_first[(size_t)p] = (int)first;
+        const uint8_t *a_base = A.pack ? c->d_blob + A.blob_off : A.dev_base, *b_base = B.pack ? c->d_blob + B.blob_off : B.dev_base;
+        const uint8_t *a_part = A.has_part ? c->d_blob + A.part_off : nullptr, *b_part = B.has_part ? c->d_blob + B.part_off : nullptr;
         int ia = 0, ib = 0;
         while (ia < A.nnodes && ib < B.nnodes) {
             const uint32_t na = A.node_id[ia], nb = B.node_id[ib];
@@ -846,72 +893,43 @@ static int match_call(int mode, int device, HSide *sides, int nsides, const int 
             int rows_per = acn;
             if (mode == 2 && (long long)acn * bcn > M_SPLIT_PAIRS) { rows_per = M_SPLIT_PAIRS / bcn; if (rows_per < 1) rows_per = 1; }
             for (int r = 0; r < acn; r += rows_per) {
-                MItem it;
-                memset(&it, 0, sizeof it);
-                it.a_mp = A.mp; it.b_mp = B.mp;
-                it.a_off = ao + r; it.a_cnt = acn - r < rows_per ? acn - r : rows_per;
-                it.b_off = bo; it.b_cnt = bcn;
-                it.a_mask = ~0ull; it.b_mask = bmask;
-                if (it.a_cnt <= 64 && A.has_part) {
-                    it.a_mask = mask_of(A, it.a_off, it.a_cnt);
-                    if (!it.a_mask) continue;                          // no row takes part
+                const int a_off = ao + r, a_cnt = acn - r < rows_per ? acn - r : rows_per;
+                unsigned long long amask = ~0ull;
+                if (a_cnt <= 64 && A.has_part) {
+                    amask = mask_of(A, a_off, a_cnt);
+                    if (!amask) continue;                              // no row takes part
                 }
-                if (it.a_cnt > 64 && A.has_part) need_part_bytes = true;
-                it.pair = p; it.nslots = nslots; it.cap = cap;
-                it.pad0 = pa[p] | (pb[p] << 16);                       // side indices, resolved to pointers below
-                c->items.push_back(it);
+                if (a_cnt > 64 && A.has_part) need_part_bytes = true;
+                if (n_items >= item_bound) { orbx_set_error("matcher call: work item bound exceeded"); return ORBX_E_INVALID; }   // (cannot happen: see the bound)
+                MItem &it = items[n_items++];
+                it.a_base = a_base; it.b_base = b_base; it.a_part = a_part; it.b_part = b_part;
+                it.a_mask = amask; it.b_mask = bmask;
+                it.a_mp = A.mp; it.b_mp = B.mp;
+                it.a_off = a_off; it.a_cnt = a_cnt; it.b_off = bo; it.b_cnt = bcn;
+                it.pair = p; it.nslots = nslots; it.tmp_off = (int)tmp_off; it.out_off = (int)c->pair_out[(size_t)p]; it.cap = cap;
+                it.cnt_idx = (int)(cnt_base + (size_t)p); it.pad0 = 0;
             }
         }
-        const int nitems = (int)(c->items.size() - first);
-        for (size_t i = first; i < c->items.size(); i++) {
-            MItem &it = c->items[i];
-            it.nitems = nitems; it.tmp_off = (int)tmp_total; it.out_off = (int)out_total;
-        }
-        if (nitems) { tmp_total += (size_t)((nslots + 3) & ~3); live++; }
-        out_total += mode == 2 ? 2 * (size_t)cap : (size_t)nslots;
+        const int nitems = (int)(n_items - first);
+        for (size_t i = first; i < n_items; i++) items[i].nitems = nitems;
+        if (nitems) { tmp_off += (size_t)((nslots + 3) & ~3); live++; }
     }
-    c->pair_first[(size_t)npairs] = (int)c->items.size();
-    const size_t cnt_base = out_total;
-    out_total += (size_t)npairs;
-    for (MItem &it : c->items) it.cnt_idx = (int)(cnt_base + (size_t)it.pair);
-    if (nsides >= 65536 || tmp_total >= (1ull << 31) || out_total >= (1ull << 31)) { orbx_set_error("matcher call too large"); return ORBX_E_INVALID; }
-    // ---- blob layout: items | per-pair F12 / epipole | participation bytes (only for sides with a node above 64 entries) | host-pointer sides
-    const bool geom = mode == 2;
-    size_t off = m_a16(c->items.size() * sizeof(MItem));
-    const size_t off_tri = off;
-    if (mode == 2 && npairs > 1) off += m_a16((size_t)npairs * sizeof(MTri));
+    c->pair_first[(size_t)npairs] = (int)n_items;
     for (int s = 0; s < nsides; s++) {
         HSide &S = sides[s];
-        S.part_off = 0;
-        if (S.has_part && need_part_bytes) { S.part_off = off; off += m_a16((size_t)S.mp); }
-    }
-    for (int s = 0; s < nsides; s++)
-        if (sides[s].pack) { sides[s].blob_off = off; off += m_a16(side_bytes(sides[s].mp, geom)); }
-    if ((rc = mctx_reserve(c, off, out_total, tmp_total, (size_t)npairs))) return rc;
-    for (int s = 0; s < nsides; s++) {
-        HSide &S = sides[s];
-        if (S.has_part && need_part_bytes) {
+        if (S.has_part && need_part_bytes) {        // (the kernel looks at these bytes only for a side of an item with more than 64 entries)
             uint8_t *pt = c->h_blob + S.part_off;
             const unsigned long long *bw = c->bits.data() + S.bits_off;
             for (int k = 0; k < S.m; k++) pt[k] = (uint8_t)((bw[k >> 6] >> (k & 63)) & 1ull);
         }
         if (S.pack) side_pack(S.pack, geom, c->h_blob + S.blob_off, S.m, S.mp);
     }
-    for (MItem &it : c->items) {
-        const HSide &A = sides[it.pad0 & 0xFFFF], &B = sides[(it.pad0 >> 16) & 0xFFFF];
-        it.a_base = A.pack ? c->d_blob + A.blob_off : A.dev_base;
-        it.b_base = B.pack ? c->d_blob + B.blob_off : B.dev_base;
-        it.a_part = A.has_part && need_part_bytes ? c->d_blob + A.part_off : nullptr;
-        it.b_part = B.has_part && need_part_bytes ? c->d_blob + B.part_off : nullptr;
-        it.pad0 = 0;
-    }
-    if (!c->items.empty()) {
-        bool by_value = npairs == 1 && c->items.size() <= M_BYVAL_MAX && !orbx_match_items_in_memory();
-        if (by_value) for (const MItem &it : c->items) by_value = by_value && it.a_off < 65536 && it.a_cnt < 65536 && it.b_off < 65536 && it.b_cnt < 65536;
-        if (!by_value) memcpy(c->h_blob, c->items.data(), c->items.size() * sizeof(MItem));
+    if (n_items) {
+        bool by_value = npairs == 1 && n_items <= M_BYVAL_MAX && !orbx_match_items_in_memory();
+        if (by_value) for (size_t i = 0; i < n_items; i++) { const MItem &it = items[i]; by_value = by_value && it.a_off < 65536 && it.a_cnt < 65536 && it.b_off < 65536 && it.b_cnt < 65536; }
         MArgs g;
         memset(&g, 0, sizeof g);
-        g.items = reinterpret_cast<const MItem *>(c->d_blob);
+        g.items = reinterpret_cast<const MItem *>(c->d_blob + off_items);
         g.tri = reinterpret_cast<const MTri *>(c->d_blob + off_tri);
         g.tmp = Published<int32_t>(c->d_tmp); g.cnt = c->d_cnt;
         g.out = c->d_out; g.flag = c->d_flag; g.ticket = ++c->ticket; g.npairs = npairs; g.npairs_live = live;
@@ -928,15 +946,15 @@ static int match_call(int mode, int device, HSide *sides, int nsides, const int 
         }
         t_prep = m_now_us();
         c->poisoned = true;         // until this call has its results: any error return below leaves scratch rows / counters in an unknown state
-        const dim3 grid((unsigned)c->items.size()), block(64);
+        const dim3 grid((unsigned)n_items), block(64);
         if (by_value) {
-            const MItem &f = c->items[0];    // one pair: tmp_off = out_off = 0, everything but masks and ranges is the same in every item
+            const MItem &f = items[0];    // one pair: tmp_off = out_off = 0, everything but masks and ranges is the same in every item
             MPairV pv;
             pv.a_base = f.a_base; pv.b_base = f.b_base; pv.a_part = f.a_part; pv.b_part = f.b_part;
             pv.a_mp = f.a_mp; pv.b_mp = f.b_mp; pv.nitems = f.nitems; pv.nslots = f.nslots; pv.cap = f.cap; pv.cnt_idx = f.cnt_idx;
             MItemsV iv;
-            for (size_t i = 0; i < c->items.size(); i++) {
-                const MItem &it = c->items[i];
+            for (size_t i = 0; i < n_items; i++) {
+                const MItem &it = items[i];
                 iv.it[i].a_mask = it.a_mask; iv.it[i].b_mask = it.b_mask;
                 iv.it[i].a_off = (uint16_t)it.a_off; iv.it[i].a_cnt = (uint16_t)it.a_cnt; iv.it[i].b_off = (uint16_t)it.b_off; iv.it[i].b_cnt = (uint16_t)it.b_cnt;
             }
@@ -973,11 +991,10 @@ static int match_call(int mode, int device, HSide *sides, int nsides, const int 
             counts[p] = 0;
             continue;
         }
-        const MItem &it = c->items[(size_t)first];
-        const int cnt = c->h_out[it.cnt_idx];
+        const int cnt = c->h_out[cnt_base + (size_t)p];
         counts[p] = cnt;
-        if (mode == 2) memcpy(row, c->h_out + it.out_off, sizeof(int32_t) * 2 * (size_t)(cnt < cap ? cnt : cap));
-        else memcpy(row, c->h_out + it.out_off, sizeof(int32_t) * (size_t)it.nslots);
+        if (mode == 2) memcpy(row, c->h_out + c->pair_out[(size_t)p], sizeof(int32_t) * 2 * (size_t)(cnt < cap ? cnt : cap));
+        else memcpy(row, c->h_out + c->pair_out[(size_t)p], sizeof(int32_t) * (size_t)(mode == 0 ? sides[pb[p]].n : sides[pa[p]].n));
     }
     g_mtime[0] = t_prep - t_begin; g_mtime[1] = t_launch - t_prep; g_mtime[2] = t_wait - t_launch; g_mtime[3] = m_now_us() - t_wait;
     return ORBX_OK;
