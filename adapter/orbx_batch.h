@@ -9,8 +9,8 @@
 //   Tracking::Relocalization, src/Tracking.cc:1661-1682                       SearchByBoWBatch(candidates, mCurrentFrame, ...)
 //     for each relocalisation candidate: matcher.SearchByBoW(pKF, mCurrentFrame, vvpMapPointMatches[i])
 //
-// A single SearchByBoW / SearchForTriangulation call costs 22-35 us on the GPU (one launch + one PCIe round trip) against 11-16 us on
-// a host core; twenty pairs in one call cost 3-5 us per pair (matchers).  What makes the batch cheap is that a keyframe's
+// A single SearchByBoW / SearchForTriangulation call costs 20-31 us on the GPU (one launch + one PCIe round trip) against 11-16 us on
+// a host core; twenty pairs in one call cost 3-4.5 us per pair, this file's work included (matchers).  What makes the batch cheap is that a keyframe's
 // descriptors, FeatureVector and undistorted keypoints never change once it exists (src/KeyFrame.cc:29-60): KeyFrameCache keeps them
 // in HBM (orbx_kf), and a call moves only the map-point flags, the node intersection and the results.
 //
