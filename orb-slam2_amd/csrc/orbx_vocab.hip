@@ -71,12 +71,19 @@ __global__ __launch_bounds__(256) void k_vocab_descend(const int *__restrict__ c
 
 extern __shared__ __align__(16) unsigned char vocab_smem[];
 
-// in-LDS bitonic sort of npad (power of two) u64 keys by 256 threads, ascending
+// in-LDS bitonic sort of npad (power of two) u64 keys by 256 threads, ascending.
+// Pair t of a stage is (lo, lo + stride) with lo = 2 t - (t & (stride - 1)); a wave takes the pairs t = 64 w + lane (+ 256 k): for strides
+// up to 64 those are exactly the elements [128 (w + 4 k), 128 (w + 4 k) + 128) -- the same block in every such stage, touched by no other wave.
+// Only the stages with a stride above 64 (6 of the 55 for 1024 keys) need the workgroup barrier; the others are ordered by the wave's own
+// in-order LDS accesses (the per-stage barrier was most of the kernel: 84 us per frame for two sorts of 1024 keys).
 __device__ void bitonic_sort_u64(unsigned long long *keys, int npad)
 {
+    bool need_barrier = true;                    // (the caller's stores into keys[] came from other waves)
     for (int size = 2; size <= npad; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
+            if (need_barrier || stride > 64) __syncthreads();
+            else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+            need_barrier = stride > 64;          // the next stage reads what other waves wrote in this one
             for (int t = threadIdx.x; t < (npad >> 1); t += 256) {
                 const int lo = 2 * t - (t & (stride - 1)); // index with bit `stride` clear
                 const int hi = lo + stride;
@@ -149,11 +156,14 @@ __global__ __launch_bounds__(256) void k_bow_build(int n, int npad, const uint32
     if (tid < 64) { // normalize(L1): ascending word order, strictly sequential doubles (BowVector.cpp:58-77).
         // Wave 0 loads 64 values at a time and adds them in lane order from registers (broadcast reads), so the
         // dependent chain is 64 register adds per memory round trip instead of one.
+        // (the broadcast is v_readlane with a constant lane, 64 unrolled steps per block: through __shfl -- an LDS permute per step --
+        // this loop was 50 of the kernel's 89 us for a 1000-word vector; lanes past the end hold +0.0, which changes no sum)
         double norm = 0.0;
         for (int base = 0; base < nb; base += 64) {
             const double v = base + tid < nb ? fabs(bow_val[base + tid]) : 0.0;
-            const int m = min(64, nb - base);
-            for (int k = 0; k < m; k++) norm += __shfl(v, k, WAVE);
+            const int v_lo = __double2loint(v), v_hi = __double2hiint(v);
+#pragma unroll
+            for (int k = 0; k < 64; k++) norm += __hiloint2double(__builtin_amdgcn_readlane(v_hi, k), __builtin_amdgcn_readlane(v_lo, k));
         }
         if (tid == 0) { s_norm = norm; counts[0] = nb; }
     }
