@@ -373,8 +373,9 @@ __device__ __forceinline__ void m_body(const MArgs &g, const MItem &it, const in
         for (int round = 0; round <= ac; round++) {
             // columns held by EARLIER rows: exclusive prefix OR over the lanes of 1 << choice
             unsigned c_lo = choice >= 0 && choice < 32 ? 1u << choice : 0u, c_hi = choice >= 32 ? 1u << (choice - 32) : 0u;
-            c_lo = (unsigned)__shfl_up((int)c_lo, 1); c_hi = (unsigned)__shfl_up((int)c_hi, 1);
-            if (lane == 0) { c_lo = 0; c_hi = 0; }
+            // (one lane up on the DPP path, wave_shr:1 with lane 0 reading 0: __shfl_up is an LDS permute round trip, twice per round on the
+            // chain every single-pair call waits for)
+            c_lo = (unsigned)ORBX_DPP((int)c_lo, 0, 0x138, 0xf, 0xf); c_hi = (unsigned)ORBX_DPP((int)c_hi, 0, 0x138, 0xf, 0xf);
             const unsigned t_lo = wave_incl_scan_or(c_lo), t_hi = bc > 32 ? wave_incl_scan_or(c_hi) : 0u;
             unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;               // smallest and second smallest key among the free columns
 #pragma unroll
