@@ -351,56 +351,88 @@ __global__ __launch_bounds__(64) void k_init_resolve(DevFrame F, DevPoints P, Pr
 {
     uint16_t *md = reinterpret_cast<uint16_t *>(resolve_smem);          // [F.n] 0xFFFF = INT_MAX
     uint16_t *m21 = md + ((F.n + 7) & ~7);                               // [F.n] holder + 1, 0 = none
+    float *fang = reinterpret_cast<float *>(m21 + ((F.n + 7) & ~7));     // [F.n] the frame's keypoint angles (read per accepted match)
     __shared__ int hist[30];
     const int lane = threadIdx.x;
-    for (int f = lane; f < F.n; f += 64) { md[f] = 0xFFFF; m21[f] = 0; }
+    for (int f = lane; f < F.n; f += 64) { md[f] = 0xFFFF; m21[f] = 0; fang[f] = pp.check_ori ? F.angle[f] : 0.f; }
     for (int i = lane; i < P.n; i += 64) { pt_choice[i] = -1; pt_dist[i] = 256; bins[i] = -1; }
     if (lane < 30) hist[lane] = 0;
     __threadfence_block();
     __syncthreads();
     int nm = 0;
-    for (int i1 = 0; i1 < P.n; i1++) {
-        const int c = cnt[i1];
-        if (c == 0) continue; // wave-uniform
-        const int e0 = beg[i1];
-        unsigned k1 = 0xFFFFFFFFu, d2 = 0x7FFFFFFFu; // lane-local: smallest (dist<<16 | position), second smallest distance
-        for (int eb = 0; eb < c; eb += 64) {
-            const int e = eb + lane;
-            if (e < c) {
-                const uint32_t en = entries[e0 + e];
-                const unsigned f = en & 0xFFFF, d = (en >> 16) & 0x1FF;
-                if (!(md[f] <= d)) {                                   // :470
-                    const unsigned key = (d << 16) | (unsigned)e;     // lists are shorter than 65536 (host check)
-                    if (key < k1) { d2 = k1 >> 16; k1 = key; }
-                    else if (d < d2) d2 = d;
-                }
-            }
+    // The walk is sequential, its memory traffic need not be: list heads (cnt, beg) are fetched 64 points at a time and handed out by
+    // v_readlane, and while point j is decided the first two 64-entry chunks of the NEXT point with a list are already on their way
+    // (a point's list is ~80 entries at 1000-2000 features and the reference's window of 100 px).  The per-point chain is then two wave
+    // minima, the LDS look-ups and lane 0's bookkeeping -- not three dependent global round trips.  Only LDS state (md, m21, hist) orders
+    // the points; the global result arrays are written as we go and read back after the walk, behind one fence.
+    for (int base = 0; base < P.n; base += 64) {
+        const int ip = base + lane;
+        const int my_cnt = ip < P.n ? cnt[ip] : 0, my_beg = ip < P.n ? beg[ip] : 0;
+        const float my_ang = ip < P.n && pp.check_ori ? P.angle[ip] : 0.f;
+        unsigned long long todo = __ballot(my_cnt > 0);
+        uint32_t nx0 = 0, nx1 = 0;                              // chunks 0 and 1 of the next point's list
+        if (todo) {
+            const int j = (int)__builtin_ctzll(todo);
+            const int c = __builtin_amdgcn_readlane(my_cnt, j), e0 = __builtin_amdgcn_readlane(my_beg, j);
+            if (lane < c) nx0 = entries[e0 + lane];
+            if (64 + lane < c) nx1 = entries[e0 + 64 + lane];
         }
-        if (k1 == 0xFFFFFFFFu) d2 = 0x7FFFFFFFu; else if (d2 == 0xFFFFu) d2 = 0x7FFFFFFFu;
-        const unsigned best = wave_min_u32(k1);
-        // second smallest over the wave: the winner lane contributes its own second, every other lane its first
-        const unsigned mine = (k1 == best) ? d2 : (k1 == 0xFFFFFFFFu ? 0x7FFFFFFFu : (k1 >> 16));
-        const unsigned second = wave_min_u32(mine);
-        if (best == 0xFFFFFFFFu) continue;
-        const int bd = (int)(best >> 16), be = (int)(best & 0xFFFF);
-        if (bd <= 50 && (float)bd < (float)(int)second * pp.nnratio) {  // TH_LOW (:485), ratio (:487)
-            const int f = (int)(entries[e0 + be] & 0xFFFF);
-            if (lane == 0) {
-                const int prev = (int)m21[f] - 1;
-                if (prev >= 0) pt_choice[prev] = -1;                   // :489-493
-                pt_choice[i1] = f; pt_dist[i1] = bd;
-                m21[f] = (uint16_t)(i1 + 1); md[f] = (uint16_t)bd;
-                if (pp.check_ori) {
-                    float rot = P.angle[i1] - F.angle[f];              // :501-509
-                    if (rot < 0.0f) rot += 360.0f;
-                    int bin = (int)roundf(rot * (1.0f / 30));
-                    if (bin == 30) bin = 0;
-                    bin = (unsigned)bin < 30u ? bin : 0;
-                    hist[bin]++; bins[i1] = bin;
+        while (todo) {
+            const int j = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int i1 = base + j;
+            const int c = __builtin_amdgcn_readlane(my_cnt, j), e0 = __builtin_amdgcn_readlane(my_beg, j);
+            const uint32_t en0 = nx0, en1 = nx1;
+            if (todo) {                                         // the next point's chunks leave now
+                const int jn = (int)__builtin_ctzll(todo);
+                const int cn = __builtin_amdgcn_readlane(my_cnt, jn), en_ = __builtin_amdgcn_readlane(my_beg, jn);
+                nx0 = lane < cn ? entries[en_ + lane] : 0u;
+                nx1 = 64 + lane < cn ? entries[en_ + 64 + lane] : 0u;
+            }
+            unsigned k1 = 0xFFFFFFFFu, d2 = 0x7FFFFFFFu; // lane-local: smallest (dist<<16 | position), second smallest distance
+            for (int eb = 0; eb < c; eb += 64) {
+                const int e = eb + lane;
+                if (e < c) {
+                    const uint32_t en = eb == 0 ? en0 : eb == 64 ? en1 : entries[e0 + e];
+                    const unsigned f = en & 0xFFFF, d = (en >> 16) & 0x1FF;
+                    if (!(md[f] <= d)) {                                   // :470
+                        const unsigned key = (d << 16) | (unsigned)e;     // lists are shorter than 65536 (host check)
+                        if (key < k1) { d2 = k1 >> 16; k1 = key; }
+                        else if (d < d2) d2 = d;
+                    }
                 }
             }
-            __threadfence_block();
-            __builtin_amdgcn_wave_barrier();
+            if (k1 == 0xFFFFFFFFu) d2 = 0x7FFFFFFFu; else if (d2 == 0xFFFFu) d2 = 0x7FFFFFFFu;
+            const unsigned best = wave_min_u32(k1);
+            // second smallest over the wave: the winner lane contributes its own second, every other lane its first
+            const unsigned mine = (k1 == best) ? d2 : (k1 == 0xFFFFFFFFu ? 0x7FFFFFFFu : (k1 >> 16));
+            const unsigned second = wave_min_u32(mine);
+            if (best == 0xFFFFFFFFu) continue;
+            const int bd = (int)(best >> 16), be = (int)(best & 0xFFFF);
+            if (bd <= 50 && (float)bd < (float)(int)second * pp.nnratio) {  // TH_LOW (:485), ratio (:487)
+                // the winning entry sits in a register of lane be % 64 (chunks 0 / 1) or, beyond them, in memory
+                const uint32_t wen = be < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)en0, be) : be < 128 ? (uint32_t)__builtin_amdgcn_readlane((int)en1, be - 64) : entries[e0 + be];
+                const int f = (int)(wen & 0xFFFF);
+                if (lane == 0) {
+                    const int prev = (int)m21[f] - 1;
+                    if (prev >= 0) pt_choice[prev] = -1;                   // :489-493
+                    pt_choice[i1] = f; pt_dist[i1] = bd;
+                    m21[f] = (uint16_t)(i1 + 1); md[f] = (uint16_t)bd;
+                    if (pp.check_ori) {
+                        float rot = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(my_ang), j)) - fang[f];   // :501-509
+                        if (rot < 0.0f) rot += 360.0f;
+                        int bin = (int)roundf(rot * (1.0f / 30));
+                        if (bin == 30) bin = 0;
+                        bin = (unsigned)bin < 30u ? bin : 0;
+                        hist[bin]++; bins[i1] = bin;
+                    }
+                }
+                // lane 0's LDS writes before the next point's LDS reads: one wave, in-order LDS -- a compiler barrier is all it takes
+                // (the workgroup fence that stood here also waited for the global stores: a memory round trip per accepted match)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
         }
     }
     __threadfence_block();
@@ -542,7 +574,7 @@ static int proj_run(int device, const orbx_frame_feats *cur, const orbx_proj_poi
         ORBX_HIP(hipHostMalloc((void **)&c->h_out, sizeof(int32_t) * (nc + 2 * np + 8) * 2, hipHostMallocDefault));
         c->out_cap = (nc + 2 * np + 8) * 2;
     }
-    const size_t resolve_lds = pp.init_search ? 2 * sizeof(uint16_t) * ((nc + 7) & ~(size_t)7) + 16 : sizeof(int) * (nc + 4);
+    const size_t resolve_lds = pp.init_search ? (2 * sizeof(uint16_t) + sizeof(float)) * ((nc + 7) & ~(size_t)7) + 16 : sizeof(int) * (nc + 4);   // init: md, m21, the frame's angles
     if (resolve_lds > 150 * 1024 || (pp.init_search && np >= 65535)) { orbx_set_error("too many features for one search"); return ORBX_E_INVALID; }
     if (pp.init_search)
         ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_init_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)resolve_lds));
