@@ -84,12 +84,16 @@ __device__ void bitonic_sort_u64(unsigned long long *keys, int npad)
             if (need_barrier || stride > 64) __syncthreads();
             else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
             need_barrier = stride > 64;          // the next stage reads what other waves wrote in this one
-            for (int t = threadIdx.x; t < (npad >> 1); t += 256) {
+            for (int t = threadIdx.x; t < (npad >> 1); t += 512) {       // two pairs per trip: their four LDS reads travel together
+                const int t2 = t + 256;
+                const bool two = t2 < (npad >> 1);
                 const int lo = 2 * t - (t & (stride - 1)); // index with bit `stride` clear
                 const int hi = lo + stride;
-                const bool asc = (lo & size) == 0;
-                const unsigned long long a = keys[lo], b = keys[hi];
+                const int lo2 = two ? 2 * t2 - (t2 & (stride - 1)) : lo, hi2 = two ? lo2 + stride : hi;
+                const bool asc = (lo & size) == 0, asc2 = (lo2 & size) == 0;
+                const unsigned long long a = keys[lo], b = keys[hi], a2 = keys[lo2], b2 = keys[hi2];
                 if ((a > b) == asc) { keys[lo] = b; keys[hi] = a; }
+                if (two && (a2 > b2) == asc2) { keys[lo2] = b2; keys[hi2] = a2; }
             }
         }
     __syncthreads();
