@@ -844,8 +844,9 @@ static int match_call(int mode, int device, HSide *sides, int nsides, const int 
         tmp_total += (size_t)((nslots + 3) & ~3);
         out_total += mode == 2 ? 2 * (size_t)cap : (size_t)nslots;
         // items of a pair: one per shared node, plus (triangulation) the row splits of nodes above M_SPLIT_PAIRS (row, column) pairs:
-        // ceil(a / floor(S / b)) <= 2 a b / S + 1 per node
-        item_bound += (size_t)(A.nnodes < B.nnodes ? A.nnodes : B.nnodes) + (mode == 2 ? 2 * (size_t)A.m * (size_t)B.m / M_SPLIT_PAIRS : 0);
+        // ceil(a / floor(S / b)) <= 2 a b / S + 1 per node, and never more than one item per row
+        const size_t split = 2 * (size_t)A.m * (size_t)B.m / M_SPLIT_PAIRS;
+        item_bound += (size_t)(A.nnodes < B.nnodes ? A.nnodes : B.nnodes) + (mode == 2 ? (split < (size_t)A.m ? split : (size_t)A.m) : 0);
     }
     const size_t cnt_base = out_total;
     out_total += (size_t)npairs;
