@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void k_vocab_descend(const int *__restrict__ c
 }
 
 extern __shared__ __align__(16) unsigned char vocab_smem[];
+#define BOW_DUAL_MAX_NPAD 4096
 
 // in-LDS bitonic sort of npad (power of two) u64 keys by 256 threads, ascending.
 // Pair t of a stage is (lo, lo + stride) with lo = 2 t - (t & (stride - 1)); a wave takes the pairs t = 64 w + lane (+ 256 k): for strides
@@ -99,6 +100,96 @@ __device__ void bitonic_sort_u64(unsigned long long *keys, int npad)
     __syncthreads();
 }
 
+// The same network with the keys in REGISTERS: thread (wave w, lane l) holds the KPL consecutive elements [KPL (64 w + l), + KPL), npad = 256 KPL.
+// Strides below KPL exchange registers of one lane, strides below 64 KPL exchange lanes of one wave (two ds_bpermute per key: no memory, no
+// barrier), and only the strides of 64 KPL and more -- 3 of the 55 stages for 1024 keys -- go through LDS.  15.8 -> ~5 us per sort of 1024 keys.
+// NS independent key sets (k_bow_build sorts two: (node, feature) and (word, feature)) go through the network TOGETHER: with one wave per SIMD a
+// stage is a chain of dependent latencies, and the second set's instructions fill the first set's waits.
+template <int KPL, int NS>
+__device__ void bitonic_sort_u64_regs(unsigned long long *const (&keys)[NS])
+{
+    constexpr int NP = 256 * KPL;
+    const int lane = threadIdx.x & 63, base = (int)threadIdx.x * KPL;
+    unsigned long long k[NS][KPL];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NS; q++)
+#pragma unroll
+        for (int r = 0; r < KPL; r++) k[q][r] = keys[q][base + r];
+    // (a single wave per SIMD issues a dependent instruction every 5-8 cycles, so a stage has to be FEW instructions: the direction of a
+    // stage is formed once per lane -- every element of a lane has the same `size` bit once size > its KPL elements --, the partner's key
+    // comes by two raw ds_bpermute, and keeping the smaller / larger key is one 64-bit compare and two selects)
+    for (int size = 2; size <= NP; size <<= 1) {
+        const bool asc_lane = (base & size) == 0;
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride < KPL) {                  // partner = another register of this lane
+#pragma unroll
+                for (int s_ = 1; s_ < KPL; s_ <<= 1) {
+                    if (stride != s_) continue;
+#pragma unroll
+                    for (int r = 0; r < KPL; r++) {
+                        if (r & s_) continue;
+                        const bool asc = size < KPL ? (r & size) == 0 : asc_lane;      // (r & size: scalar)
+#pragma unroll
+                        for (int q = 0; q < NS; q++) {
+                            const unsigned long long a_ = k[q][r], b_ = k[q][r | s_];
+                            const bool sw = (a_ > b_) == asc;
+                            k[q][r] = sw ? b_ : a_; k[q][r | s_] = sw ? a_ : b_;
+                        }
+                    }
+                }
+            } else if (stride < 64 * KPL) {      // partner = the same register of lane ^ (stride / KPL)
+                const int d = stride / KPL;      // (KPL is a power of two: a shift)
+                const int paddr = (lane ^ d) << 2;
+                const bool keep_min = ((lane & d) == 0) == asc_lane;
+                unsigned long long o[NS][KPL];
+#pragma unroll
+                for (int q = 0; q < NS; q++)
+#pragma unroll
+                    for (int r = 0; r < KPL; r++) {
+                        const unsigned lo_ = (unsigned)__builtin_amdgcn_ds_bpermute(paddr, (int)(unsigned)k[q][r]);
+                        const unsigned hi_ = (unsigned)__builtin_amdgcn_ds_bpermute(paddr, (int)(unsigned)(k[q][r] >> 32));
+                        o[q][r] = ((unsigned long long)hi_ << 32) | lo_;
+                    }
+#pragma unroll
+                for (int q = 0; q < NS; q++)
+#pragma unroll
+                    for (int r = 0; r < KPL; r++) k[q][r] = ((o[q][r] < k[q][r]) == keep_min) ? o[q][r] : k[q][r];
+            } else {                             // partner in another wave: through LDS
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < NS; q++)
+#pragma unroll
+                    for (int r = 0; r < KPL; r++) keys[q][base + r] = k[q][r];
+                __syncthreads();
+                const bool keep_min = ((base & stride) == 0) == asc_lane;
+#pragma unroll
+                for (int q = 0; q < NS; q++)
+#pragma unroll
+                    for (int r = 0; r < KPL; r++) {
+                        const unsigned long long o = keys[q][(base + r) ^ stride];
+                        k[q][r] = ((o < k[q][r]) == keep_min) ? o : k[q][r];
+                    }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NS; q++)
+#pragma unroll
+        for (int r = 0; r < KPL; r++) keys[q][base + r] = k[q][r];
+    __syncthreads();
+}
+
+// both key sets of k_bow_build
+__device__ __forceinline__ void bow_sort2(unsigned long long *ka, unsigned long long *kb, int npad)
+{
+    unsigned long long *const both[2] = { ka, kb };
+    if (npad == 1024) bitonic_sort_u64_regs<4, 2>(both);         // ORB-SLAM2's 1000 features per frame
+    else if (npad == 2048) bitonic_sort_u64_regs<8, 2>(both);    // 2000 (KITTI settings)
+    else { bitonic_sort_u64(ka, npad); bitonic_sort_u64(kb, npad); }
+}
+
 __global__ __launch_bounds__(256) void k_bow_build(int n, int npad, const uint32_t *__restrict__ word_id,
                                                    const double *__restrict__ word_w, const uint32_t *__restrict__ node_id,
                                                    uint32_t *__restrict__ bow_id, double *__restrict__ bow_val, int *__restrict__ counts,
@@ -111,15 +202,20 @@ __global__ __launch_bounds__(256) void k_bow_build(int n, int npad, const uint32
         word_id += o; word_w += o; node_id += o; bow_id += o; bow_val += o; counts += 2 * blockIdx.x;
         fv_node_id += o; fv_node_off += (long long)blockIdx.x * (stride + 4); fv_feat += (long long)blockIdx.x * npad;
     }
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(vocab_smem);
-    int *flags = reinterpret_cast<int *>(keys + npad);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(vocab_smem);     // (node id, feature) keys, then reused for nothing else
+    const bool dual = npad <= BOW_DUAL_MAX_NPAD;                                         // both key sets in LDS at once (above: one after the other, 12 bytes per key)
+    unsigned long long *keys_w = dual ? keys + npad : keys;                              // (word id, feature) keys
+    int *flags = reinterpret_cast<int *>(keys_w + npad);
     __shared__ int s_w[4];
     __shared__ double s_norm;
     const int tid = threadIdx.x;
     // ---- FeatureVector: (node id, feature) ascending; stopped words (weight 0) are in no node (:1157)
-    for (int i = tid; i < npad; i += 256)
-        keys[i] = (i < n && word_w[i] > 0) ? (((unsigned long long)node_id[i] << 32) | (unsigned)i) : ~0ull;
-    bitonic_sort_u64(keys, npad);
+    for (int i = tid; i < npad; i += 256) {
+        const bool on = i < n && word_w[i] > 0;
+        keys[i] = on ? (((unsigned long long)node_id[i] << 32) | (unsigned)i) : ~0ull;
+        if (dual) keys_w[i] = on ? (((unsigned long long)word_id[i] << 32) | (unsigned)i) : ~0ull;
+    }
+    if (dual) bow_sort2(keys, keys_w, npad); else bitonic_sort_u64(keys, npad);
     for (int i = tid; i < npad; i += 256) {
         const bool valid = keys[i] != ~0ull;
         flags[i] = valid && (i == 0 || (keys[i] >> 32) != (keys[i - 1] >> 32));
@@ -138,9 +234,12 @@ __global__ __launch_bounds__(256) void k_bow_build(int n, int npad, const uint32
     if (tid == 0) { fv_node_off[nn] = m; counts[1] = nn; }
     __syncthreads();
     // ---- BowVector: (word id, feature) ascending; per word the weights are added in feature order
-    for (int i = tid; i < npad; i += 256)
-        keys[i] = (i < n && word_w[i] > 0) ? (((unsigned long long)word_id[i] << 32) | (unsigned)i) : ~0ull;
-    bitonic_sort_u64(keys, npad);
+    if (dual) keys = keys_w;     // (sorted above, together with the node keys)
+    else {
+        for (int i = tid; i < npad; i += 256)
+            keys[i] = (i < n && word_w[i] > 0) ? (((unsigned long long)word_id[i] << 32) | (unsigned)i) : ~0ull;
+        bitonic_sort_u64(keys, npad);
+    }
     for (int i = tid; i < npad; i += 256)
         flags[i] = keys[i] != ~0ull && (i == 0 || (keys[i] >> 32) != (keys[i - 1] >> 32));
     __syncthreads();
@@ -327,7 +426,7 @@ extern "C" int orbx_bow_transform(orbx_vocab *v, const uint8_t *desc, int n, int
     hipLaunchKernelGGL(k_vocab_descend, dim3((n + 255) / 256), dim3(256), 0, v->stream, v->d_child_off, v->d_child_ids, v->d_word_id,
                        v->d_desc, v->d_weight, (const uint32_t *)d, n, v->L - levelsup, (uint32_t *)(d + o_word), (double *)(d + o_w),
                        (uint32_t *)(d + o_nid), nullptr, 0);
-    const size_t lds = (size_t)npad * 12 + 64;
+    const size_t lds = (size_t)npad * (npad <= BOW_DUAL_MAX_NPAD ? 20 : 12) + 64;     // key sets (u64: both at once up to BOW_DUAL_MAX_NPAD keys) + flags (int)
     ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_bow_build, dim3(1), dim3(256), lds, v->stream, n, npad, (const uint32_t *)(d + o_word), (const double *)(d + o_w),
                        (const uint32_t *)(d + o_nid), (uint32_t *)(d + o_bid), (double *)(d + o_bval), (int *)(d + o_cnt),
@@ -442,7 +541,7 @@ extern "C" int orbx_bow_transform_batch_device(orbx_vocab *v, orbx_bow_frames *f
     hipLaunchKernelGGL(k_vocab_descend, dim3((cap + 255) / 256, batch), dim3(256), 0, s, v->d_child_off, v->d_child_ids, v->d_word_id,
                        v->d_desc, v->d_weight, (const uint32_t *)d_desc, 0, v->L - levelsup, f->word_id, f->word_w, f->node_id,
                        (const int *)d_n, cap);
-    const size_t lds = (size_t)npad * 12 + 64;
+    const size_t lds = (size_t)npad * (npad <= BOW_DUAL_MAX_NPAD ? 20 : 12) + 64;     // key sets (u64: both at once up to BOW_DUAL_MAX_NPAD keys) + flags (int)
     ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_bow_build, dim3(batch), dim3(256), lds, s, 0, npad, f->word_id, f->word_w, f->node_id, f->bow_id, f->bow_val,
                        f->counts, f->fv_node_id, f->fv_node_off, f->fv_feat, (const int *)d_n, cap);

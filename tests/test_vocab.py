@@ -91,7 +91,7 @@ def _cmp(a, b):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,L,levelsup,n", [(10, 3, 1, 1000), (10, 4, 2, 2003), (4, 5, 4, 300), (10, 3, 0, 64), (3, 2, 5, 17)])
+@pytest.mark.parametrize("k,L,levelsup,n", [(10, 3, 1, 1000), (10, 4, 2, 2003), (4, 5, 4, 300), (10, 3, 0, 64), (3, 2, 5, 17), (10, 4, 2, 5000), (10, 4, 1, 4096)])
 def test_hip_transform_parity(pkg, oracle, k, L, levelsup, n):
     data = _data(5, n)
     par, leaf, nd, w = synth.vocab_tree(6, k, L, stop_frac=0.05, data=data)
