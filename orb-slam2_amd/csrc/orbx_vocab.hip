@@ -16,7 +16,7 @@
 
 struct orbx_vocab {
     int device, k, L, nnodes, nwords;
-    int *d_child_off, *d_child_ids, *d_word_id;
+    int *d_child_off, *d_child_ids, *d_word_id;      // breadth-first node order on the device; d_child_ids holds orig_id[] (device node -> DBoW2 node id)
     uint32_t *d_desc;
     double *d_weight;
     hipStream_t stream;
@@ -26,12 +26,17 @@ struct orbx_vocab {
     uint8_t *h_out; size_t h_out_cap;
 };
 
-__global__ __launch_bounds__(256) void k_vocab_descend(const int *__restrict__ child_off, const int *__restrict__ child_ids,
+// The vocabulary lives on the device in BREADTH-FIRST order (vocab_build): the children of a node are consecutive nodes, child number c of the
+// concatenated child lists is node c + 1, and child_off[] (first child list position of a node) is monotonic.  One memory round trip per level then
+// carries everything the next step needs: the ten children's descriptors AND their own child ranges (eleven consecutive child_off entries) --
+// the walk through separate child-id and offset arrays was three dependent round trips per level, the child-by-child loop before it sixty.
+// orig_id[] maps back to DBoW2's node ids (the FeatureVector's node ids, TemplatedVocabulary.h:1228).
+__global__ __launch_bounds__(256) void k_vocab_descend(const int *__restrict__ child_off, const int *__restrict__ orig_id,
                                                        const int *__restrict__ word_of, const uint32_t *__restrict__ ndesc,
                                                        const double *__restrict__ nweight, const uint32_t *__restrict__ feat,
                                                        int n, int nid_level, uint32_t *__restrict__ word_id,
                                                        double *__restrict__ word_w, uint32_t *__restrict__ node_id,
-                                                       const int *__restrict__ n_dev, int stride)
+                                                       const int *__restrict__ n_dev, int stride, int nnodes)
 {
     // batched form: grid.y = frame, n = n_dev[frame], arrays strided by `stride` features per frame
     if (n_dev) {
@@ -39,7 +44,8 @@ __global__ __launch_bounds__(256) void k_vocab_descend(const int *__restrict__ c
         n = min(n_dev[blockIdx.y], stride);
         feat += o * 8; word_id += o; word_w += o; node_id += o;
     }
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;    // (64-thread workgroups: a frame's 1000 features on 16 CUs, not 4 -- the descent is bound by
+                                                             // the cache-line rate of a CU's vector memory path: 64 scattered lines per load instruction)
     if (i >= n) return;
     uint32_t f[8];
     {
@@ -48,25 +54,36 @@ __global__ __launch_bounds__(256) void k_vocab_descend(const int *__restrict__ c
         f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
     }
     int nid = 0, node = 0, level = 0; // nid stays 0 (root) when nid_level <= 0 (:1228)
+    int c0 = child_off[0], c1 = child_off[1];
     for (;;) {
         ++level;
-        const int c0 = child_off[node], c1 = child_off[node + 1];
-        int best = child_ids[c0], best_d = 0x7FFFFFFF;
-        for (int c = c0; c < c1; c++) {
-            const int id = child_ids[c];
-            const uint4 *s = reinterpret_cast<const uint4 *>(ndesc + (long long)id * 8);
-            const uint4 v0 = s[0], v1 = s[1];
-            const int d = __popc(f[0] ^ v0.x) + __popc(f[1] ^ v0.y) + __popc(f[2] ^ v0.z) + __popc(f[3] ^ v0.w) +
-                          __popc(f[4] ^ v1.x) + __popc(f[5] ^ v1.y) + __popc(f[6] ^ v1.z) + __popc(f[7] ^ v1.w);
-            if (d < best_d) { best_d = d; best = id; } // first minimum wins (:1238-1249)
+        // children ten at a time (DBoW2's k; ORBvoc has k = 10)
+        int best = -1, best_d = 0x7FFFFFFF, b0 = 0, b1 = 0;
+        for (int cb = c0; cb < c1; cb += 10) {
+            int co[11];
+            uint4 v0[10], v1[10];
+#pragma unroll
+            for (int j = 0; j < 11; j++) co[j] = child_off[min(cb + 1 + j, nnodes)];
+#pragma unroll
+            for (int j = 0; j < 10; j++) {
+                const uint4 *s = reinterpret_cast<const uint4 *>(ndesc + (long long)(cb + j < c1 ? cb + 1 + j : 0) * 8);
+                v0[j] = s[0]; v1[j] = s[1];
+            }
+#pragma unroll
+            for (int j = 0; j < 10; j++) {
+                const int d = __popc(f[0] ^ v0[j].x) + __popc(f[1] ^ v0[j].y) + __popc(f[2] ^ v0[j].z) + __popc(f[3] ^ v0[j].w) +
+                              __popc(f[4] ^ v1[j].x) + __popc(f[5] ^ v1[j].y) + __popc(f[6] ^ v1[j].z) + __popc(f[7] ^ v1[j].w);
+                if (cb + j < c1 && d < best_d) { best_d = d; best = cb + 1 + j; b0 = co[j]; b1 = co[j + 1]; } // first minimum wins (:1238-1249)
+            }
         }
         node = best;
         if (level == nid_level) nid = node;
-        if (child_off[node + 1] <= child_off[node]) break; // isLeaf(): no children
+        if (b1 <= b0) break; // isLeaf(): no children
+        c0 = b0; c1 = b1;
     }
     word_id[i] = (uint32_t)word_of[node];
     word_w[i] = nweight[node];
-    node_id[i] = (uint32_t)nid;
+    node_id[i] = (uint32_t)orig_id[nid];
 }
 
 extern __shared__ __align__(16) unsigned char vocab_smem[];
@@ -310,6 +327,23 @@ static int vocab_build(int device, int k, int L, int nm1, const int32_t *parent,
     std::vector<uint8_t> d((size_t)n * 32, 0);
     for (int i = 1; i < n; i++) w[i] = weight[i - 1];
     memcpy(d.data() + 32, desc, (size_t)nm1 * 32);
+    {   // breadth-first renumbering for the device (see k_vocab_descend): order[p] = DBoW2 id of device node p; a node's children, in id order, are
+        // consecutive device nodes, and child number c of the concatenated lists is device node c + 1
+        std::vector<int> order; order.reserve(n); order.push_back(0);
+        for (size_t q = 0; q < order.size(); q++) { const int x = order[q]; for (int c = off[x]; c < off[x + 1]; c++) order.push_back(ids[c]); }
+        if ((int)order.size() != n) { orbx_set_error("vocabulary: %d of %d nodes reachable from the root", (int)order.size(), n); return ORBX_E_INVALID; }
+        std::vector<int> noff(n + 1, 0), nword(n);
+        std::vector<double> nw(n);
+        std::vector<uint8_t> nd((size_t)n * 32);
+        for (int p = 0; p < n; p++) {
+            const int x = order[p];
+            noff[p + 1] = noff[p] + (off[x + 1] - off[x]);
+            nword[p] = word[x]; nw[p] = w[x];
+            memcpy(nd.data() + 32 * (size_t)p, d.data() + 32 * (size_t)x, 32);
+        }
+        off.swap(noff); word.swap(nword); w.swap(nw); d.swap(nd);
+        ids.assign(order.begin(), order.end());      // uploaded as orig_id[]: device node -> DBoW2 node id
+    }
     ORBX_HIP(hipSetDevice(device));
     orbx_vocab *v = new orbx_vocab();
     memset(v, 0, sizeof *v);
@@ -423,9 +457,9 @@ extern "C" int orbx_bow_transform(orbx_vocab *v, const uint8_t *desc, int n, int
     }
     uint8_t *d = v->d_in;
     ORBX_HIP(hipMemcpyAsync(d, desc, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
-    hipLaunchKernelGGL(k_vocab_descend, dim3((n + 255) / 256), dim3(256), 0, v->stream, v->d_child_off, v->d_child_ids, v->d_word_id,
+    hipLaunchKernelGGL(k_vocab_descend, dim3((n + 63) / 64), dim3(64), 0, v->stream, v->d_child_off, v->d_child_ids, v->d_word_id,
                        v->d_desc, v->d_weight, (const uint32_t *)d, n, v->L - levelsup, (uint32_t *)(d + o_word), (double *)(d + o_w),
-                       (uint32_t *)(d + o_nid), nullptr, 0);
+                       (uint32_t *)(d + o_nid), nullptr, 0, v->nnodes);
     const size_t lds = (size_t)npad * (npad <= BOW_DUAL_MAX_NPAD ? 20 : 12) + 64;     // key sets (u64: both at once up to BOW_DUAL_MAX_NPAD keys) + flags (int)
     ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_bow_build, dim3(1), dim3(256), lds, v->stream, n, npad, (const uint32_t *)(d + o_word), (const double *)(d + o_w),
@@ -538,9 +572,9 @@ extern "C" int orbx_bow_transform_batch_device(orbx_vocab *v, orbx_bow_frames *f
     hipStream_t s = stream ? (hipStream_t)stream : v->stream;
     f->last_stream = s;
     const int cap = f->cap, npad = f->npad;
-    hipLaunchKernelGGL(k_vocab_descend, dim3((cap + 255) / 256, batch), dim3(256), 0, s, v->d_child_off, v->d_child_ids, v->d_word_id,
+    hipLaunchKernelGGL(k_vocab_descend, dim3((cap + 63) / 64, batch), dim3(64), 0, s, v->d_child_off, v->d_child_ids, v->d_word_id,
                        v->d_desc, v->d_weight, (const uint32_t *)d_desc, 0, v->L - levelsup, f->word_id, f->word_w, f->node_id,
-                       (const int *)d_n, cap);
+                       (const int *)d_n, cap, v->nnodes);
     const size_t lds = (size_t)npad * (npad <= BOW_DUAL_MAX_NPAD ? 20 : 12) + 64;     // key sets (u64: both at once up to BOW_DUAL_MAX_NPAD keys) + flags (int)
     ORBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bow_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_bow_build, dim3(batch), dim3(256), lds, s, 0, npad, f->word_id, f->word_w, f->node_id, f->bow_id, f->bow_val,
