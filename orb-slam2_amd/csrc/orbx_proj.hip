@@ -187,24 +187,39 @@ __global__ __launch_bounds__(256) void k_proj_lists(DevFrame F, DevPoints P, Pro
     Win w;
     int n = 0, base = 0;
     if (point_window(F, P, pp, i, &w)) {
-        int upper = 0;
-        for (int ix = w.cx0; ix <= w.cx1; ix++) upper += cell_off[ix * PG_ROWS + w.cy1 + 1] - cell_off[ix * PG_ROWS + w.cy0];
+        // The window's cells are, per grid column, one contiguous run of the CSR (cells are stored column by column): lane q fetches the run of
+        // column cx0 + q (the grid has 64 columns), a wave prefix sum flattens the runs, and the candidates are then taken 64 at a time ACROSS
+        // columns -- in the order the column-by-column walk had (the list order decides ties downstream).  That walk was four dependent memory
+        // round trips per column; this is four per point.
+        const int ncol = w.cx1 - w.cx0 + 1;
+        int c_lo = 0, c_n = 0;
+        if (lane < ncol) {
+            const int ix = w.cx0 + lane;
+            c_lo = cell_off[ix * PG_ROWS + w.cy0];
+            c_n = cell_off[ix * PG_ROWS + w.cy1 + 1] - c_lo;
+        }
+        const int c_incl = wave_incl_scan(c_n), c_excl = c_incl - c_n;
+        const int upper = __builtin_amdgcn_readlane(c_incl, 63);
         if (upper) {
             if (lane == 0) base = atomicAdd(pool_used, upper);
-            base = __shfl(base, 0, WAVE);
+            base = __builtin_amdgcn_readfirstlane(base);
         }
         if (upper && base + upper <= pool_cap) {
             uint32_t d[8];
             const uint4 *s = reinterpret_cast<const uint4 *>(P.desc + (long long)i * 8);
             const uint4 q0 = s[0], q1 = s[1];
             d[0] = q0.x; d[1] = q0.y; d[2] = q0.z; d[3] = q0.w; d[4] = q1.x; d[5] = q1.y; d[6] = q1.z; d[7] = q1.w;
-            for (int ix = w.cx0; ix <= w.cx1; ix++) {
-                const int j0 = cell_off[ix * PG_ROWS + w.cy0], j1 = cell_off[ix * PG_ROWS + w.cy1 + 1];
-                for (int jb = j0; jb < j1; jb += 64) {
-                    const int j = jb + lane;
+            {
+                for (int jb = 0; jb < upper; jb += 64) {
+                    const int jf = jb + lane;            // position in the flattened candidate sequence
+                    int j = -1;
+                    for (int q = 0; q < ncol; q++) {     // which column's run holds it (a handful of columns; their runs ride in lanes 0 .. ncol - 1)
+                        const int e_ = __builtin_amdgcn_readlane(c_excl, q), n_ = __builtin_amdgcn_readlane(c_n, q), l_ = __builtin_amdgcn_readlane(c_lo, q);
+                        if (jf >= e_ && jf < e_ + n_) j = l_ + (jf - e_);
+                    }
                     bool ok = false;
                     uint32_t en = 0;
-                    if (j < j1) {
+                    if (jf < upper) {
                         const int k = cell_idx[j];
                         if (cand_ok(F, P, pp, w, i, k)) {
                             ok = true;
