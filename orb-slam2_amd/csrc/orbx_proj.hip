@@ -160,6 +160,7 @@ __device__ __forceinline__ bool point_window(const DevFrame &F, const DevPoints 
 // claim-independent part of the candidate test: level range, box, right-image coordinate
 __device__ __forceinline__ bool cand_ok(const DevFrame &F, const DevPoints &P, const ProjParams &pp, const Win &w, int i, int k)
 {
+    if (pp.claims && F.occupied[k]) return false;   // the feature holds an observed map point: skipped by every point (:80-82, :1453-1455); filtered here, once, not in every round of the resolve kernel
     const int oct = F.octave[k];
     if (w.min_l > 0 || w.max_l >= 0) { // bCheckLevels (:408)
         if (oct < w.min_l) return false;
@@ -293,12 +294,19 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(DevFrame F, DevPoints P, 
         for (int i = stable + tid; i < P.n; i += nt) {
             int b1 = 256, b2 = 256, l1 = -1, l2 = -1, bi = -1;
             const int e0 = beg[i], e1 = e0 + cnt[i];
-            for (int e = e0; e < e1; e++) {
-                const uint32_t en = entries[e];
-                const int f = en & 0xFFFF, dist = (en >> 16) & 0x1FF, lv = en >> 25;
-                if (pp.claims && (F.occupied[f] || owner[f] < i)) continue; // the feature is held (see ProjParams::claims)
-                if (dist < b1) { b2 = b1; l2 = l1; b1 = dist; l1 = lv; bi = f; }
-                else if (dist < b2) { b2 = dist; l2 = lv; }
+            for (int eb = e0; eb < e1; eb += 8) {      // eight entries per trip: their loads travel together (one by one the walk was a memory round trip per entry and round)
+                uint32_t en8[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) en8[q] = eb + q < e1 ? entries[eb + q] : 0xFFFFFFFFu;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint32_t en = en8[q];
+                    if (eb + q >= e1) break;
+                    const int f = en & 0xFFFF, dist = (en >> 16) & 0x1FF, lv = en >> 25;
+                    if (pp.claims && owner[f] < i) continue; // the feature is held by an earlier point (see ProjParams::claims; occupied features never enter the lists)
+                    if (dist < b1) { b2 = b1; l2 = l1; b1 = dist; l1 = lv; bi = f; }
+                    else if (dist < b2) { b2 = dist; l2 = lv; }
+                }
             }
             int c = -1;
             if (b1 <= pp.max_dist) {
